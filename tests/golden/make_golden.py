@@ -1,0 +1,330 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference and `make -C oracle ref`);
+the fixtures it writes (*.npz: inputs, weights, expected outputs) are committed,
+this script is the record of how they were made.  Nothing here ships.
+
+How the reference is imported:
+  * models/components/balltree is the compiled Cython extension built by
+    oracle/Makefile (`ref` target) from the sources where they lie.
+  * third-party packages the image lacks are replaced by in-process stand-ins
+    *for import only*:  timm.models.layers.trunc_normal_ -> torch.nn.init's;
+    torch_cluster / torch_scatter -> stubs that raise if called (unreachable:
+    embed=False, mp_steps=0);  flash_attn.flash_attn_qkvpacked_func -> exact
+    softmax(QK^T*scale)V (flash-attention's published contract).
+  * precision: BallMSA.forward casts its weights with `.to(torch.float16)`
+    (attention.py:43-56), which cannot run on fp32 CPU inputs.  The attention
+    module's global name `torch` is replaced by a proxy whose `float16` IS
+    `torch.float32`, so the reference's own forward statements run unmodified,
+    in fp32 ("oracle mode A" of SURVEY.md 8c).
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("HAET_REFERENCE", "/root/reference")
+
+
+def _install_import_stand_ins():
+    timm = types.ModuleType("timm")
+    timm_models = types.ModuleType("timm.models")
+    timm_layers = types.ModuleType("timm.models.layers")
+    timm_layers.trunc_normal_ = torch.nn.init.trunc_normal_
+    timm.models, timm_models.layers = timm_models, timm_layers
+    sys.modules.update({"timm": timm, "timm.models": timm_models, "timm.models.layers": timm_layers})
+
+    fa = types.ModuleType("flash_attn")
+
+    def flash_attn_qkvpacked_func(qkv, dropout_p=0.0, softmax_scale=None, causal=False):
+        assert dropout_p == 0.0 and not causal
+        q, k, v = (t.permute(0, 2, 1, 3) for t in qkv.unbind(2))  # [nb, h, n, hd]
+        return F.scaled_dot_product_attention(q, k, v, scale=softmax_scale).permute(0, 2, 1, 3)
+
+    fa.flash_attn_qkvpacked_func = flash_attn_qkvpacked_func
+    sys.modules["flash_attn"] = fa
+
+    def _unreachable(*a, **k):
+        raise NotImplementedError("unreachable on the PhysicsAttention path (embed=False, mp_steps=0)")
+
+    tc = types.ModuleType("torch_cluster")
+    tc.radius_graph = _unreachable
+    ts = types.ModuleType("torch_scatter")
+    ts.scatter_mean = _unreachable
+    sys.modules.update({"torch_cluster": tc, "torch_scatter": ts})
+
+
+def import_reference():
+    _install_import_stand_ins()
+    sys.path[:0] = [os.path.join(ROOT, "oracle", "_ref"), REF]
+    import models  # noqa: the reference package
+    from models.components.erwinflash.components import attention as ref_attention
+
+    class _TorchFp32Proxy:
+        float16 = torch.float32
+
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+    ref_attention.torch = _TorchFp32Proxy()
+    return models
+
+
+# --------------------------------------------------------------------------- capture helpers
+def capture_tree(models):
+    """Wrap build_balltree_with_rotations where ErwinTransformer looks it up and keep a
+    copy of what it returned (the caller pops the rot list empty, erwin_flash.py:184,187)."""
+    from models.components.erwinflash import erwin_flash
+
+    store = {}
+    orig = erwin_flash.build_balltree_with_rotations
+
+    def wrapped(*a, **k):
+        ti, tm, rots = orig(*a, **k)
+        store["tree_idx"], store["tree_mask"] = ti.clone(), tm.clone()
+        for i, r in enumerate(rots):
+            if r is not None:
+                store[f"rot{i}"] = r.clone()
+        return ti, tm, rots
+
+    erwin_flash.build_balltree_with_rotations = wrapped
+    return store
+
+
+def run_attention(mod, x, tree_store):
+    cap = {}
+    hooks = []
+
+    def hk(name, idx=None):
+        def f(m, inp, out):
+            cap[name] = out.detach().clone()
+        return f
+
+    hooks.append(mod.in_project_x.register_forward_hook(hk("x_lin_raw")))
+    hooks.append(mod.erwin.register_forward_hook(hk("processed_flat")))
+    hooks.append(mod.erwin.register_forward_pre_hook(
+        lambda m, inp: cap.update(eidetic_flat=inp[0].detach().clone(), pos=inp[1].detach().clone(),
+                                  batch_idx=inp[2].detach().clone())))
+    n_enc = len(mod.erwin.encoder)
+    for i, layer in enumerate(mod.erwin.encoder):
+        for j, blk in enumerate(layer.blocks):
+            hooks.append(blk.register_forward_hook(hk(f"erwin.enc{i}.block{j}")))
+        hooks.append(layer.pool.register_forward_hook(
+            lambda m, inp, out, i=i: cap.update({f"erwin.enc{i}.pool": out.x.detach().clone()})))
+    for j, blk in enumerate(mod.erwin.bottleneck.blocks):
+        hooks.append(blk.register_forward_hook(hk(f"erwin.bott.block{j}")))
+    for k, layer in enumerate(mod.erwin.decoder):
+        hooks.append(layer.unpool.register_forward_hook(
+            lambda m, inp, out, k=k: cap.update({f"erwin.dec{k}.unpool": out.x.detach().clone()})))
+        for j, blk in enumerate(layer.blocks):
+            hooks.append(blk.register_forward_hook(hk(f"erwin.dec{k}.block{j}")))
+    tree_store.clear()
+    out = mod(x)
+    for h in hooks:
+        h.remove()
+    cap["out"] = out.detach().clone()
+    cap.update({"erwin." + k: v for k, v in tree_store.items()})
+    # rotated blocks are hooked in ROTATED order (layers.py:86-88): un-permute to tree order
+    for key in list(cap):
+        if key.endswith("block1"):
+            lvl = key.split(".")[1]
+            rk = "erwin.rot1" if lvl == "bott" else "erwin.rot0"
+            if rk in cap:
+                cap[key] = cap[key][torch.argsort(cap[rk])]
+    return cap
+
+
+def amplify(mod, gen, scale=10.0):
+    """Make every Erwin op numerically visible: scale the Erwin
+    matrices, give every bias / norm weight / BN statistic a non-trivial value."""
+    with torch.no_grad():
+        for name, p in mod.named_parameters():
+            if name.startswith("erwin.") and p.dim() == 2:
+                p.mul_(scale)
+            elif name.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=gen))
+            elif name.startswith("erwin.") and "norm" in name and name.endswith("weight"):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=gen))
+        for name, b in mod.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn(b.shape, generator=gen))
+            elif name.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=gen))
+
+
+def model_init_rule(mod):
+    """Model._init_weights (HAETransolver_Irregular_Mesh.py:279-295) applied to a bare module."""
+    import torch.nn as nn
+
+    for m in mod.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, (nn.LayerNorm, nn.BatchNorm1d)):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+
+def to_np(d):
+    out = {}
+    for k, v in d.items():
+        v = v.detach().cpu() if torch.is_tensor(v) else torch.as_tensor(v)
+        out[k] = v.numpy()
+    return out
+
+
+ATTN_CASES = [
+    # name, kind, ctor kwargs, N / grid, weights, train
+    ("irr_small_default", "irregular", dict(dim=64, heads=4, dim_head=16, slice_num=8, rotate=45), 512, "default", False),
+    ("irr_small_amp", "irregular", dict(dim=64, heads=4, dim_head=16, slice_num=16, rotate=45), 777, "amp", False),
+    ("irr_small_amp_train", "irregular", dict(dim=64, heads=4, dim_head=16, slice_num=16, rotate=45), 600, "amp", True),
+    ("irr_c2like_amp", "irregular", dict(dim=128, heads=4, dim_head=64, slice_num=32, rotate=45), 1500, "amp", False),
+    ("irr_c3like_model", "irregular", dict(dim=256, heads=8, dim_head=32, slice_num=64, rotate=45), 1024, "model", False),
+    ("irr_c3like_amp", "irregular", dict(dim=256, heads=8, dim_head=32, slice_num=64, rotate=45), 1024, "amp", False),
+    ("irr_m128_amp", "irregular", dict(dim=64, heads=8, dim_head=32, slice_num=128, rotate=45), 640, "amp", False),
+    ("irr_norot_amp", "irregular", dict(dim=64, heads=4, dim_head=16, slice_num=16, rotate=0), 300, "amp", False),
+    ("irr_b2_amp", "irregular", dict(dim=64, heads=4, dim_head=16, slice_num=16, rotate=45), 400, "amp", False),
+    ("irr_nonpow2_amp", "irregular", dict(dim=64, heads=4, dim_head=16, slice_num=12, rotate=45, ball_sizes=[16, 8]), 333, "amp", False),
+    ("s2d_c1like_amp", "structured2d", dict(dim=64, heads=4, dim_head=16, slice_num=8, H=16, W=16, rotate=45), (16, 16), "amp", False),
+    ("s3d_c5like_amp", "structured3d", dict(dim=64, heads=4, dim_head=16, slice_num=16, H=8, W=8, D=8, rotate=45), (8, 8, 8), "amp", False),
+]
+
+
+def gen_attention_fixtures(models, tree_store):
+    from models.PhysicsAttention import (Physics_Attention_Irregular_Mesh,
+                                         Physics_Attention_Structured_Mesh_2D,
+                                         Physics_Attention_Structured_Mesh_3D)
+
+    ctor = {"irregular": Physics_Attention_Irregular_Mesh,
+            "structured2d": Physics_Attention_Structured_Mesh_2D,
+            "structured3d": Physics_Attention_Structured_Mesh_3D}
+    for ci, (name, kind, kw, n, weights, train) in enumerate(ATTN_CASES):
+        torch.manual_seed(100 + ci)
+        gen = torch.Generator().manual_seed(1000 + ci)
+        mod = ctor[kind](**kw)
+        if weights == "model":
+            model_init_rule(mod)
+        elif weights == "amp":
+            amplify(mod, gen)
+        mod.train(train)
+        N = n if isinstance(n, int) else int(np.prod(n))
+        B = 2 if "b2" in name else 1
+        # fp16-representable inputs keep the fixture small and exactly reproducible
+        x = torch.randn(B, N, kw["dim"], generator=gen).half().float()
+        sd = {k: v.clone() for k, v in mod.state_dict().items()}  # BEFORE forward (BN stats move in train)
+        with torch.no_grad():
+            cap = run_attention(mod, x, tree_store)
+        meta = dict(kind=kind, kw=kw, grid=(n if not isinstance(n, int) else ()), train=train, B=B, N=N)
+        arrays = {"x": x.half().numpy()}
+        arrays.update({"sd/" + k: v for k, v in to_np(sd).items()})
+        keep_rows = 48  # per-point tensors: keep a strided sample of rows + the full final output
+        rows = torch.linspace(0, N - 1, keep_rows).long()
+        arrays["rows"] = rows.numpy()
+        arrays["exp/x_lin_rows"] = _xlin_rows(cap["x_lin_raw"], kind, B, N).index_select(1, rows).numpy()
+        for k, v in cap.items():
+            if k in ("x_lin_raw",):
+                continue
+            arrays["exp/" + k] = v.numpy()
+        arrays["meta"] = np.frombuffer(repr(meta).encode(), dtype=np.uint8)
+        path = os.path.join(HERE, f"attn_{name}.npz")
+        np.savez_compressed(path, **arrays)
+        print(f"{path}: {os.path.getsize(path)/1e6:.2f} MB  out_norm={cap['out'].norm():.4f}")
+
+
+def _xlin_rows(raw, kind, B, N):
+    if kind == "irregular":
+        return raw
+    if kind == "structured2d":
+        return raw.permute(0, 2, 3, 1).reshape(B, N, -1)
+    return raw.permute(0, 2, 3, 4, 1).reshape(B, N, -1)
+
+
+MODEL_CASES = [
+    ("irr", "HAETransolver_Irregular_Mesh", dict(space_dim=3, fun_dim=4, n_hidden=64, n_layers=2, n_head=4, mlp_ratio=2, out_dim=4, slice_num=16), 500, True),
+    ("irr_nofx", "HAETransolver_Irregular_Mesh", dict(space_dim=3, fun_dim=0, n_hidden=64, n_layers=1, n_head=4, mlp_ratio=1, out_dim=1, slice_num=8), 300, False),
+    ("s2d", "HAETransolver_Structured_Mesh_2D", dict(space_dim=2, fun_dim=1, n_hidden=64, n_layers=1, n_head=8, out_dim=1, slice_num=8, H=16, W=16), 256, True),
+    ("s3d", "HAETransolver_Structured_Mesh_3D", dict(space_dim=3, fun_dim=1, n_hidden=64, n_layers=1, n_head=4, out_dim=1, slice_num=16, H=8, W=8, D=8), 512, True),
+]
+
+
+def gen_model_fixtures(models):
+    for ci, (name, cls, kw, N, with_fx) in enumerate(MODEL_CASES):
+        torch.manual_seed(200 + ci)
+        gen = torch.Generator().manual_seed(2000 + ci)
+        model = getattr(models, cls)(**kw).eval()
+        for blk in model.blocks:
+            amplify(blk.Attn, gen)
+        x = torch.rand(1, N, kw["space_dim"], generator=gen).half().float()
+        fx = torch.rand(1, N, kw["fun_dim"], generator=gen).half().float() if with_fx else None
+        with torch.no_grad():
+            out = model(x, fx)
+        arrays = {"x": x.numpy(), "out": out.numpy()}
+        if fx is not None:
+            arrays["fx"] = fx.numpy()
+        arrays.update({"sd/" + k: v for k, v in to_np(model.state_dict()).items()})
+        arrays["meta"] = np.frombuffer(repr(dict(cls=cls, kw=kw, N=N)).encode(), dtype=np.uint8)
+        path = os.path.join(HERE, f"model_{name}.npz")
+        np.savez_compressed(path, **arrays)
+        print(f"{path}: {os.path.getsize(path)/1e6:.2f} MB  out_norm={out.norm():.4f}")
+
+
+def gen_tree_fixtures():
+    """Tree-only fixtures straight from the reference's Python entry point
+    (balltree.build_balltree_with_rotations, balltree.pyx:598-662)."""
+    import balltree as ref_bt  # oracle/_ref/balltree*.so
+
+    rng = np.random.default_rng(7)
+    cases = []
+    for M in (2, 5, 6, 8, 12, 16, 32, 64, 128):
+        for d in (2, 3):
+            for kind in ("rand", "ties", "grid", "line"):
+                for rep in range(6):
+                    nb = int(rng.integers(1, 5))
+                    T = nb * M
+                    if kind == "rand":
+                        p = rng.random((T, d))
+                    elif kind == "ties":
+                        p = rng.integers(0, 3, (T, d)).astype(np.float64)
+                    elif kind == "grid":
+                        p = np.round(rng.random((T, d)) * 4) / 4
+                    else:
+                        p = rng.random((T, d))
+                        p[:, 1:] = 0.25
+                    cases.append((M, d, nb, p.astype(np.float32)))
+    out = {}
+    for i, (M, d, nb, p) in enumerate(cases):
+        bidx = torch.arange(nb).repeat_interleave(M)
+        pow2 = (M & (M - 1)) == 0
+        ball_sizes = [min(32, M), max(1, min(16, M // 2))]
+        angle = 45.0 if pow2 else 0.0
+        ti, tm, rots = ref_bt.build_balltree_with_rotations(torch.from_numpy(p), bidx, [2], ball_sizes, angle)
+        out[f"{i}/pos"] = p
+        out[f"{i}/M"] = np.int64(M)
+        out[f"{i}/nb"] = np.int64(nb)
+        out[f"{i}/angle"] = np.float64(angle)
+        out[f"{i}/tree_idx"] = ti.numpy()
+        out[f"{i}/tree_mask"] = tm.numpy()
+        for j, r in enumerate(rots):
+            if r is not None:
+                out[f"{i}/rot{j}"] = r.numpy()
+    out["count"] = np.int64(len(cases))
+    path = os.path.join(HERE, "tree_cases.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: {len(cases)} cases, {os.path.getsize(path)/1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    models = import_reference()
+    store = capture_tree(models)
+    gen_tree_fixtures()
+    gen_attention_fixtures(models, store)
+    gen_model_fixtures(models)

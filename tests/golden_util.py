@@ -1,0 +1,62 @@
+"""Helpers to read the committed golden fixtures (tests/golden/*.npz, made by
+tests/golden/make_golden.py from the reference itself)."""
+import ast
+import glob
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def attn_fixture_names():
+    return sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN, "attn_*.npz")))
+
+
+def model_fixture_names():
+    return sorted(os.path.basename(p)[6:-4] for p in glob.glob(os.path.join(GOLDEN, "model_*.npz")))
+
+
+def _meta(z):
+    return ast.literal_eval(bytes(z["meta"]).decode())
+
+
+def load_attn(name):
+    z = np.load(os.path.join(GOLDEN, f"attn_{name}.npz"))
+    meta = _meta(z)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    exp = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("exp/")}
+    x = torch.from_numpy(z["x"].astype(np.float32))
+    rows = torch.from_numpy(z["rows"])
+    return x, sd, meta, exp, rows
+
+
+def load_model(name):
+    z = np.load(os.path.join(GOLDEN, f"model_{name}.npz"))
+    meta = _meta(z)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    x = torch.from_numpy(z["x"])
+    fx = torch.from_numpy(z["fx"]) if "fx" in z.files else None
+    return x, fx, sd, meta, torch.from_numpy(z["out"])
+
+
+def oracle_cfg_from_meta(meta):
+    """AttnCfg of the oracle from the reference ctor kwargs stored in a fixture."""
+    from oracle.haet_oracle import AttnCfg
+
+    kw = dict(meta["kw"])
+    kind = meta["kind"]
+    grid = tuple(meta["grid"]) if meta["grid"] else ()
+    defaults = {"irregular": dict(heads=8, dim_head=64, slice_num=64),
+                "structured2d": dict(heads=8, dim_head=64, slice_num=64),
+                "structured3d": dict(heads=8, dim_head=64, slice_num=32)}[kind]
+    cfg = AttnCfg(dim=kw["dim"], heads=kw.get("heads", defaults["heads"]),
+                  dim_head=kw.get("dim_head", defaults["dim_head"]),
+                  slice_num=kw.get("slice_num", defaults["slice_num"]),
+                  kind=kind, grid=grid, kernel=kw.get("kernel", 3),
+                  rotate=kw.get("rotate", 1), mlp_ratio=kw.get("mlp_ratio", 4))
+    for k in ("c_hidden", "ball_sizes", "enc_num_heads", "enc_depths", "dec_num_heads", "dec_depths", "strides"):
+        if kw.get(k) is not None:
+            setattr(cfg.erwin, k, kw[k])
+    return cfg
