@@ -1,0 +1,26 @@
+"""Physics_Attention_Structured_Mesh_2D -- drop-in for models/PhysicsAttention/
+StructuredMesh2D.py (constructor :44-69, forward :157-262).  The 3x3 Conv2d projection is
+MIOpen via PyTorch-ROCm; everything after it is the shared HIP path."""
+import torch.nn as nn
+
+from ._base import PhysicsAttentionBase
+
+
+class Physics_Attention_Structured_Mesh_2D(PhysicsAttentionBase):
+    dimensionality = 2  # StructuredMesh2D.py:102
+
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.0, slice_num=64, H=101, W=31, kernel=3,
+                 base_temp=0.5, epsilon=1e-6, c_hidden=None, ball_sizes=None, enc_num_heads=None,
+                 enc_depths=None, dec_num_heads=None, dec_depths=None, strides=None, rotate=1,
+                 decode=True, mlp_ratio=4, mp_steps=0, embed=False):
+        super().__init__()
+        self.H, self.W = H, W
+        self.in_project_x = nn.Conv2d(dim, dim_head * heads, kernel, 1, kernel // 2)
+        self._init_common(dim, heads, dim_head, dropout, slice_num, base_temp, epsilon, c_hidden,
+                          ball_sizes, enc_num_heads, enc_depths, dec_num_heads, dec_depths, strides,
+                          rotate, decode, mlp_ratio, mp_steps, embed)
+
+    def project(self, x):
+        B, N, D = x.shape
+        g = x.reshape(B, self.H, self.W, D).permute(0, 3, 1, 2).contiguous()
+        return self.in_project_x(g).permute(0, 2, 3, 1).reshape(B, N, -1)

@@ -1,0 +1,26 @@
+"""Physics_Attention_Structured_Mesh_3D -- drop-in for models/PhysicsAttention/
+StructuredMesh3D.py (constructor :45-71, forward :161-266).  The 3x3x3 Conv3d projection is
+MIOpen via PyTorch-ROCm; everything after it is the shared HIP path."""
+import torch.nn as nn
+
+from ._base import PhysicsAttentionBase
+
+
+class Physics_Attention_Structured_Mesh_3D(PhysicsAttentionBase):
+    dimensionality = 3  # StructuredMesh3D.py:106
+
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.0, slice_num=32, H=32, W=32, D=32,
+                 kernel=3, base_temp=0.5, epsilon=1e-6, c_hidden=None, ball_sizes=None,
+                 enc_num_heads=None, enc_depths=None, dec_num_heads=None, dec_depths=None,
+                 strides=None, rotate=1, decode=True, mlp_ratio=4, mp_steps=0, embed=False):
+        super().__init__()
+        self.H, self.W, self.D = H, W, D
+        self.in_project_x = nn.Conv3d(dim, dim_head * heads, kernel, 1, kernel // 2)
+        self._init_common(dim, heads, dim_head, dropout, slice_num, base_temp, epsilon, c_hidden,
+                          ball_sizes, enc_num_heads, enc_depths, dec_num_heads, dec_depths, strides,
+                          rotate, decode, mlp_ratio, mp_steps, embed)
+
+    def project(self, x):
+        B, N, Dm = x.shape
+        g = x.reshape(B, self.H, self.W, self.D, Dm).permute(0, 4, 1, 2, 3).contiguous()
+        return self.in_project_x(g).permute(0, 2, 3, 4, 1).reshape(B, N, -1)

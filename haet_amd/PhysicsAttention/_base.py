@@ -1,0 +1,106 @@
+"""Shared implementation of the three Physics_Attention_* modules.
+
+The reference copy-pastes one forward three times (models/PhysicsAttention/
+IrregularMesh.py:141-235, StructuredMesh2D.py:157-262, StructuredMesh3D.py:161-266); the
+variants differ only in the per-point projection (Linear / Conv2d / Conv3d).  Here the
+projection stays a stock PyTorch-ROCm op (rocBLAS / MIOpen) and everything after it is the
+HIP path:
+
+    x_lin [B,N,H*C] --haet_slice_fwd--> partial (m,l,St) --haet_slice_merge--> S, col stats
+      --haet_token_pos--> pos --haet_balltree_build + haet_erwin_fwd--> S'
+      --haet_deslice_fwd--> out_x [B,N,H*C] --to_out--> [B,N,dim]
+
+The [B,H,N,G] slice-weight tensor of the reference (2 GB at N=1M) is never materialised.
+With `shard_group` set, each rank holds a shard of the points and the partial records are
+all-gathered and merged (one tiny exchange per forward); everything after the
+merge is replicated.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..components import ErwinFlashTransformer as ErwinTransformer
+from .._lib import HaetError
+
+
+class PhysicsAttentionBase(nn.Module):
+    dimensionality = 3
+
+    def _init_common(self, dim, heads, dim_head, dropout, slice_num, base_temp, epsilon, c_hidden,
+                     ball_sizes, enc_num_heads, enc_depths, dec_num_heads, dec_depths, strides,
+                     rotate, decode, mlp_ratio, mp_steps, embed):
+        inner_dim = dim_head * heads
+        self.dim_head, self.heads, self.slice_num = dim_head, heads, slice_num
+        self.epsilon, self.base_temp = epsilon, base_temp
+        self.in_project_slice = nn.Linear(dim_head, slice_num)
+        self.ada_temp_linear = nn.Linear(dim_head, 1)
+        torch.nn.init.orthogonal_(self.in_project_slice.weight)
+        # defaults of IrregularMesh.py:105-118
+        if c_hidden is None:
+            c_hidden = [dim_head, dim_head * 2]
+        if ball_sizes is None:
+            ball_sizes = [min(32, slice_num), min(16, slice_num // 2)]
+        if enc_num_heads is None:
+            enc_num_heads = [heads // 2, heads]
+        if enc_depths is None:
+            enc_depths = [2, 2]
+        if dec_num_heads is None:
+            dec_num_heads = [heads // 2]
+        if dec_depths is None:
+            dec_depths = [2]
+        if strides is None:
+            strides = [2]
+        self.erwin = ErwinTransformer(
+            c_in=dim_head, c_hidden=c_hidden, ball_sizes=ball_sizes, enc_num_heads=enc_num_heads,
+            enc_depths=enc_depths, dec_num_heads=dec_num_heads, dec_depths=dec_depths, strides=strides,
+            rotate=rotate, decode=decode, mlp_ratio=mlp_ratio, dimensionality=self.dimensionality,
+            mp_steps=mp_steps, embed=embed)
+        self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout))
+        self.shard_group = None  # torch.distributed group over which the POINTS are sharded
+        self._slice_cache = None
+
+    # -- per-variant projection to [B, N, H*C] -------------------------------------------
+    def project(self, x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def _slice_params(self) -> ops.SliceParams:
+        ps = (self.in_project_slice.weight, self.in_project_slice.bias,
+              self.ada_temp_linear.weight, self.ada_temp_linear.bias)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if self._slice_cache is None or self._slice_cache[0] != key:
+            sp = ops.SliceParams(ps[0].detach(), ps[1].detach(), ps[2].detach(),
+                                 float(ps[3].detach().item()), self.base_temp, self.epsilon)
+            self._slice_cache = (key, sp)
+        return self._slice_cache[1]
+
+    def forward(self, x: torch.Tensor, return_intermediates: bool = False):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError(
+                "the HIP PhysicsAttention path is forward-only so far (backward is the next scope "
+                "row, SURVEY.md 8f-1): wrap the call in torch.no_grad()")
+        if not x.is_cuda:
+            raise HaetError("Physics_Attention_* (haet_amd) runs on a ROCm device only; move the module "
+                            "and its input with .cuda() -- there is no CPU fallback")
+        B, N, _ = x.shape
+        H, C, G = self.heads, self.dim_head, self.slice_num
+        x_lin = self.project(x).float().contiguous()                    # [B, N, H*C]
+        sp = self._slice_params()
+        parts = ops.slice_partials(x_lin, sp, H, C, G)                  # [P, record]
+        if self.shard_group is not None:
+            from ..sharding import allgather_records
+
+            local = ops.merge_records(parts, B, H, C, G, finalize=False)
+            parts = allgather_records(local, self.shard_group)          # [R, record]
+        col_max, col_sum, S = ops.merge_records(parts, B, H, C, G, finalize=True)
+        pos = ops.token_pos(S, self.dimensionality)                      # [B*H*G, d]
+        S2 = self.erwin(S, pos, n_clouds=B * H)                          # [B*H*G, C]
+        out_x = ops.deslice(x_lin, sp, col_max, col_sum, S2, H, C, G)    # [B, N, H*C]
+        out = self.to_out(out_x.to(x.dtype))
+        if return_intermediates:
+            return out, dict(x_lin=x_lin, col_max=col_max, col_sum=col_sum, eidetic=S, pos=pos,
+                             processed=S2, out_x=out_x)
+        return out

@@ -1,0 +1,89 @@
+"""ctypes binding of libhaet_hip.so (the C ABI declared in include/haet_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails,
+an exception is raised.  (The CPU oracle under oracle/ is test infrastructure and is
+never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhaet_hip.so")
+
+MAX_LEVELS = 4
+MAX_DEPTH = 4
+
+
+class HaetError(RuntimeError):
+    pass
+
+
+class ErwinBlockW(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in (
+        "norm1", "norm2", "pe_w", "pe_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
+        "w1_w", "w1_b", "w2_w", "w2_b", "w3_w", "w3_b")]
+
+
+class ErwinLayer(ctypes.Structure):
+    _fields_ = [("c", c_int32), ("heads", c_int32), ("ball", c_int32), ("depth", c_int32),
+                ("hidden", c_int32), ("blocks", ErwinBlockW * MAX_DEPTH)]
+
+
+class ErwinResample(ctypes.Structure):
+    _fields_ = [("stride", c_int32), ("w", c_int32), ("b", c_int32),
+                ("bn_scale", c_int32), ("bn_shift", c_int32)]
+
+
+class ErwinDesc(ctypes.Structure):
+    _fields_ = [("n_levels", c_int32), ("d", c_int32), ("rotate", c_int32), ("decode", c_int32),
+                ("enc", ErwinLayer * MAX_LEVELS), ("dec", ErwinLayer * MAX_LEVELS),
+                ("pool", ErwinResample * MAX_LEVELS), ("unpool", ErwinResample * MAX_LEVELS)]
+
+
+# name -> (restype, argtypes); every symbol include/haet_hip.h declares
+_P = c_void_p
+SIGNATURES = {
+    "haet_abi_version": (c_int, []),
+    "haet_last_error_string": (c_char_p, []),
+    "haet_slice_num_parts": (c_int, [c_int] * 5),
+    "haet_slice_part_floats": (c_size_t, [c_int] * 4),
+    "haet_slice_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float] + [c_int] * 5 + [_P, _P]),
+    "haet_slice_merge": (c_int, [_P] + [c_int] * 6 + [_P, _P, _P, _P, _P]),
+    "haet_token_pos": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "haet_balltree_build": (c_int, [_P, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int),
+                                    c_float, _P, _P, _P, _P]),
+    "haet_erwin_lds_bytes": (c_size_t, [POINTER(ErwinDesc), c_int]),
+    "haet_erwin_fwd": (c_int, [_P, _P, _P, _P, _P, _P, POINTER(ErwinDesc), c_int, c_int, _P, _P]),
+    "haet_deslice_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P]
+                         + [c_int] * 5 + [_P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libhaet_hip.so (raises HaetError if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HaetError(
+                f"{LIB_PATH} not found: build it with `make -C haet_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "There is no CPU fallback for the HIP path.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+            fn.restype, fn.argtypes = res, args
+        if lib.haet_abi_version() != 1:
+            raise HaetError(f"libhaet_hip.so ABI {lib.haet_abi_version()} != 1")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().haet_last_error_string().decode(errors="replace")
+        raise HaetError(f"{what} failed (code {rc}): {msg}")

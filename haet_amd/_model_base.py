@@ -1,0 +1,94 @@
+"""Shared body of the three HAETransolver_* model wrappers.
+
+API surface only: constructor kwargs, forward(x, fx, T) and
+state_dict keys follow models/HAETransolver_Irregular_Mesh.py:26-376 (and the
+Structured_Mesh_2D / _3D twins); LayerNorm / MLP arithmetic is stock PyTorch-ROCm, the
+attention inside every block is the HIP path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.utils.checkpoint as checkpoint
+from torch.nn.init import trunc_normal_
+
+from .components import MLP, timestep_embedding
+
+
+class TransolverErwinBlockBase(nn.Module):
+    """LN -> Attn -> +res -> LN -> MLP -> +res [-> LN -> Linear]
+    (HAETransolver_Irregular_Mesh.py:114-134)."""
+
+    def _init_block(self, attn: nn.Module, hidden_dim, act, mlp_ratio, last_layer, out_dim):
+        self.last_layer = last_layer
+        self.ln_1 = nn.LayerNorm(hidden_dim)
+        self.Attn = attn
+        self.ln_2 = nn.LayerNorm(hidden_dim)
+        self.mlp = MLP(hidden_dim, hidden_dim * mlp_ratio, hidden_dim, n_layers=0, res=False, act=act)
+        if self.last_layer:
+            self.ln_3 = nn.LayerNorm(hidden_dim)
+            self.mlp2 = nn.Linear(hidden_dim, out_dim)
+
+    def forward(self, fx):
+        fx = self.Attn(self.ln_1(fx)) + fx
+        fx = self.mlp(self.ln_2(fx)) + fx
+        if self.last_layer:
+            return self.mlp2(self.ln_3(fx))
+        return fx
+
+
+class ModelBase(nn.Module):
+    placeholder_always = False  # irregular: always added; structured: only when fx is None
+
+    def _init_model(self, make_block, in_dim, n_layers, n_hidden, act, Time_Input):
+        self.preprocess = MLP(in_dim, n_hidden * 2, n_hidden, n_layers=0, res=False, act=act)
+        if Time_Input:
+            self.time_fc = nn.Sequential(nn.Linear(n_hidden, n_hidden), nn.SiLU(), nn.Linear(n_hidden, n_hidden))
+        self.blocks = nn.ModuleList([make_block(i == n_layers - 1) for i in range(n_layers)])
+        self.initialize_weights()
+        self.placeholder = nn.Parameter((1 / n_hidden) * torch.rand(n_hidden, dtype=torch.float))
+
+    def initialize_weights(self):
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        # HAETransolver_Irregular_Mesh.py:279-295
+        if isinstance(m, nn.Linear):
+            trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, (nn.LayerNorm, nn.BatchNorm1d)):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def unified_positions(self, x):
+        raise NotImplementedError
+
+    def forward(self, x, fx, T=None):
+        if self.unified_pos:
+            x = self.unified_positions(x)
+        if fx is not None:
+            fx = self.preprocess(torch.cat((x, fx), -1))
+            if self.placeholder_always:
+                fx = fx + self.placeholder[None, None, :]
+        else:
+            fx = self.preprocess(x) + self.placeholder[None, None, :]
+        if T is not None:
+            emb = timestep_embedding(T, self.n_hidden).repeat(1, x.shape[1], 1)
+            fx = fx + self.time_fc(emb)
+        for block in self.blocks:
+            if getattr(self, "use_checkpoint", False):
+                fx = checkpoint.checkpoint(block, fx)
+            else:
+                fx = block(fx)
+        return fx
+
+
+def reference_grid_distances(x, ref, dims):
+    """Distances from every point to a ref^dims reference grid on [0,1]^dims
+    (get_grid, HAETransolver_Irregular_Mesh.py:297-336); on x's device instead of the
+    reference's hard-coded .cuda()."""
+    axes = [torch.tensor(np.linspace(0, 1, ref), dtype=torch.float, device=x.device)] * dims
+    grid = torch.stack(torch.meshgrid(*axes, indexing="ij"), dim=-1).reshape(1, ref ** dims, dims)
+    return torch.sqrt(torch.sum((x[:, :, None, :] - grid[:, None, :, :]) ** 2, dim=-1)).contiguous()

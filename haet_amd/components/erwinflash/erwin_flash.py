@@ -1,0 +1,177 @@
+"""Erwin hierarchical ball transformer over the slice tokens -- host-side mirror of
+models/components/erwinflash/ (ErwinTransformer erwin_flash.py:14-195, BasicLayer /
+ErwinTransformerBlock components/layers.py, BallMSA components/attention.py, SwiGLU
+components/mlp.py, BallPooling / BallUnpooling components/pooling.py).
+
+The module tree exists to own the parameters under the reference's exact state_dict
+keys; the arithmetic of the whole stage is ONE fused HIP kernel (haet_erwin_fwd) fed by
+the device ball-tree builder (haet_balltree_build), instead of ~100 small launches and
+a host round trip per forward.  Only the configuration every PhysicsAttention module
+uses is supported (embed=False, mp_steps=0, decode=True).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..._lib import ErwinDesc, HaetError
+
+
+class SwiGLU(nn.Module):
+    """W3(W2 x * silu(W1 x))  (components/mlp.py:8-18)."""
+
+    def __init__(self, in_dim: int, dim: int):
+        super().__init__()
+        self.w1 = nn.Linear(in_dim, dim)
+        self.w2 = nn.Linear(in_dim, dim)
+        self.w3 = nn.Linear(dim, in_dim)
+
+
+class BallMSA(nn.Module):
+    """Ball attention parameters (components/attention.py:13-25). sigma_att is kept for
+    checkpoint compatibility; like the reference's flash variant it is never used."""
+
+    def __init__(self, dim: int, num_heads: int, ball_size: int, dimensionality: int = 3):
+        super().__init__()
+        self.num_heads, self.ball_size = num_heads, ball_size
+        self.head_dim = dim // num_heads
+        assert self.head_dim * num_heads == dim, "dim must be divisible by num_heads"
+        self.qkv = nn.Linear(dim, 3 * dim)
+        self.proj = nn.Linear(dim, dim)
+        self.pe_proj = nn.Linear(dimensionality, dim)
+        self.sigma_att = nn.Parameter(-1 + 0.01 * torch.randn((1, num_heads, 1, 1)))
+
+
+class ErwinTransformerBlock(nn.Module):
+    def __init__(self, dim, num_heads, ball_size, mlp_ratio, dimensionality=3):
+        super().__init__()
+        self.ball_size = ball_size
+        self.norm1 = nn.RMSNorm(dim)
+        self.norm2 = nn.RMSNorm(dim)
+        self.BMSA = BallMSA(dim, num_heads, ball_size, dimensionality)
+        self.swiglu = SwiGLU(dim, dim * mlp_ratio)
+
+
+class BallPooling(nn.Module):
+    def __init__(self, in_dim, out_dim, stride, dimensionality=3):
+        super().__init__()
+        self.stride = stride
+        self.proj = nn.Linear(stride * in_dim + stride * dimensionality, out_dim)
+        self.norm = nn.BatchNorm1d(out_dim)
+
+
+class BallUnpooling(nn.Module):
+    def __init__(self, in_dim, out_dim, stride, dimensionality=3):
+        super().__init__()
+        self.stride = stride
+        self.proj = nn.Linear(in_dim + stride * dimensionality, stride * out_dim)
+        self.norm = nn.BatchNorm1d(out_dim)
+
+
+class BasicLayer(nn.Module):
+    """components/layers.py:35-70 (parameters only)."""
+
+    def __init__(self, direction, depth, stride, in_dim, out_dim, num_heads, ball_size,
+                 mlp_ratio, rotate, dimensionality=3):
+        super().__init__()
+        hidden_dim = in_dim if direction == "down" else out_dim
+        self.hidden_dim, self.num_heads, self.ball_size = hidden_dim, num_heads, ball_size
+        self.mlp_ratio = mlp_ratio
+        self.blocks = nn.ModuleList(
+            [ErwinTransformerBlock(hidden_dim, num_heads, ball_size, mlp_ratio, dimensionality)
+             for _ in range(depth)])
+        self.rotate = [i % 2 for i in range(depth)] if rotate else [False] * depth
+        if direction == "down" and stride is not None:
+            self.pool = BallPooling(hidden_dim, out_dim, stride, dimensionality)
+        elif direction == "up" and stride is not None:
+            self.unpool = BallUnpooling(in_dim, hidden_dim, stride, dimensionality)
+
+
+class ErwinTransformer(nn.Module):
+    """Same constructor and state_dict as the reference (erwin_flash.py:41-136)."""
+
+    def __init__(self, c_in: int, c_hidden: List, ball_sizes: List, enc_num_heads: List,
+                 enc_depths: List, dec_num_heads: List, dec_depths: List, strides: List,
+                 rotate: int, decode: bool = True, mlp_ratio: int = 4, dimensionality: int = 3,
+                 mp_steps: int = 3, embed: bool = True):
+        super().__init__()
+        assert len(enc_num_heads) == len(enc_depths) == len(ball_sizes)
+        assert len(dec_num_heads) == len(dec_depths) == len(strides)
+        assert len(strides) == len(ball_sizes) - 1
+        if embed or mp_steps:
+            raise NotImplementedError(
+                "ErwinEmbedding / MPNN (embed=True or mp_steps>0) are outside the PhysicsAttention "
+                "hot path: every Physics_Attention_* module passes embed=False, mp_steps=0")
+        self.rotate, self.decode = rotate, decode
+        self.ball_sizes, self.strides = list(ball_sizes), list(strides)
+        self.mp_steps, self.use_embedding = mp_steps, embed
+        self.dimensionality = dimensionality
+        self.c_hidden = list(c_hidden)
+        num_layers = len(enc_depths) - 1
+        self.encoder = nn.ModuleList()
+        for i in range(num_layers):
+            self.encoder.append(BasicLayer("down", enc_depths[i], strides[i], c_hidden[i], c_hidden[i + 1],
+                                           enc_num_heads[i], ball_sizes[i], mlp_ratio, rotate > 0, dimensionality))
+        self.bottleneck = BasicLayer(None, enc_depths[-1], None, c_hidden[-1], c_hidden[-1],
+                                     enc_num_heads[-1], ball_sizes[-1], mlp_ratio, rotate > 0, dimensionality)
+        if decode:
+            self.decoder = nn.ModuleList()
+            for i in range(num_layers - 1, -1, -1):
+                self.decoder.append(BasicLayer("up", dec_depths[i], strides[i], c_hidden[i + 1], c_hidden[i],
+                                               dec_num_heads[i], ball_sizes[i], mlp_ratio, rotate > 0, dimensionality))
+        self.in_dim, self.out_dim = c_in, c_hidden[0]
+        self.apply(self._init_weights)
+        self._packed = None  # (key, weights blob, desc)
+
+    def _init_weights(self, m):
+        # erwin_flash.py:127-136
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, mean=0.0, std=0.02, a=-2.0, b=2.0)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+            if m.weight is not None:
+                nn.init.constant_(m.weight, 1.0)
+
+    # ------------------------------------------------------------------ packing
+    def _pack_key(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def packed(self):
+        """(weights blob, desc) for haet_erwin_fwd, rebuilt only when a parameter changed."""
+        from .pack import pack_erwin
+
+        key = (self._pack_key(), self.training)
+        if self._packed is None or self._packed[0] != key:
+            blob, desc = pack_erwin(self)
+            self._packed = (key, blob, desc)
+        return self._packed[1], self._packed[2]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, node_features: torch.Tensor, node_positions: torch.Tensor,
+                batch_idx: Optional[torch.Tensor] = None, n_clouds: Optional[int] = None, **kwargs):
+        """tokens [T, c], positions [T, d]; the T tokens are n_clouds equally sized clouds in
+        order (what PhysicsAttention builds: batch_idx = arange(B*H).repeat_interleave(G))."""
+        if not self.decode:
+            raise NotImplementedError("decode=False is outside the PhysicsAttention hot path")
+        if self.training:
+            raise NotImplementedError(
+                "train-mode BatchNorm (batch statistics over all clouds) is not implemented in the "
+                "HIP Erwin kernel yet; call .eval()")
+        T = node_features.shape[0]
+        if n_clouds is None:
+            if batch_idx is None:
+                raise HaetError("either batch_idx or n_clouds is required")
+            n_clouds = int(batch_idx[-1].item()) + 1  # sync; PhysicsAttention passes n_clouds
+        if T % n_clouds:
+            raise HaetError("the HIP Erwin stage needs equally sized clouds")
+        M = T // n_clouds
+        blob, desc = self.packed()
+        tree_idx, tree_mask, rot, _ = ops.balltree_build(
+            node_positions, n_clouds, M, self.strides, self.ball_sizes, float(self.rotate))
+        return ops.erwin_fwd(node_features, node_positions, tree_idx, tree_mask, rot, blob, desc, n_clouds, M)

@@ -1,0 +1,310 @@
+// Device ball-tree builder: the reference builds this tree on the HOST every forward
+// (models/components/balltree/balltree.pyx:542-550 -> a GPU->CPU->GPU sync); here one
+// wave per cloud builds it in LDS.
+//
+// The permutation must equal what libstdc++'s std::nth_element leaves behind
+// (balltree.h:91-100), because BallPooling concatenates leaf pairs in that order
+// (pooling.py:35-38).  So this is a step-for-step device version of introselect
+// (median-of-3 to front, unguarded Hoare partition while range > 3, heap-select when
+// the 2*floor(log2 n) budget is spent, insertion sort of the last <= 3), written from
+// the algorithm description in SURVEY.md appendix A.  All nodes of one tree level are
+// independent and run on different lanes of the wave.
+//
+// Keys are the fp32 positions; the reference converts them to float64 first
+// (balltree.pyx:542), an exact, order-preserving conversion, so fp32 compares give
+// identical decisions.  Spreads are differenced in double like the reference.
+#include "common.h"
+
+namespace haet {
+
+constexpr int kMaxPts = 128;  // slots per cloud
+constexpr int kMaxDim = 3;
+
+__device__ __forceinline__ bool lt(const float* kd, int a, int b) { return kd[a] < kd[b]; }
+__device__ __forceinline__ void swp(int* a, int* b) {
+    const int t = *a;
+    *a = *b;
+    *b = t;
+}
+
+__device__ void push_heap_(int* first, int hole, int top, int value, const float* kd) {
+    int parent = (hole - 1) / 2;
+    while (hole > top && lt(kd, first[parent], value)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+
+__device__ void adjust_heap_(int* first, int hole, int len, int value, const float* kd) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (lt(kd, first[child], first[child - 1])) child--;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    push_heap_(first, hole, top, value, kd);
+}
+
+__device__ void heap_select_(int* first, int* middle, int* last, const float* kd) {
+    const int len = (int)(middle - first);
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        for (;;) {
+            adjust_heap_(first, parent, len, first[parent], kd);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    for (int* i = middle; i < last; ++i) {
+        if (lt(kd, *i, *first)) {
+            const int value = *i;
+            *i = *first;
+            adjust_heap_(first, 0, len, value, kd);
+        }
+    }
+}
+
+__device__ void insertion_sort_(int* first, int* last, const float* kd) {
+    if (first == last) return;
+    for (int* i = first + 1; i != last; ++i) {
+        const int val = *i;
+        if (lt(kd, val, *first)) {
+            for (int* p = i; p != first; --p) *p = *(p - 1);
+            *first = val;
+        } else {
+            int* hole = i;
+            int* prev = i - 1;
+            while (lt(kd, val, *prev)) {
+                *hole = *prev;
+                hole = prev;
+                --prev;
+            }
+            *hole = val;
+        }
+    }
+}
+
+__device__ void select_nth(int* first, int* nth, int* last, const float* kd) {
+    if (first == last || nth == last) return;
+    int depth = 2 * (31 - __clz((int)(last - first)));
+    while (last - first > 3) {
+        if (depth == 0) {
+            heap_select_(first, nth + 1, last, kd);
+            swp(first, nth);
+            return;
+        }
+        --depth;
+        int *a = first + 1, *b = first + (last - first) / 2, *c = last - 1;
+        if (lt(kd, *a, *b)) {
+            if (lt(kd, *b, *c)) swp(first, b);
+            else if (lt(kd, *a, *c)) swp(first, c);
+            else swp(first, a);
+        } else if (lt(kd, *a, *c)) swp(first, a);
+        else if (lt(kd, *b, *c)) swp(first, c);
+        else swp(first, b);
+        int *lo = first + 1, *hi = last;
+        for (;;) {
+            while (lt(kd, *lo, *first)) ++lo;
+            --hi;
+            while (lt(kd, *first, *hi)) --hi;
+            if (!(lo < hi)) break;
+            swp(lo, hi);
+            ++lo;
+        }
+        if (lo <= nth) first = lo;
+        else last = lo;
+    }
+    insertion_sort_(first, last, kd);
+}
+
+// balltree.h:32-66
+__device__ int split_dim(const float* keys, int kstride, int nd, const int* idx, int s, int e) {
+    if (e - s <= 1) return 0;
+    int best = 0;
+    double best_spread = 0.0;
+    for (int d = 0; d < nd; ++d) {
+        const float* kd = keys + d * kstride;
+        float lo = kd[idx[s]], hi = lo;
+        for (int i = s + 1; i < e; ++i) {
+            const float v = kd[idx[i]];
+            lo = v < lo ? v : lo;
+            hi = hi < v ? v : hi;
+        }
+        const double spread = (double)hi - (double)lo;
+        if (spread > best_spread) {
+            best_spread = spread;
+            best = d;
+        }
+    }
+    return best;
+}
+
+// node `j` of level `L` covers idx[s, e) obtained by halving [0, n) along j's bits (MSB first)
+__device__ __forceinline__ void node_range(int n, int L, int j, int& s, int& e) {
+    s = 0;
+    e = n;
+    for (int b = L - 1; b >= 0; --b) {
+        const int mid = (s + e) / 2;
+        if ((j >> b) & 1) s = mid;
+        else e = mid;
+    }
+}
+
+// split every node of level L (one lane each); stop_small: partition_ball_tree's n<=1 exit
+__device__ void split_level(const float* keys, int kstride, int nd, int* idx, int n, int L,
+                            int lane) {
+    if (lane < (1 << L)) {
+        int s, e;
+        node_range(n, L, lane, s, e);
+        if (e - s > 1) {
+            const int dim = split_dim(keys, kstride, nd, idx, s, e);
+            select_nth(idx + s, idx + (s + e) / 2, idx + e, keys + dim * kstride);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct Rot3 {
+    float r[9];
+};
+
+__global__ __launch_bounds__(64) void balltree_kernel(
+    const float* __restrict__ pos, int M, int nd, int depth, int n_levels, int s0, int s1, int s2,
+    int t0, int t1, int t2, int t3, int rotate, Rot3 R, int32_t* __restrict__ tree_idx,
+    uint8_t* __restrict__ tree_mask, int32_t* __restrict__ rot) {
+    __shared__ float kmain[kMaxDim * kMaxPts];
+    __shared__ float ka[kMaxDim * kMaxPts];
+    __shared__ float kb[kMaxDim * kMaxPts];
+    __shared__ int idx[kMaxPts];
+    __shared__ int tl[kMaxPts];
+    const int lane = threadIdx.x, cloud = blockIdx.x, n_clouds = gridDim.x;
+    const int Mp = 2 << depth;
+    const int strides[3] = {s0, s1, s2};
+    const int targets[4] = {t0, t1, t2, t3};
+
+    for (int i = lane; i < M; i += 64) {
+        idx[i] = i;
+        for (int d = 0; d < nd; ++d) kmain[d * kMaxPts + i] = pos[((size_t)cloud * M + i) * nd + d];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // main tree: balltree.h:121-186
+    for (int L = 0; L < depth; ++L) split_level(kmain, kMaxPts, nd, idx, M, L, lane);
+    if (lane < (1 << depth)) {
+        int s, e;
+        node_range(M, depth, lane, s, e);
+        const int a = idx[s], b = (e - s == 1) ? a : idx[s + 1];
+        tl[2 * lane] = a;
+        tl[2 * lane + 1] = b;
+        const size_t o = (size_t)cloud * Mp + 2 * lane;
+        tree_idx[o] = cloud * M + a;
+        tree_idx[o + 1] = cloud * M + b;
+        tree_mask[o] = 1;
+        tree_mask[o + 1] = (e - s == 1) ? 0 : 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (!rotate) return;
+
+    // rotated leaves (balltree.pyx:639-646): fp32 leaves @ R
+    for (int i = lane; i < Mp; i += 64) {
+        const int p = tl[i];
+        for (int j = 0; j < nd; ++j) {
+            float acc = kmain[p] * R.r[j];
+            for (int k = 1; k < nd; ++k) acc = fmaf(kmain[k * kMaxPts + p], R.r[k * nd + j], acc);
+            ka[j * kMaxPts + i] = acc;
+        }
+    }
+    float* cur = ka;
+    float* nxt = kb;
+    int n = Mp;
+    size_t rot_off = 0;
+    for (int lev = 0; lev < n_levels; ++lev) {
+        for (int i = lane; i < n; i += 64) idx[i] = i;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // balltree.h:205-259: `target` halvings, nodes of <= 1 point stop early
+        for (int L = 0; L < targets[lev] && (n >> L) > 1; ++L)
+            split_level(cur, kMaxPts, nd, idx, n, L, lane);
+        for (int i = lane; i < n; i += 64)
+            rot[rot_off + (size_t)cloud * n + i] = cloud * n + idx[i];
+        rot_off += (size_t)n_clouds * n;
+        if (lev < n_levels - 1) {
+            // mean-pool consecutive `stride` leaves (balltree.pyx:658-660)
+            const int st = strides[lev], n2 = n / st;
+            for (int i = lane; i < n2; i += 64)
+                for (int j = 0; j < nd; ++j) {
+                    float sum = cur[j * kMaxPts + i * st];
+                    for (int q = 1; q < st; ++q) sum += cur[j * kMaxPts + i * st + q];
+                    nxt[j * kMaxPts + i] = sum / (float)st;
+                }
+            float* t = cur;
+            cur = nxt;
+            nxt = t;
+            n = n2;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+}  // namespace haet
+
+using namespace haet;
+
+extern "C" int haet_balltree_build(const float* pos, int n_clouds, int M, int d, int n_levels,
+                                   const int* strides, const int* targets, float angle_deg,
+                                   int32_t* tree_idx, uint8_t* tree_mask, int32_t* rot,
+                                   haet_stream_t stream) {
+    if (!pos || !tree_idx || !tree_mask || n_clouds < 1)
+        return fail(HAET_E_ARG, "balltree: null pointer or n_clouds < 1");
+    if (M < 2 || M > kMaxPts) return fail(HAET_E_ARG, "balltree: M=%d unsupported (2..128)", M);
+    if (d != 2 && d != 3) return fail(HAET_E_ARG, "balltree: d=%d unsupported (2 or 3)", d);
+    if (n_levels < 1 || n_levels > 4) return fail(HAET_E_ARG, "balltree: n_levels=%d", n_levels);
+    // depth = ceil(log2 M) - 1   (balltree.pyx:58-60)
+    int depth = 0;
+    while ((2 << depth) < M) ++depth;
+    const int Mp = 2 << depth;
+    int st[3] = {1, 1, 1}, tg[4] = {0, 0, 0, 0};
+    const int rotate = angle_deg > 0.f;
+    if (rotate) {
+        if (!rot || !targets || (n_levels > 1 && !strides))
+            return fail(HAET_E_ARG, "balltree: rot/targets/strides missing");
+        int n = Mp;
+        for (int i = 0; i < n_levels; ++i) {
+            tg[i] = targets[i];
+            if (tg[i] < 0) return fail(HAET_E_ARG, "balltree: negative target");
+            if (i < n_levels - 1) {
+                st[i] = strides[i];
+                if (st[i] < 1 || n % st[i]) return fail(HAET_E_ARG, "balltree: stride %d", st[i]);
+                n /= st[i];
+            }
+        }
+    }
+    // generate_rotation_matrix (balltree.pyx:576-596): python doubles -> fp32 tensor
+    Rot3 R = {};
+    const double a = (double)angle_deg * 3.14159265358979323846 / 180.0;
+    const double c = cos(a), s = sin(a);
+    if (d == 2) {
+        const double m[4] = {c, -s, s, c};
+        for (int i = 0; i < 4; ++i) R.r[i] = (float)m[i];
+    } else {
+        const double m[9] = {c * c, s * c * (s - 1), s * (s + c * c), s * c, s * s * s + c * c,
+                             s * c * (s - 1), -s, s * c, c * c};
+        for (int i = 0; i < 9; ++i) R.r[i] = (float)m[i];
+    }
+    hipLaunchKernelGGL(balltree_kernel, dim3(n_clouds), dim3(64), 0, as_stream(stream), pos, M, d,
+                       depth, n_levels, st[0], st[1], st[2], tg[0], tg[1], tg[2], tg[3], rotate, R,
+                       tree_idx, tree_mask, rot);
+    return check_launch("balltree_kernel");
+}

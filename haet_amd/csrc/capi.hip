@@ -1,0 +1,65 @@
+// C-ABI glue: error string, version, and the shape dispatch of the slice / de-slice passes.
+#include <cstring>
+
+#include "common.h"
+
+namespace haet {
+
+char* err_buf() {
+    static thread_local char buf[512] = "";
+    return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// slice_valu.hip
+int slice_shape_ok(int B, int N, int H, int C, int M);
+int slice_valu_num_parts(int N);
+int slice_valu_fwd(const float*, const float*, const float*, const float*, float, float, float, int,
+                   int, int, int, int, float*, hipStream_t);
+int deslice_valu_fwd(const float*, const float*, const float*, const float*, float, float, float,
+                     const float*, const float*, const float*, int, int, int, int, int, float*,
+                     hipStream_t);
+
+}  // namespace haet
+
+using namespace haet;
+
+extern "C" int haet_abi_version(void) { return HAET_ABI_VERSION; }
+extern "C" const char* haet_last_error_string(void) { return err_buf(); }
+
+extern "C" int haet_slice_num_parts(int B, int N, int H, int C, int M) {
+    if (slice_shape_ok(B, N, H, C, M) != HAET_OK) return HAET_E_ARG;
+    return slice_valu_num_parts(N);
+}
+
+extern "C" size_t haet_slice_part_floats(int B, int H, int C, int M) {
+    return (size_t)B * H * M * (C + 2);
+}
+
+extern "C" int haet_slice_fwd(const float* x_lin, const float* Ws, const float* bs, const float* wt,
+                              float bt, float base_temp, float c0, int B, int N, int H, int C, int M,
+                              float* parts, haet_stream_t stream) {
+    if (!x_lin || !Ws || !bs || !wt || !parts) return fail(HAET_E_ARG, "slice_fwd: null pointer");
+    int rc = slice_shape_ok(B, N, H, C, M);
+    if (rc != HAET_OK) return rc;
+    return slice_valu_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, B, N, H, C, M, parts, as_stream(stream));
+}
+
+extern "C" int haet_deslice_fwd(const float* x_lin, const float* Ws, const float* bs, const float* wt,
+                                float bt, float base_temp, float c0, const float* col_max,
+                                const float* col_sum, const float* S2, int B, int N, int H, int C,
+                                int M, float* out_x, haet_stream_t stream) {
+    if (!x_lin || !Ws || !bs || !wt || !col_max || !col_sum || !S2 || !out_x)
+        return fail(HAET_E_ARG, "deslice_fwd: null pointer");
+    int rc = slice_shape_ok(B, N, H, C, M);
+    if (rc != HAET_OK) return rc;
+    return deslice_valu_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, S2, B, N, H, C, M,
+                            out_x, as_stream(stream));
+}

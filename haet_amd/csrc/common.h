@@ -1,0 +1,47 @@
+// Shared helpers for the libhaet_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/haet_hip.h"
+
+namespace haet {
+
+constexpr int kWave = 64;
+
+// thread-local "last error" text behind haet_last_error_string()
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(HAET_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return HAET_OK;
+}
+
+inline hipStream_t as_stream(haet_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Ada-Temp (models/PhysicsAttention/IrregularMesh.py:168): tau = base + clamp(t, -0.4, 0.4)
+__device__ __forceinline__ float ada_temp(float t, float base_temp) {
+    return base_temp + fminf(fmaxf(t, -0.4f), 0.4f);
+}
+
+}  // namespace haet

@@ -1,0 +1,100 @@
+// Log-sum-exp merge of slice partial records and the token-position kernel.
+#include "common.h"
+
+namespace haet {
+
+// One wave per (b,h,g): lanes stride over the C channels, all lanes redo the scalar
+// (m, l) recurrences.  R is a few hundred workgroup partials or <= 8 rank records.
+__global__ __launch_bounds__(64) void slice_merge_kernel(
+    const float* __restrict__ rec, int R, int BH, int C, int M, int finalize,
+    float* __restrict__ out_rec, float* __restrict__ col_max, float* __restrict__ col_sum,
+    float* __restrict__ S) {
+    const int bhg = blockIdx.x, bh = bhg / M, g = bhg % M, lane = threadIdx.x;
+    const size_t rstride = (size_t)BH * M * (C + 2);
+    const size_t base = (size_t)bh * M * (C + 2);
+    float mx = -INFINITY;
+    for (int r = lane; r < R; r += 64) mx = fmaxf(mx, rec[r * rstride + base + g]);
+    mx = wave_max(mx);
+    float lsum = 0.f;
+    for (int r = lane; r < R; r += 64) {
+        const float mr = rec[r * rstride + base + g];
+        const float a = (mr == -INFINITY) ? 0.f : __expf(mr - mx);
+        lsum += rec[r * rstride + base + M + g] * a;
+    }
+    lsum = wave_sum(lsum);
+    for (int c = lane; c < C; c += 64) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float mr = rec[r * rstride + base + g];
+            const float a = (mr == -INFINITY) ? 0.f : __expf(mr - mx);
+            s = fmaf(rec[r * rstride + base + 2 * M + (size_t)g * C + c], a, s);
+        }
+        if (out_rec) out_rec[base + 2 * M + (size_t)g * C + c] = s;
+        // IrregularMesh.py:186-188 with slice_norm == sum_n softmax == 1
+        if (finalize) S[(size_t)bhg * C + c] = (s / lsum) / (1.0f + 1e-5f);
+    }
+    if (lane == 0) {
+        if (out_rec) {
+            out_rec[base + g] = mx;
+            out_rec[base + M + g] = lsum;
+        }
+        if (finalize) {
+            col_max[bhg] = mx;
+            col_sum[bhg] = lsum;
+        }
+    }
+}
+
+// models/PhysicsAttention/IrregularMesh.py:204-209.  Single workgroup: T <= a few thousand.
+__global__ __launch_bounds__(256) void token_pos_kernel(const float* __restrict__ S, int T, int C,
+                                                        int d, float* __restrict__ pos) {
+    __shared__ float smin[4][4], smax[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = 0; j < d; ++j) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int t = threadIdx.x; t < T; t += 256) {
+            const float v = S[(size_t)t * C + j];
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+        if (lane == 0) {
+            smin[wave][j] = lo;
+            smax[wave][j] = hi;
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j < d; ++j) {
+        const float lo = fminf(fminf(smin[0][j], smin[1][j]), fminf(smin[2][j], smin[3][j]));
+        const float hi = fmaxf(fmaxf(smax[0][j], smax[1][j]), fmaxf(smax[2][j], smax[3][j]));
+        const float rng = hi - lo + 1e-8f;
+        for (int t = threadIdx.x; t < T; t += 256)
+            pos[(size_t)t * d + j] = (S[(size_t)t * C + j] - lo) / rng;
+    }
+}
+
+}  // namespace haet
+
+using namespace haet;
+
+extern "C" int haet_slice_merge(const float* records, int R, int B, int H, int C, int M,
+                                int finalize, float* out_record, float* col_max, float* col_sum,
+                                float* S, haet_stream_t stream) {
+    if (!records || R < 1 || B < 1 || H < 1 || C < 1 || M < 1)
+        return fail(HAET_E_ARG, "slice_merge: bad arguments");
+    if (finalize && (!col_max || !col_sum || !S))
+        return fail(HAET_E_ARG, "slice_merge: finalize needs col_max, col_sum and S");
+    if (!finalize && !out_record) return fail(HAET_E_ARG, "slice_merge: out_record is NULL");
+    hipLaunchKernelGGL(slice_merge_kernel, dim3(B * H * M), dim3(64), 0, as_stream(stream), records,
+                       R, B * H, C, M, finalize, out_record, col_max, col_sum, S);
+    return check_launch("slice_merge_kernel");
+}
+
+extern "C" int haet_token_pos(const float* S, int T, int C, int d, float* pos,
+                              haet_stream_t stream) {
+    if (!S || !pos || T < 1 || d < 1 || d > 4 || d > C)
+        return fail(HAET_E_ARG, "token_pos: bad arguments (T=%d C=%d d=%d)", T, C, d);
+    hipLaunchKernelGGL(token_pos_kernel, dim3(1), dim3(256), 0, as_stream(stream), S, T, C, d, pos);
+    return check_launch("token_pos_kernel");
+}

@@ -1,0 +1,155 @@
+"""Torch-tensor front-ends of the C-ABI entry points (one call per stage).
+
+These only validate, allocate outputs with torch (device memory + stream plumbing) and
+hand raw pointers to libhaet_hip.so on the current HIP stream.  All tensors must live
+on a ROCm device; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import HaetError, check
+
+Tensor = torch.Tensor
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t: Tensor, name: str) -> Tensor:
+    if not t.is_cuda:
+        raise HaetError(f"{name} must be a ROCm device tensor (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _p(t: Optional[Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def tree_slots(M: int) -> int:
+    """Slots per cloud of the complete ball tree: 2 * 2^(ceil(log2 M) - 1) (balltree.pyx:58-60)."""
+    depth = 0
+    while (2 << depth) < M:
+        depth += 1
+    return 2 << depth
+
+
+class SliceParams:
+    """Device views of the Rep-Slice / Ada-Temp parameters (in_project_slice, ada_temp_linear)."""
+
+    def __init__(self, Ws: Tensor, bs: Tensor, wt: Tensor, bt: float, base_temp: float, epsilon: float):
+        self.Ws, self.bs, self.wt = _f32(Ws, "in_project_slice.weight"), _f32(bs, "in_project_slice.bias"), _f32(wt.reshape(-1), "ada_temp_linear.weight")
+        self.bt, self.base_temp = float(bt), float(base_temp)
+        # log(-log(eps)) evaluated in fp32 like the reference (IrregularMesh.py:172)
+        self.c0 = float(torch.log(-torch.log(torch.tensor(epsilon, dtype=torch.float32))))
+
+
+def slice_partials(x_lin: Tensor, p: SliceParams, H: int, C: int, M: int) -> Tensor:
+    """Slice pass -> [P, B*H*M*(C+2)] partial records (haet_slice_fwd)."""
+    lib = _lib.load()
+    x_lin = _f32(x_lin, "x_lin")
+    B, N, HC = x_lin.shape
+    if HC != H * C:
+        raise HaetError(f"x_lin last dim {HC} != heads*dim_head {H * C}")
+    P = lib.haet_slice_num_parts(B, N, H, C, M)
+    if P < 0:
+        check(P, "haet_slice_num_parts")
+    rec = lib.haet_slice_part_floats(B, H, C, M)
+    parts = torch.empty((P, rec), dtype=torch.float32, device=x_lin.device)
+    check(lib.haet_slice_fwd(_p(x_lin), _p(p.Ws), _p(p.bs), _p(p.wt), p.bt, p.base_temp, p.c0,
+                             B, N, H, C, M, _p(parts), _stream()), "haet_slice_fwd")
+    return parts
+
+
+def merge_records(records: Tensor, B: int, H: int, C: int, M: int, finalize: bool):
+    """haet_slice_merge.  finalize=False -> one merged record [rec];
+    finalize=True -> (col_max [B*H*M], col_sum [B*H*M], S [B*H*M, C])."""
+    lib = _lib.load()
+    records = _f32(records, "records")
+    R = records.shape[0]
+    dev = records.device
+    if finalize:
+        cm = torch.empty(B * H * M, dtype=torch.float32, device=dev)
+        cs = torch.empty_like(cm)
+        S = torch.empty((B * H * M, C), dtype=torch.float32, device=dev)
+        check(lib.haet_slice_merge(_p(records), R, B, H, C, M, 1, _p(None), _p(cm), _p(cs), _p(S), _stream()),
+              "haet_slice_merge")
+        return cm, cs, S
+    out = torch.empty(records.shape[1], dtype=torch.float32, device=dev)
+    check(lib.haet_slice_merge(_p(records), R, B, H, C, M, 0, _p(out), _p(None), _p(None), _p(None), _stream()),
+          "haet_slice_merge")
+    return out
+
+
+def token_pos(S: Tensor, d: int) -> Tensor:
+    lib = _lib.load()
+    S = _f32(S, "S")
+    T, C = S.shape
+    pos = torch.empty((T, d), dtype=torch.float32, device=S.device)
+    check(lib.haet_token_pos(_p(S), T, C, d, _p(pos), _stream()), "haet_token_pos")
+    return pos
+
+
+def rot_targets(total_leaves: int, ball_sizes: Sequence[int]) -> List[int]:
+    """balltree.pyx:643 (the TOTAL leaf count over all clouds enters -- reference quirk)."""
+    return [max(0, int(math.log2(total_leaves / bs))) for bs in ball_sizes]
+
+
+def balltree_build(pos: Tensor, n_clouds: int, M: int, strides: Sequence[int],
+                   ball_sizes: Sequence[int], angle: float):
+    """Device build_balltree_with_rotations for equally sized clouds.
+    Returns (tree_idx int32[n_clouds*Mp], tree_mask uint8[...], rot int32 flat | None, [level sizes])."""
+    lib = _lib.load()
+    pos = _f32(pos, "pos")
+    d = pos.shape[1]
+    if pos.shape[0] != n_clouds * M:
+        raise HaetError("pos rows != n_clouds * M")
+    if len(strides) != len(ball_sizes) - 1:
+        raise AssertionError("Strides must be one less than ball sizes")
+    Mp = tree_slots(M)
+    nl = len(ball_sizes)
+    dev = pos.device
+    tree_idx = torch.empty(n_clouds * Mp, dtype=torch.int32, device=dev)
+    tree_mask = torch.empty(n_clouds * Mp, dtype=torch.uint8, device=dev)
+    sizes, n = [], Mp
+    for i in range(nl):
+        sizes.append(n_clouds * n)
+        if i < nl - 1:
+            n //= strides[i]
+    rot = torch.empty(sum(sizes), dtype=torch.int32, device=dev) if angle > 0 else None
+    tg = rot_targets(n_clouds * Mp, ball_sizes)
+    c_str = (ctypes.c_int * max(1, nl - 1))(*list(strides)[: nl - 1]) if nl > 1 else (ctypes.c_int * 1)(1)
+    c_tg = (ctypes.c_int * nl)(*tg)
+    check(lib.haet_balltree_build(_p(pos), n_clouds, M, d, nl, c_str, c_tg, float(angle),
+                                  _p(tree_idx), _p(tree_mask), _p(rot), _stream()), "haet_balltree_build")
+    return tree_idx, tree_mask, rot, sizes
+
+
+def erwin_fwd(tokens: Tensor, pos: Tensor, tree_idx: Tensor, tree_mask: Tensor, rot: Optional[Tensor],
+              weights: Tensor, desc: "_lib.ErwinDesc", n_clouds: int, M: int) -> Tensor:
+    lib = _lib.load()
+    tokens, pos = _f32(tokens, "tokens"), _f32(pos, "pos")
+    out = torch.empty_like(tokens)
+    check(lib.haet_erwin_fwd(_p(tokens), _p(pos), _p(tree_idx), _p(tree_mask), _p(rot), _p(weights),
+                             ctypes.byref(desc), n_clouds, M, _p(out), _stream()), "haet_erwin_fwd")
+    return out
+
+
+def deslice(x_lin: Tensor, p: SliceParams, col_max: Tensor, col_sum: Tensor, S2: Tensor,
+            H: int, C: int, M: int) -> Tensor:
+    lib = _lib.load()
+    x_lin = _f32(x_lin, "x_lin")
+    B, N, _ = x_lin.shape
+    out = torch.empty_like(x_lin)
+    check(lib.haet_deslice_fwd(_p(x_lin), _p(p.Ws), _p(p.bs), _p(p.wt), p.bt, p.base_temp, p.c0,
+                               _p(col_max), _p(col_sum), _p(_f32(S2, "S2")), B, N, H, C, M, _p(out),
+                               _stream()), "haet_deslice_fwd")
+    return out

@@ -1,0 +1,38 @@
+"""Point-sharded multi-GPU execution of the PhysicsAttention path.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in the CPU
+tests).  Every rank holds a shard of the N points; the ONLY exchange per forward is the
+all-gather of the per-rank slice record  [B*H*M*(C+2)] floats  (~70 KB at C3), merged by
+the log-sum-exp rule on every rank.  The message is latency-bound, so it is a single
+all-gather (one hop on the fully connected xGMI node), not a ring all-reduce of max + sum.
+Everything after the merge (token positions, ball tree, Erwin) is replicated.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def allgather_records(local_record: torch.Tensor, group=None) -> torch.Tensor:
+    """[rec] on each rank -> [R, rec] in rank order on every rank."""
+    world = dist.get_world_size(group)
+    out = torch.empty((world, local_record.numel()), dtype=local_record.dtype, device=local_record.device)
+    dist.all_gather_into_tensor(out, local_record.contiguous(), group=group)
+    return out
+
+
+def shard_points(model: torch.nn.Module, group=None) -> torch.nn.Module:
+    """Mark every Physics_Attention_* module of `model` as point-sharded over `group`."""
+    from .PhysicsAttention._base import PhysicsAttentionBase
+
+    for m in model.modules():
+        if isinstance(m, PhysicsAttentionBase):
+            m.shard_group = group if group is not None else dist.group.WORLD
+    return model
+
+
+def shard_bounds(n_points: int, rank: int, world: int):
+    """Contiguous, balanced split of n_points (first n % world ranks get one extra)."""
+    base, extra = divmod(n_points, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)

@@ -1,0 +1,179 @@
+/*
+ * haet_hip.h -- C ABI of libhaet_hip.so: the MI355X (gfx950) implementation of
+ * HAET's PhysicsAttention hot path.
+ *
+ * The reference (pedrocurvo/HAET) has no FFI layer of its own; its seams on this
+ * path are Python calls into third-party / native code.  Each entry point below
+ * replaces one of them (reference file:line given per function).  A maintainer
+ * binds these with ctypes; this repo's own binding is
+ * haet_amd/_lib.py.
+ *
+ * Conventions
+ *   - plain C, no exceptions: return 0 on success, a negative HAET_E_* code on
+ *     error; haet_last_error_string() describes the last error of the calling
+ *     thread.
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch CUDA tensor storage),
+ *     row-major, contiguous, fp32 unless stated; the caller owns all buffers.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*,
+ *     NULL = the null stream); no allocation, no synchronisation inside, so the
+ *     sequence can be captured into a hipGraph.
+ *   - workspaces are sized by the *_workspace_bytes / *_parts queries first.
+ *   - single-threaded caller per stream; functions are re-entrant (no globals
+ *     except the thread-local error string).
+ *
+ * Notation: B batch, N points, H heads, C = dim_head, M = slice_num,
+ *           T = B*H*M slice tokens, d = token-position dimensionality (2 or 3).
+ */
+#ifndef HAET_HIP_H
+#define HAET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HAET_ABI_VERSION 1
+
+#define HAET_OK 0
+#define HAET_E_ARG (-1)      /* bad argument / unsupported shape */
+#define HAET_E_LAUNCH (-2)   /* hip launch error */
+#define HAET_E_RESOURCE (-3) /* needs more LDS / workspace than available */
+
+typedef void* haet_stream_t;
+
+int haet_abi_version(void);
+const char* haet_last_error_string(void);
+
+/* ------------------------------------------------------------------ slice pass
+ * Replaces the materialised Rep-Slice softmax + eidetic einsum of
+ * models/PhysicsAttention/IrregularMesh.py:168-188 (Ada-Temp, logits, softmax over
+ * the POINT axis, slice_norm, 'bhnc,bhng->bhgc', normalise) by one streaming pass
+ * with an online softmax over N.
+ *
+ * x_lin [B, N, H*C] is the output of in_project_x in its natural layout (the
+ * reference's permute to [B,H,N,C], IrregularMesh.py:157-164, is never done).
+ *
+ * The pass produces `P = haet_slice_num_parts(...)` partial records, one per
+ * point chunk.  A record holds, for every (b,h,g):  m = max_n z, l = sum_n
+ * exp(z - m), St[c] = sum_n exp(z - m) x[n,c]  with z = (x.Ws[g] + bs[g] - c0)/tau_n,
+ * laid out as  [B*H][ m[M] | l[M] | St[M][C] ]  (B*H*M*(C+2) floats).
+ */
+int haet_slice_num_parts(int B, int N, int H, int C, int M);
+size_t haet_slice_part_floats(int B, int H, int C, int M); /* floats per record */
+
+int haet_slice_fwd(const float* x_lin, const float* Ws /*[M,C]*/, const float* bs /*[M]*/,
+                   const float* wt /*[C]*/, float bt, float base_temp, float c0 /*log(-log eps)*/,
+                   int B, int N, int H, int C, int M,
+                   float* parts /*[P][record]*/, haet_stream_t stream);
+
+/* Log-sum-exp merge of R records (workgroup partials of one GPU, or the
+ * all-gathered records of R ranks -- SURVEY.md 8e):
+ *   m = max_r m_r;  l = sum_r l_r e^{m_r-m};  St = sum_r St_r e^{m_r-m}.
+ * finalize == 0: write one merged record to `out_record`.
+ * finalize != 0: also write col_max[B*H*M], col_sum[B*H*M] and the normalised
+ *   eidetic states S[B*H*M, C] = (St / l) / (1 + 1e-5)   (IrregularMesh.py:177,186-188;
+ *   sum_n softmax == 1). out_record may be NULL then.
+ */
+int haet_slice_merge(const float* records, int R, int B, int H, int C, int M, int finalize,
+                     float* out_record, float* col_max, float* col_sum, float* S,
+                     haet_stream_t stream);
+
+/* ------------------------------------------------------------------ token positions
+ * models/PhysicsAttention/IrregularMesh.py:204-209: per-channel min/max over ALL T
+ * tokens, pos[t, j] = (S[t,j] - min_j) / (max_j - min_j + 1e-8), j < d.            */
+int haet_token_pos(const float* S /*[T,C]*/, int T, int C, int d, float* pos /*[T,d]*/,
+                   haet_stream_t stream);
+
+/* ------------------------------------------------------------------ ball tree
+ * Device replacement of balltree.build_balltree_with_rotations
+ * (models/components/balltree/balltree.pyx:598-662 -> balltree.h:32-259), which the
+ * reference runs on the HOST with a GPU->CPU->GPU sync every forward.
+ * n_clouds = B*H equally sized clouds of M points (batch_idx = arange(B*H)
+ * .repeat_interleave(M), IrregularMesh.py:213).  Mp = 2*2^(ceil(log2 M)-1) slots per
+ * cloud.  Outputs (device):
+ *   tree_idx  int32[n_clouds*Mp]  global token index per slot (libstdc++ nth_element order)
+ *   tree_mask uint8[n_clouds*Mp]  0 = padding duplicate
+ *   rot       int32[...]          for level i (0..n_levels-1) the rotated re-partition,
+ *                                 n_clouds*Mp/prod(strides[:i]) entries each, concatenated;
+ *                                 values index positions in tree order at that level.
+ *                                 Not written when angle <= 0.
+ * targets[i] = max(0, int(log2(total_leaves / ball_sizes[i])))  (balltree.pyx:643) is
+ * computed by the caller.  Indices are int32 (T < 2^31); the reference returns int64.
+ */
+int haet_balltree_build(const float* pos /*[n_clouds*M, d]*/, int n_clouds, int M, int d,
+                        int n_levels, const int* strides /*[n_levels-1], host*/,
+                        const int* targets /*[n_levels], host*/, float angle_deg,
+                        int32_t* tree_idx, uint8_t* tree_mask, int32_t* rot,
+                        haet_stream_t stream);
+
+/* ------------------------------------------------------------------ Erwin stage
+ * Replaces ErwinTransformer.forward with embed=False, mp_steps=0
+ * (models/components/erwinflash/erwin_flash.py:138-195; BasicLayer layers.py:72-92;
+ * ErwinTransformerBlock layers.py:30-32; BallMSA attention.py:42-91 incl. the
+ * flash_attn_qkvpacked_func call :82-84; SwiGLU mlp.py:8-18; BallPooling/
+ * BallUnpooling pooling.py:25-72) for eval-mode BatchNorm, one workgroup per cloud.
+ *
+ * `desc` (host, passed to the kernel by value) describes the network; `weights` (device) is
+ * ONE packed fp32 blob laid out by haet_amd/erwin_pack.py.  Returns HAET_E_RESOURCE when the
+ * token state of one cloud does not fit the 160 KiB LDS of a CU.
+ */
+#define HAET_ERWIN_MAX_LEVELS 4
+#define HAET_ERWIN_MAX_DEPTH 4
+
+typedef struct {
+    /* offsets (in floats) into the packed weight blob; Linear weights are stored
+     * TRANSPOSED, [in][out], so that consecutive lanes read consecutive outputs */
+    int32_t norm1, norm2;            /* [c] */
+    int32_t pe_w, pe_b;              /* [d][c], [c] */
+    int32_t qkv_w, qkv_b;            /* [c][3c], [3c] */
+    int32_t proj_w, proj_b;          /* [c][c], [c] */
+    int32_t w1_w, w1_b, w2_w, w2_b;  /* [c][hidden], [hidden] */
+    int32_t w3_w, w3_b;              /* [hidden][c], [c] */
+} haet_erwin_block_w;
+
+typedef struct {
+    int32_t c, heads, ball, depth, hidden; /* channels, heads, ball size, #blocks, SwiGLU width */
+    haet_erwin_block_w blocks[HAET_ERWIN_MAX_DEPTH];
+} haet_erwin_layer;
+
+typedef struct {
+    int32_t stride;
+    int32_t w, b;               /* Linear, [K][out] / [out] */
+    int32_t bn_scale, bn_shift; /* eval BatchNorm as y*scale+shift, [c_out] */
+} haet_erwin_resample;
+
+typedef struct {
+    int32_t n_levels; /* encoder layers + bottleneck (>= 1) */
+    int32_t d;        /* position dimensionality (2 or 3) */
+    int32_t rotate;   /* 1: odd blocks run on the rotated partition */
+    int32_t decode;   /* must be 1 */
+    haet_erwin_layer enc[HAET_ERWIN_MAX_LEVELS];       /* enc[n_levels-1] is the bottleneck */
+    haet_erwin_layer dec[HAET_ERWIN_MAX_LEVELS];       /* dec[i] runs at level i (i < n_levels-1) */
+    haet_erwin_resample pool[HAET_ERWIN_MAX_LEVELS];   /* level i -> i+1 */
+    haet_erwin_resample unpool[HAET_ERWIN_MAX_LEVELS]; /* level i+1 -> i */
+} haet_erwin_desc;
+
+size_t haet_erwin_lds_bytes(const haet_erwin_desc* desc, int Mp);
+
+int haet_erwin_fwd(const float* tokens /*[n_clouds*M, c0]*/, const float* pos /*[n_clouds*M, d]*/,
+                   const int32_t* tree_idx, const uint8_t* tree_mask, const int32_t* rot,
+                   const float* weights, const haet_erwin_desc* desc,
+                   int n_clouds, int M, float* out /*[n_clouds*M, c0]*/, haet_stream_t stream);
+
+/* ------------------------------------------------------------------ de-slice pass
+ * Replaces einsum('bhgc,bhng->bhnc') + rearrange 'b h n d -> b n (h d)'
+ * (models/PhysicsAttention/IrregularMesh.py:228-232): recomputes the slice weights
+ * w[n,g] = exp(z - col_max[g]) / col_sum[g] from x_lin and writes
+ * out_x[b,n,h*C+c] = sum_g w[n,g] * S2[b,h,g,c]   directly in [B,N,H*C].            */
+int haet_deslice_fwd(const float* x_lin, const float* Ws, const float* bs, const float* wt,
+                     float bt, float base_temp, float c0,
+                     const float* col_max /*[B*H*M]*/, const float* col_sum /*[B*H*M]*/,
+                     const float* S2 /*[B*H*M, C]*/, int B, int N, int H, int C, int M,
+                     float* out_x /*[B,N,H*C]*/, haet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAET_HIP_H */

@@ -1,0 +1,83 @@
+"""CPU: host-side mirror of the reference interface -- constructor surface, state_dict keys
+(checked against the state_dicts the reference itself produced, stored in the fixtures),
+loud failure without the HIP path, weight packing."""
+import pytest
+import torch
+
+import haet_amd
+from haet_amd.PhysicsAttention import (Physics_Attention_Irregular_Mesh,
+                                       Physics_Attention_Structured_Mesh_2D,
+                                       Physics_Attention_Structured_Mesh_3D)
+from haet_amd._lib import HaetError
+from tests import golden_util as G
+
+CTOR = {"irregular": Physics_Attention_Irregular_Mesh, "structured2d": Physics_Attention_Structured_Mesh_2D,
+        "structured3d": Physics_Attention_Structured_Mesh_3D}
+
+
+@pytest.mark.parametrize("name", G.attn_fixture_names())
+def test_attention_state_dict_matches_reference(name):
+    x, sd, meta, exp, rows = G.load_attn(name)
+    mod = CTOR[meta["kind"]](**meta["kw"])
+    mod.load_state_dict(sd, strict=True)  # identical keys and shapes
+
+
+@pytest.mark.parametrize("name", G.model_fixture_names())
+def test_model_state_dict_matches_reference(name):
+    x, fx, sd, meta, out = G.load_model(name)
+    model = getattr(haet_amd, meta["cls"])(**meta["kw"])
+    model.load_state_dict(sd, strict=True)
+
+
+def test_default_erwin_hyperparameters():
+    m = Physics_Attention_Irregular_Mesh(256, heads=8, dim_head=32, slice_num=64, rotate=45)
+    assert m.erwin.ball_sizes == [32, 16] and m.erwin.strides == [2]
+    assert m.erwin.encoder[0].num_heads == 4 and m.erwin.bottleneck.num_heads == 8
+    assert m.erwin.c_hidden == [32, 64] and m.dimensionality == 3
+    assert Physics_Attention_Structured_Mesh_2D(64, heads=4, dim_head=16, H=8, W=8).dimensionality == 2
+
+
+def test_no_cpu_fallback():
+    m = Physics_Attention_Irregular_Mesh(64, heads=4, dim_head=16, slice_num=8).eval()
+    with torch.no_grad(), pytest.raises(HaetError):
+        m(torch.randn(1, 100, 64))
+
+
+def test_backward_is_refused_loudly():
+    m = Physics_Attention_Irregular_Mesh(64, heads=4, dim_head=16, slice_num=8).eval()
+    with pytest.raises(NotImplementedError):
+        m(torch.randn(1, 100, 64))
+
+
+def test_embedding_variants_are_out_of_scope():
+    with pytest.raises(NotImplementedError):
+        Physics_Attention_Irregular_Mesh(64, heads=4, dim_head=16, slice_num=8, embed=True)
+
+
+def test_pack_erwin_layout():
+    from haet_amd.components.erwinflash.pack import pack_erwin
+
+    m = Physics_Attention_Irregular_Mesh(256, heads=8, dim_head=32, slice_num=64, rotate=45).eval()
+    blob, desc = pack_erwin(m.erwin)
+    assert desc.n_levels == 2 and desc.d == 3 and desc.rotate == 1 and desc.decode == 1
+    e0, e1, d0 = desc.enc[0], desc.enc[1], desc.dec[0]
+    assert (e0.c, e0.heads, e0.ball, e0.depth, e0.hidden) == (32, 4, 32, 2, 128)
+    assert (e1.c, e1.heads, e1.ball, e1.depth, e1.hidden) == (64, 8, 16, 2, 256)
+    assert (d0.c, d0.heads, d0.ball, d0.depth) == (32, 4, 32, 2)
+    # transposed Linear: blob[qkv_w + k*3c + o] == qkv.weight[o, k]
+    blk = m.erwin.encoder[0].blocks[1]
+    w = e0.blocks[1]
+    assert torch.equal(blob[w.qkv_w:w.qkv_w + 32 * 96].view(32, 96), blk.BMSA.qkv.weight.t())
+    assert w.qkv_w % 4 == 0 and w.w3_w % 4 == 0
+    pool = m.erwin.encoder[0].pool
+    assert torch.equal(blob[desc.pool[0].w:desc.pool[0].w + 70 * 64].view(70, 64), pool.proj.weight.t())
+    from haet_amd import _lib
+    import ctypes
+    assert 0 < _lib.load().haet_erwin_lds_bytes(ctypes.byref(desc), 64) < 160 * 1024
+
+
+def test_rot_targets_use_total_leaf_count():
+    from haet_amd.ops import rot_targets, tree_slots
+
+    assert rot_targets(512, [32, 16]) == [4, 5]  # C3: 8 clouds x 64 slots (balltree.pyx:643 quirk)
+    assert tree_slots(64) == 64 and tree_slots(12) == 16 and tree_slots(5) == 8 and tree_slots(2) == 2
