@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Headline benchmark: PhysicsAttention forward throughput (points/s) on a 1M-point
+irregular mesh, M = 64 slices (BASELINE.json metric / config C3), on N GPUs of one node.
+
+A step = one forward of Physics_Attention_Irregular_Mesh(dim=256, heads=8, dim_head=32,
+slice_num=64, rotate=45) over one synthetic cloud of `--points` points resident in HBM
+(the module-level workload of SURVEY.md 8d).  With N > 1 the SAME cloud is point-sharded
+over the ranks (strong scaling, config C4): one all-gather of the slice records per forward.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline     -- the dominant hand-written kernel: algorithmic bytes / measured duration
+                  (HIP events on the launch stream) against the 8 TB/s HBM peak
+  cpu_baseline -- the CPU oracle (op-for-op port of the reference's forward) timed on the
+                  host cores of this box on the same 1M-point input (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
+STAGES = ("project", "slice", "merge", "token", "erwin", "deslice", "to_out")
+# algorithmic HBM bytes per point of the two streaming kernels (DESIGN.md / SURVEY.md 8d), fp32 I/O
+BYTES_PER_POINT = {"slice": lambda HC: 4 * HC, "deslice": lambda HC: 8 * HC}
+
+
+def build_module(dev):
+    from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh
+    import torch.nn as nn
+
+    torch.manual_seed(0)
+    mod = Physics_Attention_Irregular_Mesh(dim=256, heads=8, dim_head=32, slice_num=64, rotate=45)
+    # the weight-init rule the reference's Model applies (HAETransolver_Irregular_Mesh.py:279-295)
+    for m in mod.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            nn.init.constant_(m.bias, 0)
+    return mod.eval().to(dev)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from haet_amd import _lib
+    from haet_amd.sharding import shard_bounds, shard_points
+
+    _lib.load()
+    mod = build_module(dev)
+    if world > 1:
+        shard_points(mod)
+
+    N = args.points
+    a, b = shard_bounds(N, rank, world)
+    g = torch.Generator().manual_seed(1234)
+    # the full synthetic cloud is generated identically on every rank, each keeps its shard
+    x_full = torch.randn(1, N, 256, generator=g)
+    x = x_full[:, a:b].contiguous().to(dev)
+    if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
+        del x_full
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = mod(x)
+        mod.stage_events = []  # per-stage HIP events on the launch stream, read after the loop
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = mod(x)
+        sync()
+        dt = time.perf_counter() - t0
+    events = mod.stage_events
+    mod.stage_events = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    stage_ms = {s: 0.0 for s in STAGES}
+    for name, e0, e1 in events:
+        stage_ms[name] += e0.elapsed_time(e1)
+    stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        dom = max(("slice", "deslice"), key=lambda k: stage_ms[k])
+        n_local = b - a
+        gbs = n_local * BYTES_PER_POINT[dom](256) / (stage_ms[dom] * 1e-3) / 1e9
+        res = {
+            "metric": "forward points/sec + L2 vs ref, 1M-pt irregular mesh, M=64 slices",
+            "value": N * args.steps / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: Physics_Attention_Irregular_Mesh forward, "
+                       f"N={N} points, dim=256, heads=8, dim_head=32, M=64, Erwin defaults, B=1",
+                       "points": N, "slices": 64, "sharding": f"points/{world}"},
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res.update(cpu_leg(mod, x_full, out))
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_leg(mod, x_full, gpu_out):
+    """CPU oracle on the same input: the reported CPU baseline (kind 'port': the reference
+    itself cannot travel to this box) and the full-size rel-L2 of the GPU result."""
+    from oracle import haet_oracle as O
+
+    n_thr = os.cpu_count() or 1
+    torch.set_num_threads(n_thr)
+    cfg = O.AttnCfg(dim=256, heads=8, dim_head=32, slice_num=64, rotate=45)
+    sd = {k: v.detach().cpu() for k, v in mod.state_dict().items()}
+    times = []
+    with torch.no_grad():
+        for i in range(3):  # 1 warm-up + 2 timed forwards of the full 1M-point cloud
+            t0 = time.perf_counter()
+            ref = O.physics_attention_forward(x_full, sd, cfg)
+            times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    N = x_full.shape[1]
+    return {
+        "cpu_baseline": {"value": N / best, "unit": "points/s", "cores": torch.get_num_threads(),
+                         "kind": "port",
+                         "sample": f"full workload: {N}-point forward, fp32, best of 2 after 1 warm-up "
+                                   f"({best:.2f} s each)"},
+        "rel_l2_vs_cpu_oracle": O.rel_l2(gpu_out.cpu(), ref),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,25 @@ from ..components import ErwinFlashTransformer as ErwinTransformer
 from .._lib import HaetError
 
 
+class _StageTimer:
+    """Brackets a stage with HIP events on the current (= launch) stream when enabled."""
+
+    def __init__(self, sink, name):
+        self.sink, self.name = sink, name
+
+    def __enter__(self):
+        if self.sink is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.sink is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.sink.append((self.name, self.e0, e1))
+        return False
+
+
 class PhysicsAttentionBase(nn.Module):
     dimensionality = 3
 
@@ -61,6 +80,7 @@ class PhysicsAttentionBase(nn.Module):
             mp_steps=mp_steps, embed=embed)
         self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout))
         self.shard_group = None  # torch.distributed group over which the POINTS are sharded
+        self.stage_events = None  # set to [] to collect (stage, start, end) HIP events (bench.py)
         self._slice_cache = None
 
     # -- per-variant projection to [B, N, H*C] -------------------------------------------
@@ -77,6 +97,9 @@ class PhysicsAttentionBase(nn.Module):
             self._slice_cache = (key, sp)
         return self._slice_cache[1]
 
+    def _stage(self, name):
+        return _StageTimer(self.stage_events, name)
+
     def forward(self, x: torch.Tensor, return_intermediates: bool = False):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError(
@@ -87,19 +110,27 @@ class PhysicsAttentionBase(nn.Module):
                             "and its input with .cuda() -- there is no CPU fallback")
         B, N, _ = x.shape
         H, C, G = self.heads, self.dim_head, self.slice_num
-        x_lin = self.project(x).float().contiguous()                    # [B, N, H*C]
+        ev = self._stage
+        with ev("project"):
+            x_lin = self.project(x).float().contiguous()                # [B, N, H*C]
         sp = self._slice_params()
-        parts = ops.slice_partials(x_lin, sp, H, C, G)                  # [P, record]
-        if self.shard_group is not None:
-            from ..sharding import allgather_records
+        with ev("slice"):
+            parts = ops.slice_partials(x_lin, sp, H, C, G)              # [P, record]
+        with ev("merge"):
+            if self.shard_group is not None:
+                from ..sharding import allgather_records
 
-            local = ops.merge_records(parts, B, H, C, G, finalize=False)
-            parts = allgather_records(local, self.shard_group)          # [R, record]
-        col_max, col_sum, S = ops.merge_records(parts, B, H, C, G, finalize=True)
-        pos = ops.token_pos(S, self.dimensionality)                      # [B*H*G, d]
-        S2 = self.erwin(S, pos, n_clouds=B * H)                          # [B*H*G, C]
-        out_x = ops.deslice(x_lin, sp, col_max, col_sum, S2, H, C, G)    # [B, N, H*C]
-        out = self.to_out(out_x.to(x.dtype))
+                local = ops.merge_records(parts, B, H, C, G, finalize=False)
+                parts = allgather_records(local, self.shard_group)      # [R, record]
+            col_max, col_sum, S = ops.merge_records(parts, B, H, C, G, finalize=True)
+        with ev("token"):
+            pos = ops.token_pos(S, self.dimensionality)                  # [B*H*G, d]
+        with ev("erwin"):
+            S2 = self.erwin(S, pos, n_clouds=B * H)                      # [B*H*G, C]
+        with ev("deslice"):
+            out_x = ops.deslice(x_lin, sp, col_max, col_sum, S2, H, C, G)  # [B, N, H*C]
+        with ev("to_out"):
+            out = self.to_out(out_x.to(x.dtype))
         if return_intermediates:
             return out, dict(x_lin=x_lin, col_max=col_max, col_sum=col_sum, eidetic=S, pos=pos,
                              processed=S2, out_x=out_x)

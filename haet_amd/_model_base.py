@@ -78,8 +78,8 @@ class ModelBase(nn.Module):
             emb = timestep_embedding(T, self.n_hidden).repeat(1, x.shape[1], 1)
             fx = fx + self.time_fc(emb)
         for block in self.blocks:
-            if getattr(self, "use_checkpoint", False):
-                fx = checkpoint.checkpoint(block, fx)
+            if getattr(self, "use_checkpoint", False) and torch.is_grad_enabled():
+                fx = checkpoint.checkpoint(block, fx, use_reentrant=False)
             else:
                 fx = block(fx)
         return fx

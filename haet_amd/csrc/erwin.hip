@@ -178,6 +178,8 @@ __device__ void ball_attention(const float* qkv, int ldq, int n, int c, int head
 __device__ void attention_dispatch(int hd, const float* qkv, int ldq, int n, int c, int heads,
                                    int ball, const int* perm, float* A, int lda) {
     switch (hd) {
+        case 1: ball_attention<1>(qkv, ldq, n, c, heads, ball, perm, A, lda); break;
+        case 2: ball_attention<2>(qkv, ldq, n, c, heads, ball, perm, A, lda); break;
         case 4: ball_attention<4>(qkv, ldq, n, c, heads, ball, perm, A, lda); break;
         case 8: ball_attention<8>(qkv, ldq, n, c, heads, ball, perm, A, lda); break;
         case 16: ball_attention<16>(qkv, ldq, n, c, heads, ball, perm, A, lda); break;
@@ -435,7 +437,7 @@ static int erwin_validate(const haet_erwin_desc* D, int Mp) {
             if (L.c < 4 || L.c % 4) return fail(HAET_E_ARG, "erwin: channels=%d (multiple of 4)", L.c);
             if (L.heads < 1 || L.c % L.heads) return fail(HAET_E_ARG, "erwin: heads=%d", L.heads);
             const int hd = L.c / L.heads;
-            if (hd != 4 && hd != 8 && hd != 16 && hd != 32 && hd != 64)
+            if (hd != 1 && hd != 2 && hd != 4 && hd != 8 && hd != 16 && hd != 32 && hd != 64)
                 return fail(HAET_E_ARG, "erwin: head_dim=%d unsupported", hd);
             if (L.ball < 1 || n % L.ball)
                 return fail(HAET_E_ARG, "erwin: ball size %d does not divide %d tokens", L.ball, n);

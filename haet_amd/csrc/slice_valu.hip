@@ -256,8 +256,8 @@ static int launch_deslice(int NG, dim3 grid, size_t lds, hipStream_t st, const f
 
 int slice_shape_ok(int B, int N, int H, int C, int M) {
     if (B < 1 || N < 1 || H < 1 || M < 1) return fail(HAET_E_ARG, "slice: B,N,H,M must be >= 1");
-    if (C != 16 && C != 32 && C != 64)
-        return fail(HAET_E_ARG, "slice: dim_head C=%d unsupported (16, 32 or 64)", C);
+    if (C != 8 && C != 16 && C != 32 && C != 64)
+        return fail(HAET_E_ARG, "slice: dim_head C=%d unsupported (8, 16, 32 or 64)", C);
     if (M > 128) return fail(HAET_E_ARG, "slice: slice_num M=%d unsupported (<= 128)", M);
     if ((long long)B * H > 65535) return fail(HAET_E_ARG, "slice: B*H too large");
     return HAET_OK;
@@ -272,6 +272,7 @@ int slice_valu_fwd(const float* x, const float* Ws, const float* bs, const float
     dim3 grid(P, B * H);
     const size_t lds = (size_t)(C + 2) * 64 * NG * sizeof(float);
     switch (C) {
+        case 8: return launch_slice<8>(NG, grid, lds, st, x, Ws, bs, wt, bt, base_temp, c0, N, H, M, chunk, parts);
         case 16: return launch_slice<16>(NG, grid, lds, st, x, Ws, bs, wt, bt, base_temp, c0, N, H, M, chunk, parts);
         case 32: return launch_slice<32>(NG, grid, lds, st, x, Ws, bs, wt, bt, base_temp, c0, N, H, M, chunk, parts);
         default: return launch_slice<64>(NG, grid, lds, st, x, Ws, bs, wt, bt, base_temp, c0, N, H, M, chunk, parts);
@@ -285,6 +286,7 @@ int deslice_valu_fwd(const float* x, const float* Ws, const float* bs, const flo
     dim3 grid((N + chunk - 1) / chunk, B * H);
     const size_t lds = ((size_t)M * C + 4 * (64 / C) * M) * sizeof(float);
     switch (C) {
+        case 8: return launch_deslice<8>(NG, grid, lds, st, x, Ws, bs, wt, bt, base_temp, c0, cm, cs, S2, N, H, M, chunk, out);
         case 16: return launch_deslice<16>(NG, grid, lds, st, x, Ws, bs, wt, bt, base_temp, c0, cm, cs, S2, N, H, M, chunk, out);
         case 32: return launch_deslice<32>(NG, grid, lds, st, x, Ws, bs, wt, bt, base_temp, c0, cm, cs, S2, N, H, M, chunk, out);
         default: return launch_deslice<64>(NG, grid, lds, st, x, Ws, bs, wt, bt, base_temp, c0, cm, cs, S2, N, H, M, chunk, out);
