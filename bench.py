@@ -137,18 +137,35 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cores():
+    """Threads for the CPU leg: the cores this process may really use (affinity mask, cgroup
+    quota); a GPU box exposes all 256 host threads but grants one GPU's share of them (16),
+    and 256 oversubscribed threads run the CPU path ~4x slower than 16."""
+    env = os.environ.get("HAET_CPU_THREADS")
+    if env:
+        return int(env)
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n if n <= 32 else 16
+
+
 def cpu_leg(mod, x_full, gpu_out):
     """CPU oracle on the same input: the reported CPU baseline (kind 'port': the reference
     itself cannot travel to this box) and the full-size rel-L2 of the GPU result."""
     from oracle import haet_oracle as O
 
-    n_thr = os.cpu_count() or 1
+    n_thr = host_cores()
     torch.set_num_threads(n_thr)
     cfg = O.AttnCfg(dim=256, heads=8, dim_head=32, slice_num=64, rotate=45)
     sd = {k: v.detach().cpu() for k, v in mod.state_dict().items()}
     times = []
     with torch.no_grad():
-        for i in range(3):  # 1 warm-up + 2 timed forwards of the full 1M-point cloud
+        for i in range(3):  # 1 warm-up + 2 timed forwards of the full cloud (~6 s each on 16 cores)
             t0 = time.perf_counter()
             ref = O.physics_attention_forward(x_full, sd, cfg)
             times.append(time.perf_counter() - t0)
