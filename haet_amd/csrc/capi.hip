@@ -1,4 +1,5 @@
 // C-ABI glue: error string, version, and the shape dispatch of the slice / de-slice passes.
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -27,6 +28,25 @@ int deslice_valu_fwd(const float*, const float*, const float*, const float*, flo
                      const float*, const float*, const float*, int, int, int, int, int, float*,
                      hipStream_t);
 
+// slice_mfma.hip
+struct MfmaPlan {
+    int li, ipw, mb, hpw, tiles_per_chunk, parts;
+    size_t lds_slice, lds_deslice;
+};
+bool mfma_plan(int B, int N, int H, int C, int M, MfmaPlan* p);
+int slice_mfma_fwd(const float*, const float*, const float*, const float*, float, float, float, int,
+                   int, int, int, int, float*, hipStream_t);
+int deslice_mfma_fwd(const float*, const float*, const float*, const float*, float, float, float,
+                     const float*, const float*, const float*, int, int, int, int, int, float*,
+                     hipStream_t);
+
+// HAET_FORCE_VALU=1 routes every shape through the generic fp32 VALU kernels (tests)
+static bool use_mfma(int B, int N, int H, int C, int M, MfmaPlan* p) {
+    const char* e = getenv("HAET_FORCE_VALU");
+    if (e && e[0] == '1') return false;
+    return mfma_plan(B, N, H, C, M, p);
+}
+
 }  // namespace haet
 
 using namespace haet;
@@ -36,6 +56,8 @@ extern "C" const char* haet_last_error_string(void) { return err_buf(); }
 
 extern "C" int haet_slice_num_parts(int B, int N, int H, int C, int M) {
     if (slice_shape_ok(B, N, H, C, M) != HAET_OK) return HAET_E_ARG;
+    MfmaPlan p;
+    if (use_mfma(B, N, H, C, M, &p)) return p.parts;
     return slice_valu_num_parts(N);
 }
 
@@ -49,6 +71,8 @@ extern "C" int haet_slice_fwd(const float* x_lin, const float* Ws, const float* 
     if (!x_lin || !Ws || !bs || !wt || !parts) return fail(HAET_E_ARG, "slice_fwd: null pointer");
     int rc = slice_shape_ok(B, N, H, C, M);
     if (rc != HAET_OK) return rc;
+    if (use_mfma(B, N, H, C, M, nullptr))
+        return slice_mfma_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, B, N, H, C, M, parts, as_stream(stream));
     return slice_valu_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, B, N, H, C, M, parts, as_stream(stream));
 }
 
@@ -60,6 +84,9 @@ extern "C" int haet_deslice_fwd(const float* x_lin, const float* Ws, const float
         return fail(HAET_E_ARG, "deslice_fwd: null pointer");
     int rc = slice_shape_ok(B, N, H, C, M);
     if (rc != HAET_OK) return rc;
+    if (use_mfma(B, N, H, C, M, nullptr))
+        return deslice_mfma_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, S2, B, N, H, C,
+                                M, out_x, as_stream(stream));
     return deslice_valu_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, S2, B, N, H, C, M,
                             out_x, as_stream(stream));
 }

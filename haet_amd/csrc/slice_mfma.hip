@@ -1,0 +1,562 @@
+// MFMA kernels for the two streaming passes (slice, de-slice) -- gfx950 only.
+//
+// Roofline: both passes are HBM-bound (read H*C*4 B per point; de-slice also writes as
+// much): 1024 / 2048 B per point at H*C = 256.  The arithmetic (2*H*C*M MACs per point
+// and pass) runs on the matrix cores as split-bf16: every fp32 operand is carried as
+// hi + lo bf16 (hi = RNE(x), lo = RNE(x - hi)) and each product is three MFMAs
+// (hi*hi + hi*lo + lo*hi) accumulated in fp32 -- ~2^-16 relative operand error, which
+// keeps the path inside the 1e-3 fp32 parity bar (plain bf16 does not: SURVEY.md s.7).
+//
+// Slice pass == single-query-block flash attention with Q = W_s (M slice queries),
+// K = V = x_proj tile:
+//   Y[n,g]  = X[n,:] . Ws[g,:] + b_g          v_mfma_f32_32x32x16_bf16, A = X rows, B = Ws
+//   p[n,g]  = exp2(Y * s_n - m2_g)            s_n = log2(e)/tau_n ; lane = g, regs = n
+//   Z[g,c] += sum_n p[n,g] X[n,c]             A = P straight from the accumulator
+//                                             (acc tile as next operand), B = X via
+//                                             ds_read_b64_tr_b16 (transposed LDS read)
+// The column max is a *reference* m2_g (deferred: rescale only when the tile max exceeds it
+// by 2^20), so (m, l, St) stay a valid log-sum-exp record without tracking the exact max.
+//
+// De-slice keeps the POINT on the lane through the whole chain, so nothing is transposed:
+//   Yt[g,n] = Ws[g,:] . X[n,:] + b_g          A = Ws rows, B = X rows
+//   pt[g,n] = exp2(Yt * s_n - m2_g)
+//   Ot[c,n] = sum_g (S'[g,c]/l_g) pt[g,n]     A = S' (pre-scaled), B = P from the accumulator
+//
+// Tile = 32 points x all heads.  All 8 waves stage it: coalesced 1 KB row loads -> fp32 ->
+// {hi, lo} bf16 -> LDS images [head][hi|lo][32 rows][C] (64-B rows, 16-B chunks XOR-swizzled
+// by (row>>2)&3: conflict-free for both the b128 row reads and the tr_b16 reads), and
+// Ada-Temp tau per (point, head) is reduced in the loader (8 lanes per head, DPP).  Loads
+// for tile t+1 are issued before computing tile t and written to the other LDS buffer
+// after it (one barrier per tile).
+#include "common.h"
+
+namespace haet {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+constexpr int TN = 32;          // points per tile
+constexpr int NW = 8;           // waves per workgroup
+constexpr int NTHR = NW * 64;
+constexpr int kC = 32;          // dim_head of this fast path
+constexpr int IMG = 2048 + 32;  // bytes per [32][32] bf16 image (+32: de-phase heads in the banks)
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kThr2 = 20.0f;  // deferred-max threshold, log2 units
+
+struct Frag {
+    u32x4 hi, lo;
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// 8 fp32 -> split-bf16 operand fragment (element j in bf16 slot j)
+__device__ __forceinline__ Frag split8(const float (&v)[8]) {
+    Frag f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned h = pack_bf16(v[2 * i], v[2 * i + 1]);
+        const float h0 = __uint_as_float(h << 16), h1 = __uint_as_float(h & 0xffff0000u);
+        f.hi[i] = h;
+        f.lo[i] = pack_bf16(v[2 * i] - h0, v[2 * i + 1] - h1);
+    }
+    return f;
+}
+
+__device__ __forceinline__ f32x16 mfma3(const Frag& a, const Frag& b, f32x16 c) {
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, a.hi), al = __builtin_bit_cast(bf16x8, a.lo);
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi), bl = __builtin_bit_cast(bf16x8, b.lo);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+    return c;
+}
+
+// byte offset of (row, 16-B chunk) in a swizzled [32][32] bf16 image
+__device__ __forceinline__ int img_off(int row, int chunk) {
+    return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// ----------------------------------------------------------------------------- tile loader
+// LI = ceil(H/2): 16-B chunks per thread per tile (32 rows x H*8 chunks / 512 threads)
+template <int LI>
+struct Loader {
+    f32x4 xr[LI];
+    float wt4[4];
+    int q8;  // chunk index inside the head: c0 = 4*q8
+
+    __device__ __forceinline__ void init(const float* __restrict__ wt) {
+        q8 = threadIdx.x & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wt4[i] = wt[4 * q8 + i];
+    }
+    // issue the global loads of one tile (rows >= nvalid read as zero)
+    __device__ __forceinline__ void fetch(const float* __restrict__ xb, int H, int row0, int nvalid) {
+        const int cpr = H * 8;  // chunks per row
+#pragma unroll
+        for (int i = 0; i < LI; ++i) {
+            const int e = threadIdx.x + NTHR * i;
+            const int row = e / cpr, q = e - row * cpr;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < TN && row < nvalid)
+                v = *reinterpret_cast<const f32x4*>(xb + ((size_t)(row0 + row) * cpr + q) * 4);
+            xr[i] = v;
+        }
+    }
+    // split to bf16 hi/lo, write the LDS images, reduce Ada-Temp and write s_n = log2e / tau
+    __device__ __forceinline__ void stage(char* buf, float* sarr, int H, float bt, float base_temp) {
+        const int cpr = H * 8;
+#pragma unroll
+        for (int i = 0; i < LI; ++i) {
+            const int e = threadIdx.x + NTHR * i;
+            const int row = e / cpr, q = e - row * cpr;
+            if (row < TN) {
+                const f32x4 v = xr[i];
+                float t = v[0] * wt4[0];
+                t = fmaf(v[1], wt4[1], t);
+                t = fmaf(v[2], wt4[2], t);
+                t = fmaf(v[3], wt4[3], t);
+                t += dpp<0xB1>(t);   // quad_perm [1,0,3,2]
+                t += dpp<0x4E>(t);   // quad_perm [2,3,0,1]
+                t += dpp<0x141>(t);  // row_half_mirror: the other quad of the 8-lane group
+                const int h = q >> 3;
+                const unsigned h01 = pack_bf16(v[0], v[1]), h23 = pack_bf16(v[2], v[3]);
+                const float a0 = __uint_as_float(h01 << 16), a1 = __uint_as_float(h01 & 0xffff0000u);
+                const float a2 = __uint_as_float(h23 << 16), a3 = __uint_as_float(h23 & 0xffff0000u);
+                const u32x2 hi = {h01, h23};
+                const u32x2 lo = {pack_bf16(v[0] - a0, v[1] - a1), pack_bf16(v[2] - a2, v[3] - a3)};
+                const int off = img_off(row, q8 >> 1) + ((q8 & 1) << 3);
+                char* img = buf + h * (2 * IMG);
+                *reinterpret_cast<u32x2*>(img + off) = hi;
+                *reinterpret_cast<u32x2*>(img + IMG + off) = lo;
+                if (q8 == 0) sarr[h * TN + row] = kLog2e / ada_temp(t + bt, base_temp);
+            }
+        }
+    }
+};
+
+// split-bf16 fragment of 8 consecutive channels of `row` (A operand of Y = X.Ws, B operand of Yt)
+__device__ __forceinline__ Frag read_rows(const char* img, int row, int chunk) {
+    Frag f;
+    const int off = img_off(row, chunk);
+    f.hi = *reinterpret_cast<const u32x4*>(img + off);
+    f.lo = *reinterpret_cast<const u32x4*>(img + IMG + off);
+    return f;
+}
+
+// transposed fragment: lane (c = lane&31, hf) gets X[n = 16s + 8(j>>2) + 4hf + (j&3)][c], j = 0..7
+// -- the k order an accumulator tile has when it is reused as the A operand (guide s.3).
+__device__ __forceinline__ Frag read_cols(const char* img, int s, int lane) {
+    const int i = lane & 15, cb = (lane >> 4) & 1, hf = lane >> 5;
+    const int chunk = 2 * cb + ((i & 3) >> 1), sub = (i & 1) << 3;
+    Frag f;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const char* base = img + part * IMG;
+        const int r0 = 16 * s + 4 * hf + (i >> 2), r1 = r0 + 8;
+        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(base + img_off(r0, chunk) + sub));
+        const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(base + img_off(r1, chunk) + sub));
+        const u32x2 a2 = __builtin_bit_cast(u32x2, a), b2 = __builtin_bit_cast(u32x2, b);
+        const u32x4 v = {a2[0], a2[1], b2[0], b2[1]};
+        if (part == 0) f.hi = v;
+        else f.lo = v;
+    }
+    return f;
+}
+
+// Ws as MB swizzled [32][32] split-bf16 image pairs in LDS (same for every head): both passes
+// re-read their Ws fragments per tile instead of pinning 16 VGPRs per column block.
+__device__ __forceinline__ void stage_ws(char* wimg, const float* __restrict__ Ws, int M) {
+    for (int e = threadIdx.x; e < M * 4; e += NTHR) {
+        const int g = e >> 2, chunk = e & 3;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = Ws[g * kC + 8 * chunk + j];
+        const Frag f = split8(v);
+        char* img = wimg + (g >> 5) * (2 * IMG);
+        const int off = img_off(g & 31, chunk);
+        *reinterpret_cast<u32x4*>(img + off) = f.hi;
+        *reinterpret_cast<u32x4*>(img + IMG + off) = f.lo;
+    }
+}
+
+// ----------------------------------------------------------------------------- slice
+// IPW items (head, 32-column block) per wave; MB = M/32 column blocks per head.
+template <int LI, int IPW, int MB>
+__global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ Ws, const float* __restrict__ bs,
+    const float* __restrict__ wt, float bt, float base_temp, float c0, int N, int H,
+    int tiles_per_chunk, float* __restrict__ parts) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int M = 32 * MB;
+    constexpr int IPH = (IPW < MB) ? IPW : MB;  // items of one head handled by this wave
+    constexpr int HPW = IPW / IPH;              // heads per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y, BH = gridDim.y * H;
+    const int n_tiles = (N + TN - 1) / TN;
+    const int t_begin = blockIdx.x * tiles_per_chunk;
+    const int t_end = min(n_tiles, t_begin + tiles_per_chunk);
+    const int buf_bytes = H * 2 * IMG;
+    char* bufs[2] = {smem, smem + buf_bytes};
+    float* sarr[2] = {reinterpret_cast<float*>(smem + 2 * buf_bytes),
+                      reinterpret_cast<float*>(smem + 2 * buf_bytes) + H * TN};
+    float* scratch = reinterpret_cast<float*>(smem + 2 * buf_bytes) + 2 * H * TN + wave * 32;
+    char* wimg = smem + 2 * buf_bytes + (2 * H * TN + NW * 32) * 4;  // [MB][hi|lo] images of Ws
+    const float* xb = x + (size_t)b * N * H * kC;
+
+    Loader<LI> ld;
+    ld.init(wt);
+    stage_ws(wimg, Ws, M);
+
+    // per-item state (the Ws fragments -- B operand: col g = lane&31, k = c -- come from LDS)
+    float bias[IPW], m2[IPW], lsum[IPW];
+    f32x16 Z[IPW];
+    const int item0 = wave * IPW;
+#pragma unroll
+    for (int k = 0; k < IPW; ++k) {
+        const int id = item0 + k, gb = id % MB;
+        const int g = 32 * gb + l31;
+        bias[k] = bs[g] - c0;
+        m2[k] = -INFINITY;
+        lsum[k] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Z[k][r] = 0.f;
+    }
+    const bool active = item0 < H * MB;
+
+    ld.fetch(xb, H, t_begin * TN, N - t_begin * TN);
+    ld.stage(bufs[0], sarr[0], H, bt, base_temp);
+    __syncthreads();
+    int cur = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+        const bool more = t + 1 < t_end;
+        if (more) ld.fetch(xb, H, (t + 1) * TN, N - (t + 1) * TN);
+        if (active) {
+            const int nvalid = N - t * TN;  // >= 32 except on the last tile
+#pragma unroll
+            for (int hh = 0; hh < HPW; ++hh) {
+                const int h = (item0 + hh * IPH) / MB;
+                const char* img = bufs[cur] + h * (2 * IMG);
+                const float* sp = sarr[cur] + h * TN;
+                // rows of this lane's accumulator registers: n = (r&3) + 8(r>>2) + 4hf
+                f32x4 s4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s4[i] = *reinterpret_cast<const f32x4*>(sp + 8 * i + 4 * hf);
+                const Frag xa0 = read_rows(img, l31, hf), xa1 = read_rows(img, l31, 2 + hf);
+                const Frag xb0 = read_cols(img, 0, lane), xb1 = read_cols(img, 1, lane);
+#pragma unroll
+                for (int kk = 0; kk < IPH; ++kk) {
+                    const int k = hh * IPH + kk;
+                    const char* wi = wimg + ((item0 + k) % MB) * (2 * IMG);
+                    f32x16 Y;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Y[r] = bias[k];
+                    Y = mfma3(xa0, read_rows(wi, l31, hf), Y);
+                    Y = mfma3(xa1, read_rows(wi, l31, 2 + hf), Y);
+                    float tmax = -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        Y[r] *= s4[r >> 2][r & 3];
+                        tmax = fmaxf(tmax, Y[r]);
+                    }
+                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                    if (__any(tmax > m2[k] + kThr2)) {  // deferred rescale (rare)
+                        const float mn = fmaxf(m2[k], tmax);
+                        const float a = __builtin_amdgcn_exp2f(m2[k] - mn);  // m2 = -inf -> 0
+                        lsum[k] *= a;
+                        if (hf == 0) scratch[l31] = a;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 a4 = *reinterpret_cast<const f32x4*>(scratch + 8 * i + 4 * hf);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) Z[k][4 * i + q] *= a4[q];
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        m2[k] = mn;
+                    }
+                    float p[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(Y[r] - m2[k]);
+                    if (nvalid < TN) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if ((r & 3) + 8 * (r >> 2) + 4 * hf >= nvalid) p[r] = 0.f;
+                    }
+                    float ps = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ps += p[r];
+                    lsum[k] += ps;
+                    float p0[8], p1[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        p0[j] = p[j];
+                        p1[j] = p[8 + j];
+                    }
+                    // Z[g,c] += P^T X : accumulator tile reused as the A operand
+                    Z[k] = mfma3(split8(p0), xb0, Z[k]);
+                    Z[k] = mfma3(split8(p1), xb1, Z[k]);
+                }
+            }
+        }
+        if (more) ld.stage(bufs[cur ^ 1], sarr[cur ^ 1], H, bt, base_temp);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // record of this chunk: [B*H][ m[M] | l[M] | St[M][C] ]
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < IPW; ++k) {
+            const int id = item0 + k, h = id / MB, gb = id % MB;
+            float* rec = parts + ((size_t)blockIdx.x * BH + b * H + h) * (size_t)M * (kC + 2);
+            const float l = lsum[k] + __shfl_xor(lsum[k], 32);
+            if (hf == 0) {
+                rec[32 * gb + l31] = m2[k] * kLn2;
+                rec[M + 32 * gb + l31] = l;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int g = 32 * gb + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                rec[2 * M + g * kC + l31] = Z[k][r];
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- de-slice
+// HPW heads per wave; all MB column blocks of a head are summed into one output tile.
+template <int LI, int HPW, int MB>
+__global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ Ws, const float* __restrict__ bs,
+    const float* __restrict__ wt, float bt, float base_temp, float c0,
+    const float* __restrict__ col_max, const float* __restrict__ col_sum,
+    const float* __restrict__ S2, int N, int H, int tiles_per_chunk, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int M = 32 * MB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y;
+    const int n_tiles = (N + TN - 1) / TN;
+    const int t_begin = blockIdx.x * tiles_per_chunk;
+    const int t_end = min(n_tiles, t_begin + tiles_per_chunk);
+    const int buf_bytes = H * 2 * IMG;
+    char* bufs[2] = {smem, smem + buf_bytes};
+    float* fl = reinterpret_cast<float*>(smem + 2 * buf_bytes);
+    float* sarr[2] = {fl, fl + H * TN};
+    float* biasL = fl + 2 * H * TN;  // [H][M]  bs - c0
+    float* m2L = biasL + H * M;      // [H][M]  col_max * log2e
+    char* wimg = reinterpret_cast<char*>(m2L + H * M);  // [MB][hi|lo] images of Ws
+    const float* xb = x + (size_t)b * N * H * kC;
+    float* ob = out + (size_t)b * N * H * kC;
+
+    for (int i = threadIdx.x; i < H * M; i += NTHR) {
+        biasL[i] = bs[i % M] - c0;
+        m2L[i] = col_max[(size_t)b * H * M + i] * kLog2e;
+    }
+    Loader<LI> ld;
+    ld.init(wt);
+    stage_ws(wimg, Ws, M);
+
+    // per-head constants: the S'/l fragments (A operand: row c = lane&31, k = g in accumulator
+    // order); the Ws fragments (A operand: row g = lane&31, k = c) come from LDS
+    Frag sf[HPW][MB][2];
+    const int head0 = wave * HPW;
+#pragma unroll
+    for (int hh = 0; hh < HPW; ++hh) {
+        const int h = min(head0 + hh, H - 1);
+        const float* s2h = S2 + ((size_t)b * H + h) * M * kC;
+        const float* csh = col_sum + ((size_t)b * H + h) * M;
+#pragma unroll
+        for (int gb = 0; gb < MB; ++gb) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int g = 32 * gb + 16 * s + 8 * (j >> 2) + 4 * hf + (j & 3);
+                    v[j] = s2h[g * kC + l31] / csh[g];
+                }
+                sf[hh][gb][s] = split8(v);
+            }
+        }
+    }
+
+    ld.fetch(xb, H, t_begin * TN, N - t_begin * TN);
+    ld.stage(bufs[0], sarr[0], H, bt, base_temp);
+    __syncthreads();
+    int cur = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+        const bool more = t + 1 < t_end;
+        if (more) ld.fetch(xb, H, (t + 1) * TN, N - (t + 1) * TN);
+        const int nvalid = N - t * TN;
+#pragma unroll
+        for (int hh = 0; hh < HPW; ++hh) {
+            const int h = head0 + hh;
+            if (h < H) {
+                const char* img = bufs[cur] + h * (2 * IMG);
+                const float sn = sarr[cur][h * TN + l31];
+                const Frag x0 = read_rows(img, l31, hf), x1 = read_rows(img, l31, 2 + hf);
+                f32x16 O;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) O[r] = 0.f;
+#pragma unroll
+                for (int gb = 0; gb < MB; ++gb) {
+                    const float* bp = biasL + h * M + 32 * gb + 4 * hf;
+                    const float* mp = m2L + h * M + 32 * gb + 4 * hf;
+                    f32x16 Y;
+                    f32x4 m4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + 8 * i);
+                        m4[i] = *reinterpret_cast<const f32x4*>(mp + 8 * i);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) Y[4 * i + q] = b4[q];
+                    }
+                    const char* wi = wimg + gb * (2 * IMG);
+                    Y = mfma3(read_rows(wi, l31, hf), x0, Y);  // Yt[g,n]: rows g in regs, point on the lane
+                    Y = mfma3(read_rows(wi, l31, 2 + hf), x1, Y);
+                    float p0[8], p1[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        p0[j] = __builtin_amdgcn_exp2f(fmaf(Y[j], sn, -m4[j >> 2][j & 3]));
+                        p1[j] = __builtin_amdgcn_exp2f(fmaf(Y[8 + j], sn, -m4[2 + (j >> 2)][j & 3]));
+                    }
+                    O = mfma3(sf[hh][gb][0], split8(p0), O);  // Ot[c,n] += (S'/l)^T P
+                    O = mfma3(sf[hh][gb][1], split8(p1), O);
+                }
+                if (l31 < nvalid) {
+                    float* orow = ob + ((size_t)(t * TN + l31) * H + h) * kC + 4 * hf;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 v = {O[4 * i], O[4 * i + 1], O[4 * i + 2], O[4 * i + 3]};
+                        *reinterpret_cast<f32x4*>(orow + 8 * i) = v;
+                    }
+                }
+            }
+        }
+        if (more) ld.stage(bufs[cur ^ 1], sarr[cur ^ 1], H, bt, base_temp);
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// ----------------------------------------------------------------------------- host side
+struct MfmaPlan {
+    int li, ipw, mb, hpw, tiles_per_chunk, parts;
+    size_t lds_slice, lds_deslice;
+};
+
+// shapes the MFMA path covers: C = 32, M in {32, 64, 128}, even H <= 16
+bool mfma_plan(int B, int N, int H, int C, int M, MfmaPlan* p) {
+    if (C != kC || (M != 32 && M != 64 && M != 128)) return false;
+    if (H < 2 || H > 16 || (H & 1)) return false;
+    const int mb = M / 32, items = H * mb;
+    const int ipw = (items + NW - 1) / NW;
+    if (ipw != 1 && ipw != 2 && ipw != 4) return false;
+    const int iph = ipw < mb ? ipw : mb;
+    if (mb % iph || ipw % iph) return false;
+    const int hpw = (H + NW - 1) / NW;
+    if (hpw != 1 && hpw != 2) return false;
+    if (p) {
+        p->li = (H + 1) / 2;
+        p->ipw = ipw;
+        p->mb = mb;
+        p->hpw = hpw;
+        const int n_tiles = (N + TN - 1) / TN;
+        int target = 512 / (B < 1 ? 1 : B);
+        if (target < 1) target = 1;
+        p->tiles_per_chunk = (n_tiles + target - 1) / target;
+        p->parts = (n_tiles + p->tiles_per_chunk - 1) / p->tiles_per_chunk;
+        const size_t bufs = (size_t)2 * H * 2 * IMG + (size_t)2 * H * TN * 4;
+        const size_t wimg = (size_t)mb * 2 * IMG;
+        p->lds_slice = bufs + NW * 32 * 4 + wimg;
+        p->lds_deslice = bufs + (size_t)2 * H * M * 4 + wimg;
+    }
+    return true;
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return fail(HAET_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    return HAET_OK;
+}
+
+#define SLICE_CASE(LI_, IPW_, MB_)                                                              \
+    if (p.li == LI_ && p.ipw == IPW_ && p.mb == MB_) {                                           \
+        auto kern = slice_mfma_kernel<LI_, IPW_, MB_>;                                           \
+        if (int rc = set_lds(kern, p.lds_slice)) return rc;                                      \
+        hipLaunchKernelGGL(kern, grid, dim3(NTHR), p.lds_slice, st, x, Ws, bs, wt, bt, base_temp, \
+                           c0, N, H, p.tiles_per_chunk, parts);                                  \
+        return check_launch("slice_mfma_kernel");                                                \
+    }
+
+int slice_mfma_fwd(const float* x, const float* Ws, const float* bs, const float* wt, float bt,
+                   float base_temp, float c0, int B, int N, int H, int C, int M, float* parts,
+                   hipStream_t st) {
+    MfmaPlan p;
+    if (!mfma_plan(B, N, H, C, M, &p)) return fail(HAET_E_ARG, "slice_mfma: unsupported shape");
+    dim3 grid(p.parts, B);
+    SLICE_CASE(4, 2, 2)  // H=8,  M=64  (C3/C4)
+    SLICE_CASE(4, 1, 1)  // H=8,  M=32
+    SLICE_CASE(4, 4, 4)  // H=8,  M=128 (C5)
+    SLICE_CASE(2, 1, 2)  // H=4,  M=64
+    SLICE_CASE(2, 1, 1)  // H=4,  M=32
+    SLICE_CASE(2, 2, 4)  // H=4,  M=128
+    SLICE_CASE(1, 1, 1)  // H=2
+    SLICE_CASE(1, 1, 2)
+    SLICE_CASE(1, 1, 4)
+    SLICE_CASE(8, 2, 1)  // H=16, M=32
+    SLICE_CASE(8, 4, 2)  // H=16, M=64
+    return fail(HAET_E_ARG, "slice_mfma: no instantiation for H=%d M=%d", H, M);
+}
+
+#define DESLICE_CASE(LI_, HPW_, MB_)                                                              \
+    if (p.li == LI_ && p.hpw == HPW_ && p.mb == MB_) {                                             \
+        auto kern = deslice_mfma_kernel<LI_, HPW_, MB_>;                                           \
+        if (int rc = set_lds(kern, p.lds_deslice)) return rc;                                      \
+        hipLaunchKernelGGL(kern, grid, dim3(NTHR), p.lds_deslice, st, x, Ws, bs, wt, bt, base_temp, \
+                           c0, cm, cs, S2, N, H, p.tiles_per_chunk, out);                          \
+        return check_launch("deslice_mfma_kernel");                                                \
+    }
+
+int deslice_mfma_fwd(const float* x, const float* Ws, const float* bs, const float* wt, float bt,
+                     float base_temp, float c0, const float* cm, const float* cs, const float* S2,
+                     int B, int N, int H, int C, int M, float* out, hipStream_t st) {
+    MfmaPlan p;
+    if (!mfma_plan(B, N, H, C, M, &p)) return fail(HAET_E_ARG, "deslice_mfma: unsupported shape");
+    dim3 grid(p.parts, B);
+    DESLICE_CASE(4, 1, 2)
+    DESLICE_CASE(4, 1, 1)
+    DESLICE_CASE(4, 1, 4)
+    DESLICE_CASE(2, 1, 2)
+    DESLICE_CASE(2, 1, 1)
+    DESLICE_CASE(2, 1, 4)
+    DESLICE_CASE(1, 1, 1)
+    DESLICE_CASE(1, 1, 2)
+    DESLICE_CASE(1, 1, 4)
+    DESLICE_CASE(8, 2, 1)
+    DESLICE_CASE(8, 2, 2)
+    return fail(HAET_E_ARG, "deslice_mfma: no instantiation for H=%d M=%d", H, M);
+}
+
+}  // namespace haet
