@@ -16,9 +16,10 @@ import torch.distributed as dist
 def allgather_records(local_record: torch.Tensor, group=None) -> torch.Tensor:
     """[rec] on each rank -> [R, rec] in rank order on every rank."""
     world = dist.get_world_size(group)
-    out = torch.empty((world, local_record.numel()), dtype=local_record.dtype, device=local_record.device)
-    dist.all_gather_into_tensor(out, local_record.contiguous(), group=group)
-    return out
+    flat = local_record.contiguous().reshape(-1)
+    out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
+    dist.all_gather_into_tensor(out, flat, group=group)  # flat output: accepted by RCCL and gloo
+    return out.view(world, flat.numel())
 
 
 def shard_points(model: torch.nn.Module, group=None) -> torch.nn.Module:
