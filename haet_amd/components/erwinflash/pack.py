@@ -1,8 +1,8 @@
 """Pack an ErwinTransformer's parameters into the single fp32 blob + descriptor that
 haet_erwin_fwd consumes (layout contract: include/haet_hip.h, haet_erwin_desc).
 
-Linear weights are stored transposed ([in][out]) so consecutive lanes read consecutive
-output columns; eval-mode BatchNorm1d is folded to y*scale + shift
+Linear weights keep PyTorch's [out][in] layout with rows zero-padded to a multiple of 32
+floats (one lane of the MFMA B operand reads 8 consecutive k of one output row); eval-mode BatchNorm1d is folded to y*scale + shift
 (scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale;
 models/components/erwinflash/components/pooling.py:23,38,56,68)."""
 from __future__ import annotations
@@ -28,6 +28,15 @@ class _Blob:
         return off
 
     def lin(self, linear):
+        """[out][in] rows zero-padded to a multiple of 32 floats (MFMA k-step)."""
+        w = linear.weight.detach().float()
+        pad = (-w.shape[1]) % 32
+        if pad:
+            w = torch.nn.functional.pad(w, (0, pad))
+        return self.add(w.contiguous()), self.add(linear.bias)
+
+    def lin_t(self, linear):
+        """transposed [in][out] (the 2/3-wide positional projection, evaluated on the VALU)."""
         return self.add(linear.weight.t().contiguous()), self.add(linear.bias)
 
     def tensor(self):
@@ -42,7 +51,7 @@ def _fill_layer(dst, layer, blob):
     for j, blk in enumerate(layer.blocks):
         w = dst.blocks[j]
         w.norm1, w.norm2 = blob.add(blk.norm1.weight), blob.add(blk.norm2.weight)
-        w.pe_w, w.pe_b = blob.lin(blk.BMSA.pe_proj)
+        w.pe_w, w.pe_b = blob.lin_t(blk.BMSA.pe_proj)
         w.qkv_w, w.qkv_b = blob.lin(blk.BMSA.qkv)
         w.proj_w, w.proj_b = blob.lin(blk.BMSA.proj)
         w.w1_w, w.w1_b = blob.lin(blk.swiglu.w1)

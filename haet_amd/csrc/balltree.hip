@@ -13,6 +13,8 @@
 // Keys are the fp32 positions; the reference converts them to float64 first
 // (balltree.pyx:542), an exact, order-preserving conversion, so fp32 compares give
 // identical decisions.  Spreads are differenced in double like the reference.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace haet {
@@ -258,6 +260,12 @@ __global__ __launch_bounds__(64) void balltree_kernel(
     }
 }
 
+// balltree_wave.hip: register-resident variant for power-of-two clouds of <= 64 points
+bool balltree_wave_ok(int M, int n_levels, const int* st);
+int balltree_wave_launch(const float* pos, int n_clouds, int M, int d, int n_levels, const int* st,
+                         const int* tg, int rotate, const float* R9, int32_t* tree_idx,
+                         uint8_t* tree_mask, int32_t* rot, hipStream_t stream);
+
 }  // namespace haet
 
 using namespace haet;
@@ -293,7 +301,7 @@ extern "C" int haet_balltree_build(const float* pos, int n_clouds, int M, int d,
     }
     // generate_rotation_matrix (balltree.pyx:576-596): python doubles -> fp32 tensor
     Rot3 R = {};
-    const double a = (double)angle_deg * 3.14159265358979323846 / 180.0;
+    const double a = (double)angle_deg * (3.14159265358979323846 / 180.0);  // math.radians
     const double c = cos(a), s = sin(a);
     if (d == 2) {
         const double m[4] = {c, -s, s, c};
@@ -303,6 +311,10 @@ extern "C" int haet_balltree_build(const float* pos, int n_clouds, int M, int d,
                              s * c * (s - 1), -s, s * c, c * c};
         for (int i = 0; i < 9; ++i) R.r[i] = (float)m[i];
     }
+    const char* force_lds = getenv("HAET_TREE_LDS");
+    if (!(force_lds && force_lds[0] == '1') && balltree_wave_ok(M, n_levels, st))
+        return balltree_wave_launch(pos, n_clouds, M, d, n_levels, st, tg, rotate, R.r, tree_idx,
+                                    tree_mask, rot, as_stream(stream));
     hipLaunchKernelGGL(balltree_kernel, dim3(n_clouds), dim3(64), 0, as_stream(stream), pos, M, d,
                        depth, n_levels, st[0], st[1], st[2], tg[0], tg[1], tg[2], tg[3], rotate, R,
                        tree_idx, tree_mask, rot);

@@ -1,0 +1,253 @@
+// Register-resident ball-tree builder (power-of-two clouds of <= 64 points): one wave per
+// cloud, the working arrays of std::nth_element live ACROSS THE LANES of two VGPRs
+// (lane p = array position p: an order-preserving integer key and the point index), and the
+// sequential introselect runs as scalar control flow that reads/writes single lanes with
+// v_readlane and single-lane selects.  The two Hoare scans ("while key[lo] < pivot", "while pivot <
+// key[hi]") are one ballot + find-first-bit each instead of a dependent LDS round trip per
+// element, and the split dimension / key gather of ALL nodes of a tree level is one
+// segmented butterfly.  Same algorithm, same permutation as balltree.hip (and as the
+// reference's libstdc++ nth_element, models/components/balltree/balltree.h:91-100), ~15x
+// less latency: the tree is on the critical path of every forward.
+#include "common.h"
+
+namespace haet {
+
+__device__ __forceinline__ unsigned okey(float f) {
+    // order-preserving float -> uint map (ties stay ties: -0 is folded into +0 first)
+    const unsigned u = __float_as_uint(f + 0.0f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+struct LaneArr {
+    unsigned key;  // lane p: key of the element at position p
+    int idx;       // lane p: element id at position p
+
+    __device__ __forceinline__ unsigned k(int p) const {
+        return (unsigned)__builtin_amdgcn_readlane((int)key, p);
+    }
+    __device__ __forceinline__ int i(int p) const { return __builtin_amdgcn_readlane(idx, p); }
+    // single-lane write as compare + select (this clang has no v_writelane builtin)
+    __device__ __forceinline__ void set(int p, unsigned kk, int ii) {
+        const bool me = (int)(threadIdx.x & 63) == p;
+        key = me ? kk : key;
+        idx = me ? ii : idx;
+    }
+    __device__ __forceinline__ void swap(int p, int q) {
+        const unsigned kp = k(p), kq = k(q);
+        const int ip = i(p), iq = i(q);
+        set(p, kq, iq);
+        set(q, kp, ip);
+    }
+};
+
+// ---- heap fallback of introselect (depth budget spent) -- generic single-lane accesses
+__device__ __forceinline__ void w_adjust_heap(LaneArr& a, int first, int hole, int len, unsigned vk, int vi) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (a.k(first + child) < a.k(first + child - 1)) child--;
+        a.set(first + hole, a.k(first + child), a.i(first + child));
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        a.set(first + hole, a.k(first + child - 1), a.i(first + child - 1));
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && a.k(first + parent) < vk) {
+        a.set(first + hole, a.k(first + parent), a.i(first + parent));
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a.set(first + hole, vk, vi);
+}
+
+__device__ __forceinline__ void w_heap_select(LaneArr& a, int first, int middle, int last) {
+    const int len = middle - first;
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        for (;;) {
+            w_adjust_heap(a, first, parent, len, a.k(first + parent), a.i(first + parent));
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    for (int p = middle; p < last; ++p) {
+        if (a.k(p) < a.k(first)) {
+            const unsigned vk = a.k(p);
+            const int vi = a.i(p);
+            a.set(p, a.k(first), a.i(first));
+            w_adjust_heap(a, first, 0, len, vk, vi);
+        }
+    }
+}
+
+__device__ __forceinline__ void w_insertion_sort(LaneArr& a, int first, int last) {
+    if (first == last) return;
+    for (int p = first + 1; p != last; ++p) {
+        const unsigned vk = a.k(p);
+        const int vi = a.i(p);
+        if (vk < a.k(first)) {
+            for (int q = p; q != first; --q) a.set(q, a.k(q - 1), a.i(q - 1));
+            a.set(first, vk, vi);
+        } else {
+            int hole = p, prev = p - 1;
+            while (vk < a.k(prev)) {
+                a.set(hole, a.k(prev), a.i(prev));
+                hole = prev;
+                --prev;
+            }
+            a.set(hole, vk, vi);
+        }
+    }
+}
+
+// introselect on positions [first, last), all scalars wave-uniform
+__device__ __forceinline__ void w_select_nth(LaneArr& a, int first, int nth, int last) {
+    if (first == last || nth == last) return;
+    int depth = 2 * (31 - __clz(last - first));
+    while (last - first > 3) {
+        if (depth == 0) {
+            w_heap_select(a, first, nth + 1, last);
+            a.swap(first, nth);
+            return;
+        }
+        --depth;
+        const int pa = first + 1, pb = first + (last - first) / 2, pc = last - 1;
+        const unsigned ka = a.k(pa), kb = a.k(pb), kc = a.k(pc);
+        int med;  // median of three goes to `first`
+        if (ka < kb) med = (kb < kc) ? pb : ((ka < kc) ? pc : pa);
+        else med = (ka < kc) ? pa : ((kb < kc) ? pc : pb);
+        a.swap(first, med);
+        const unsigned pivot = a.k(first);
+        int lo = first + 1, hi = last;
+        for (;;) {
+            // while (key[lo] < pivot) ++lo;      (unguarded: a stopper always exists)
+            const unsigned long long lt = __ballot(a.key < pivot);
+            lo = __builtin_ctzll(~lt & (~0ull << lo));
+            --hi;
+            // while (pivot < key[hi]) --hi;
+            const unsigned long long gt = __ballot(pivot < a.key);
+            hi = 63 - __builtin_clzll(~gt & (~0ull >> (63 - hi)));
+            if (!(lo < hi)) break;
+            a.swap(lo, hi);
+            ++lo;
+        }
+        if (lo <= nth) first = lo;
+        else last = lo;
+    }
+    w_insertion_sort(a, first, last);
+}
+
+// one tree level: all nodes have `sz` points (power of two, lane-aligned segments).
+// cx,cy,cz: coordinates BY ELEMENT (lane e = element e).
+__device__ __forceinline__ void w_split_level(LaneArr& a, float cx, float cy, float cz, int nd, int n, int sz) {
+    // coordinates of the element sitting at my position
+    float v[3] = {__shfl(cx, a.idx), __shfl(cy, a.idx), nd > 2 ? __shfl(cz, a.idx) : 0.f};
+    int best = 0;
+    double best_spread = 0.0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (d < nd) {
+            float lo = v[d], hi = v[d];
+            for (int off = 1; off < sz; off <<= 1) {
+                lo = fminf(lo, __shfl_xor(lo, off));
+                hi = fmaxf(hi, __shfl_xor(hi, off));
+            }
+            const double spread = (double)hi - (double)lo;
+            if (spread > best_spread) {  // strict: ties keep the lowest dimension (balltree.h:58)
+                best_spread = spread;
+                best = d;
+            }
+        }
+    }
+    a.key = okey(best == 0 ? v[0] : (best == 1 ? v[1] : v[2]));
+    for (int s = 0; s < n; s += sz) w_select_nth(a, s, s + sz / 2, s + sz);
+}
+
+struct Rot3w {
+    float r[9];
+};
+
+__global__ __launch_bounds__(64) void balltree_wave_kernel(
+    const float* __restrict__ pos, int M, int nd, int n_levels, int s0, int s1, int s2, int t0,
+    int t1, int t2, int t3, int rotate, Rot3w R, int32_t* __restrict__ tree_idx,
+    uint8_t* __restrict__ tree_mask, int32_t* __restrict__ rot) {
+    const int lane = threadIdx.x, cloud = blockIdx.x, n_clouds = gridDim.x;
+    const int strides[3] = {s0, s1, s2};
+    const int targets[4] = {t0, t1, t2, t3};
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    if (lane < M) {
+        const float* p = pos + ((size_t)cloud * M + lane) * nd;
+        cx = p[0];
+        cy = p[1];
+        if (nd > 2) cz = p[2];
+    }
+    LaneArr a;
+    a.idx = lane;
+    a.key = 0;
+    // main tree (balltree.h:121-186): halve until the nodes hold 2 points
+    for (int sz = M; sz > 2; sz >>= 1) w_split_level(a, cx, cy, cz, nd, M, sz);
+    if (lane < M) {
+        tree_idx[(size_t)cloud * M + lane] = cloud * M + a.idx;
+        tree_mask[(size_t)cloud * M + lane] = 1;
+    }
+    if (!rotate) return;
+    // leaves in tree order, rotated (balltree.pyx:639-646)
+    const float lx = __shfl(cx, a.idx), ly = __shfl(cy, a.idx), lz = __shfl(cz, a.idx);
+    float rx, ry, rz = 0.f;
+    if (nd == 2) {
+        rx = fmaf(ly, R.r[2], lx * R.r[0]);
+        ry = fmaf(ly, R.r[3], lx * R.r[1]);
+    } else {
+        rx = fmaf(lz, R.r[6], fmaf(ly, R.r[3], lx * R.r[0]));
+        ry = fmaf(lz, R.r[7], fmaf(ly, R.r[4], lx * R.r[1]));
+        rz = fmaf(lz, R.r[8], fmaf(ly, R.r[5], lx * R.r[2]));
+    }
+    int n = M;
+    size_t rot_off = 0;
+    for (int lev = 0; lev < n_levels; ++lev) {
+        a.idx = lane;
+        int sz = n;
+        for (int L = 0; L < targets[lev] && sz > 1; ++L, sz >>= 1) w_split_level(a, rx, ry, rz, nd, n, sz);
+        if (lane < n) rot[rot_off + (size_t)cloud * n + lane] = cloud * n + a.idx;
+        rot_off += (size_t)n_clouds * n;
+        if (lev < n_levels - 1) {
+            const int st = strides[lev];
+            float sx = 0.f, sy = 0.f, sz2 = 0.f;
+            for (int q = 0; q < st; ++q) {  // sequential sum like .mean(axis=1)
+                const int src = (lane * st + q) & 63;
+                const float gx = __shfl(rx, src), gy = __shfl(ry, src), gz = __shfl(rz, src);
+                sx = q ? sx + gx : gx;
+                sy = q ? sy + gy : gy;
+                sz2 = q ? sz2 + gz : gz;
+            }
+            rx = sx / (float)st;
+            ry = sy / (float)st;
+            rz = sz2 / (float)st;
+            n /= st;
+        }
+    }
+}
+
+bool balltree_wave_ok(int M, int n_levels, const int* st) {
+    if (M < 2 || M > 64 || (M & (M - 1))) return false;
+    for (int i = 0; i < n_levels - 1; ++i)
+        if (st[i] < 1 || (st[i] & (st[i] - 1))) return false;
+    return true;
+}
+
+int balltree_wave_launch(const float* pos, int n_clouds, int M, int d, int n_levels, const int* st,
+                         const int* tg, int rotate, const float* R9, int32_t* tree_idx,
+                         uint8_t* tree_mask, int32_t* rot, hipStream_t stream) {
+    Rot3w R;
+    for (int i = 0; i < 9; ++i) R.r[i] = R9[i];
+    hipLaunchKernelGGL(balltree_wave_kernel, dim3(n_clouds), dim3(64), 0, stream, pos, M, d, n_levels,
+                       st[0], st[1], st[2], tg[0], tg[1], tg[2], tg[3], rotate, R, tree_idx, tree_mask,
+                       rot);
+    return check_launch("balltree_wave_kernel");
+}
+
+}  // namespace haet

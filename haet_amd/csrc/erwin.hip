@@ -10,8 +10,10 @@
 // which place of the ball sequence; everything except the per-ball attention and
 // the ball-centre is per-token and order-free.
 //
-// Weights stream from global/L2 in [in][out] order (lane = output column, coalesced);
-// activations are broadcast from LDS (all lanes of a wave share the token).
+// Every Linear runs on the matrix cores as split-bf16 (v_mfma_f32_16x16x32_bf16 x3: hi*hi +
+// hi*lo + lo*hi, fp32 accumulate): a wave owns a 16-token x 16-output tile, reads the
+// activations from LDS and its weight fragments straight from global/L2 ([out][in] rows,
+// 8 consecutive k per lane), all of a tile's weight loads in flight before the first MFMA.
 #include "common.h"
 
 namespace haet {
@@ -30,79 +32,108 @@ struct Lds {
     int* ident;
 };
 
-// Y[t][o] = sum_k X[t*ldx+k] * Wt[k*O+o]; epi(t, o, acc) finishes (bias, residual, ...)
-template <typename Epi>
-__device__ __forceinline__ void linear_lds(const float* X, int ldx, int n, int K,
-                                           const float* __restrict__ Wt, int O, Epi epi) {
-    const int ol = threadIdx.x & 63, tg = threadIdx.x >> 6;
-    for (int o0 = 0; o0 < O; o0 += 64) {
-        const int o = o0 + ol;
-        const bool ov = o < O;
-        const float* wp = Wt + (ov ? o : 0);
-        for (int t0 = 0; t0 < n; t0 += 32) {
-            float acc[8];
-            const float* xr[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                acc[i] = 0.f;
-                const int t = min(t0 + tg + 4 * i, n - 1);
-                xr[i] = X + t * ldx;
-            }
-            int k = 0;
-            for (; k + 4 <= K; k += 4) {
-                const float w0 = wp[(size_t)k * O], w1 = wp[(size_t)(k + 1) * O];
-                const float w2 = wp[(size_t)(k + 2) * O], w3 = wp[(size_t)(k + 3) * O];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float4 xv = *reinterpret_cast<const float4*>(xr[i] + k);
-                    acc[i] = fmaf(xv.w, w3, fmaf(xv.z, w2, fmaf(xv.y, w1, fmaf(xv.x, w0, acc[i]))));
-                }
-            }
-            for (; k < K; ++k) {
-                const float w0 = wp[(size_t)k * O];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = fmaf(xr[i][k], w0, acc[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int t = t0 + tg + 4 * i;
-                if (ov && t < n) epi(t, o, acc[i]);
-            }
-        }
-    }
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+struct Frag {
+    u32x4 hi, lo;
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
-// two matrices over the same input (SwiGLU's w1 / w2): epi(t, o, acc1, acc2)
-template <typename Epi>
-__device__ __forceinline__ void linear_lds2(const float* X, int ldx, int n, int K,
-                                            const float* __restrict__ W1t,
-                                            const float* __restrict__ W2t, int O, Epi epi) {
-    const int ol = threadIdx.x & 63, tg = threadIdx.x >> 6;
-    for (int o0 = 0; o0 < O; o0 += 64) {
-        const int o = o0 + ol;
-        const bool ov = o < O;
-        const int oo = ov ? o : 0;
-        for (int t0 = 0; t0 < n; t0 += 32) {
-            float a1[8], a2[8];
-            const float* xr[8];
+// 8 fp32 -> split-bf16 MFMA operand (hi = RNE(x), lo = RNE(x - hi)): fp32-class products
+__device__ __forceinline__ Frag split8(const f32x4 a, const f32x4 b) {
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    Frag f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                a1[i] = a2[i] = 0.f;
-                xr[i] = X + min(t0 + tg + 4 * i, n - 1) * ldx;
-            }
-            for (int k = 0; k < K; ++k) {
-                const float u = W1t[(size_t)k * O + oo], v = W2t[(size_t)k * O + oo];
+    for (int i = 0; i < 4; ++i) {
+        const unsigned h = pack_bf16(v[2 * i], v[2 * i + 1]);
+        f.hi[i] = h;
+        f.lo[i] = pack_bf16(v[2 * i] - __uint_as_float(h << 16),
+                            v[2 * i + 1] - __uint_as_float(h & 0xffff0000u));
+    }
+    return f;
+}
+
+__device__ __forceinline__ f32x4 mfma3(const Frag& a, const Frag& b, f32x4 c) {
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, a.hi), al = __builtin_bit_cast(bf16x8, a.lo);
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi), bl = __builtin_bit_cast(bf16x8, b.lo);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    return c;
+}
+
+constexpr int kKC = 4;  // k-steps (of 32) whose weight loads are put in flight together
+
+// Y[t][o] = sum_k X[t*ldx + k] * W[o*Kp + k]  on the matrix cores (v_mfma_f32_16x16x32_bf16,
+// split-bf16 x3).  X: fp32 rows in LDS; W: global, PyTorch [out][in] layout with rows zero-padded
+// to Kp = roundup(K, 32).  One wave owns a 16-token x 16-output tile; its weight fragments
+// (lane = output row, 8 consecutive k: two 16-B loads per k-step) are all issued before the
+// first MFMA, so a tile costs ~one L2 latency instead of one per k.  NMAT = 2 evaluates two
+// weight matrices on the same activations (SwiGLU's w1/w2).  epi(t, o, acc...) finishes.
+template <int NMAT, typename Epi>
+__device__ __forceinline__ void linear_mfma(const float* X, int ldx, int n, int K,
+                                            const float* __restrict__ W0,
+                                            const float* __restrict__ W1, int O, Epi epi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int Kp = (K + 31) & ~31, nks = Kp >> 5;
+    const int nto = (O + 15) >> 4, ntiles = ((n + 15) >> 4) * nto;
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int tt = tile / nto, ot = tile - tt * nto;
+        const int trow = min(tt * 16 + l15, n - 1);
+        const int orow = min(ot * 16 + l15, O - 1);
+        const float* xr = X + trow * ldx + 8 * kq;
+        const float* w0 = W0 + (size_t)orow * Kp + 8 * kq;
+        const float* w1 = NMAT == 2 ? W1 + (size_t)orow * Kp + 8 * kq : nullptr;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < nks; k0 += kKC) {
+            f32x4 wa[kKC][2], wb[kKC][2];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float xv = xr[i][k];
-                    a1[i] = fmaf(xv, u, a1[i]);
-                    a2[i] = fmaf(xv, v, a2[i]);
+            for (int i = 0; i < kKC; ++i) {
+                if (k0 + i < nks) {
+                    wa[i][0] = *reinterpret_cast<const f32x4*>(w0 + 32 * (k0 + i));
+                    wa[i][1] = *reinterpret_cast<const f32x4*>(w0 + 32 * (k0 + i) + 4);
+                    if (NMAT == 2) {
+                        wb[i][0] = *reinterpret_cast<const f32x4*>(w1 + 32 * (k0 + i));
+                        wb[i][1] = *reinterpret_cast<const f32x4*>(w1 + 32 * (k0 + i) + 4);
+                    }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int t = t0 + tg + 4 * i;
-                if (ov && t < n) epi(t, o, a1[i], a2[i]);
+            for (int i = 0; i < kKC; ++i) {
+                if (k0 + i < nks) {
+                    const int kb = 32 * (k0 + i) + 8 * kq;  // this lane's first k
+                    f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+                    if (kb + 8 <= K) {
+                        x0 = *reinterpret_cast<const f32x4*>(xr + 32 * (k0 + i));
+                        x1 = *reinterpret_cast<const f32x4*>(xr + 32 * (k0 + i) + 4);
+                    } else {  // ragged tail (K = 70, 3, ...): never read past the row
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (kb + j < K) x0[j] = xr[32 * (k0 + i) + j];
+                            if (kb + 4 + j < K) x1[j] = xr[32 * (k0 + i) + 4 + j];
+                        }
+                    }
+                    const Frag xa = split8(x0, x1);
+                    acc0 = mfma3(xa, split8(wa[i][0], wa[i][1]), acc0);
+                    if (NMAT == 2) acc1 = mfma3(xa, split8(wb[i][0], wb[i][1]), acc1);
+                }
+            }
+        }
+        const int o = ot * 16 + l15;
+        if (o < O) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = tt * 16 + 4 * kq + r;
+                if (t < n) epi(t, o, acc0[r], acc1[r]);
             }
         }
     }
@@ -113,7 +144,7 @@ __device__ __forceinline__ void linear_lds2(const float* X, int ldx, int n, int 
 __device__ void rms_norm_rows(const float* X, int ldx, int n, int c, const float* __restrict__ w,
                               float* A, int lda) {
     const int sub = threadIdx.x & 3;
-    for (int t = threadIdx.x >> 2; t < n; t += 64) {
+    for (int t = threadIdx.x >> 2; t < n; t += (blockDim.x >> 2)) {
         const float* xr = X + t * ldx;
         float ss = 0.f;
         for (int ch = sub; ch < c; ch += 4) ss = fmaf(xr[ch], xr[ch], ss);
@@ -214,16 +245,16 @@ __device__ void erwin_block(const Lds& s, int lvl, const haet_erwin_layer& L,
     {
         const float* qb = W + w.qkv_b;
         float* Q = s.Bf;
-        linear_lds(s.A, ld, n, c, W + w.qkv_w, 3 * c,
-                   [=](int t, int o, float v) { Q[t * ldq + o] = v + qb[o]; });
+        linear_mfma<1>(s.A, ld, n, c, W + w.qkv_w, nullptr, 3 * c,
+                       [=](int t, int o, float v, float) { Q[t * ldq + o] = v + qb[o]; });
     }
     __syncthreads();
     attention_dispatch(c / L.heads, s.Bf, ldq, n, c, L.heads, L.ball, perm, s.A, ld);
     __syncthreads();
     {
         const float* pb = W + w.proj_b;
-        linear_lds(s.A, ld, n, c, W + w.proj_w, c,
-                   [=](int t, int o, float v) { X[t * ld + o] += v + pb[o]; });
+        linear_mfma<1>(s.A, ld, n, c, W + w.proj_w, nullptr, c,
+                       [=](int t, int o, float v, float) { X[t * ld + o] += v + pb[o]; });
     }
     __syncthreads();
     // x += W3( W2 x^ * silu(W1 x^) ),  x^ = RMSNorm(x)          (mlp.py:17-18)
@@ -233,7 +264,7 @@ __device__ void erwin_block(const Lds& s, int lvl, const haet_erwin_layer& L,
         const float* b1 = W + w.w1_b;
         const float* b2 = W + w.w2_b;
         float* Hd = s.Bf;
-        linear_lds2(s.A, ld, n, c, W + w.w1_w, W + w.w2_w, hid, [=](int t, int o, float u, float v) {
+        linear_mfma<2>(s.A, ld, n, c, W + w.w1_w, W + w.w2_w, hid, [=](int t, int o, float u, float v) {
             const float g = u + b1[o];
             Hd[t * ldh + o] = (v + b2[o]) * (g / (1.0f + __expf(-g)));
         });
@@ -241,8 +272,8 @@ __device__ void erwin_block(const Lds& s, int lvl, const haet_erwin_layer& L,
     __syncthreads();
     {
         const float* b3 = W + w.w3_b;
-        linear_lds(s.Bf, ldh, n, hid, W + w.w3_w, c,
-                   [=](int t, int o, float v) { X[t * ld + o] += v + b3[o]; });
+        linear_mfma<1>(s.Bf, ldh, n, hid, W + w.w3_w, nullptr, c,
+                       [=](int t, int o, float v, float) { X[t * ld + o] += v + b3[o]; });
     }
     __syncthreads();
 }
@@ -255,7 +286,7 @@ __device__ void run_layer(const Lds& s, int lvl, const haet_erwin_layer& L,
     }
 }
 
-__global__ __launch_bounds__(256) void erwin_kernel(
+__global__ __launch_bounds__(512) void erwin_kernel(
     const float* __restrict__ tokens, const float* __restrict__ pos,
     const int32_t* __restrict__ tree_idx, const uint8_t* __restrict__ tree_mask,
     const int32_t* __restrict__ rot, const float* __restrict__ W, const haet_erwin_desc D, int M,
@@ -343,8 +374,8 @@ __global__ __launch_bounds__(256) void erwin_kernel(
             const float* b = W + R.b;
             const float* sc = W + R.bn_scale;
             const float* sh = W + R.bn_shift;
-            linear_lds(s.Bf, ldk, n2, K, W + R.w, D.enc[l + 1].c,
-                       [=](int t, int o, float v) { Y[t * ldy + o] = (v + b[o]) * sc[o] + sh[o]; });
+            linear_mfma<1>(s.Bf, ldk, n2, K, W + R.w, nullptr, D.enc[l + 1].c,
+                           [=](int t, int o, float v, float) { Y[t * ldy + o] = (v + b[o]) * sc[o] + sh[o]; });
         }
         __syncthreads();
     }
@@ -372,7 +403,7 @@ __global__ __launch_bounds__(256) void erwin_kernel(
             const float* b = W + R.b;
             const float* sc = W + R.bn_scale;
             const float* sh = W + R.bn_shift;
-            linear_lds(s.Bf, ldk, n2, K, W + R.w, st * c, [=](int t, int o, float v) {
+            linear_mfma<1>(s.Bf, ldk, n2, K, W + R.w, nullptr, st * c, [=](int t, int o, float v, float) {
                 const int q = o / c, ch = o % c;  // 'n (m d) -> (n m) d'
                 float* y = Y + (t * st + q) * ldy + ch;
                 *y = (*y + v + b[o]) * sc[ch] + sh[ch];
@@ -489,7 +520,7 @@ extern "C" int haet_erwin_fwd(const float* tokens, const float* pos, const int32
         if (e != hipSuccess) return fail(HAET_E_LAUNCH, "erwin: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = bytes;
     }
-    hipLaunchKernelGGL(erwin_kernel, dim3(n_clouds), dim3(256), bytes, as_stream(stream), tokens,
+    hipLaunchKernelGGL(erwin_kernel, dim3(n_clouds), dim3(512), bytes, as_stream(stream), tokens,
                        pos, tree_idx, tree_mask, rot, weights, *desc, M, Mp, wide, out);
     return check_launch("erwin_kernel");
 }

@@ -3,37 +3,61 @@
 
 namespace haet {
 
-// One wave per (b,h,g): lanes stride over the C channels, all lanes redo the scalar
-// (m, l) recurrences.  R is a few hundred workgroup partials or <= 8 rank records.
-__global__ __launch_bounds__(64) void slice_merge_kernel(
+// One 256-thread workgroup per (b,h,g).  Phase 1: reference max and the weights
+// a_r = e^{m_r - max} of the R records (kept in LDS), l = sum_r l_r a_r.  Phase 2: the C
+// channels x (256/C) record groups accumulate sum_r a_r St_r[c] in a fixed order
+// (deterministic), reduced through LDS.  R = a few hundred workgroup partials, or <= 8 ranks.
+constexpr int kMergeMaxR = 2048;
+
+__global__ __launch_bounds__(256) void slice_merge_kernel(
     const float* __restrict__ rec, int R, int BH, int C, int M, int finalize,
     float* __restrict__ out_rec, float* __restrict__ col_max, float* __restrict__ col_sum,
     float* __restrict__ S) {
-    const int bhg = blockIdx.x, bh = bhg / M, g = bhg % M, lane = threadIdx.x;
+    __shared__ float aw[kMergeMaxR];
+    __shared__ float red[256];
+    __shared__ float wred[8];
+    const int bhg = blockIdx.x, bh = bhg / M, g = bhg % M, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const size_t rstride = (size_t)BH * M * (C + 2);
     const size_t base = (size_t)bh * M * (C + 2);
     float mx = -INFINITY;
-    for (int r = lane; r < R; r += 64) mx = fmaxf(mx, rec[r * rstride + base + g]);
-    mx = wave_max(mx);
-    float lsum = 0.f;
-    for (int r = lane; r < R; r += 64) {
+    for (int r = tid; r < R; r += 256) {
         const float mr = rec[r * rstride + base + g];
+        aw[r] = mr;
+        mx = fmaxf(mx, mr);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) wred[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    float lsum = 0.f;
+    for (int r = tid; r < R; r += 256) {
+        const float mr = aw[r];
         const float a = (mr == -INFINITY) ? 0.f : __expf(mr - mx);
-        lsum += rec[r * rstride + base + M + g] * a;
+        aw[r] = a;
+        lsum = fmaf(rec[r * rstride + base + M + g], a, lsum);
     }
     lsum = wave_sum(lsum);
-    for (int c = lane; c < C; c += 64) {
-        float s = 0.f;
-        for (int r = 0; r < R; ++r) {
-            const float mr = rec[r * rstride + base + g];
-            const float a = (mr == -INFINITY) ? 0.f : __expf(mr - mx);
-            s = fmaf(rec[r * rstride + base + 2 * M + (size_t)g * C + c], a, s);
-        }
-        if (out_rec) out_rec[base + 2 * M + (size_t)g * C + c] = s;
-        // IrregularMesh.py:186-188 with slice_norm == sum_n softmax == 1
-        if (finalize) S[(size_t)bhg * C + c] = (s / lsum) / (1.0f + 1e-5f);
+    if (lane == 0) wred[4 + wave] = lsum;
+    __syncthreads();
+    lsum = (wred[4] + wred[5]) + (wred[6] + wred[7]);
+    // phase 2
+    const int ngrp = 256 / C, c = tid % C, grp = tid / C;
+    float s = 0.f;
+    if (grp < ngrp) {
+        const float* sp = rec + base + 2 * M + (size_t)g * C + c;
+        for (int r = grp; r < R; r += ngrp) s = fmaf(sp[r * rstride], aw[r], s);
     }
-    if (lane == 0) {
+    red[tid] = s;
+    __syncthreads();
+    if (tid < C) {
+        float tot = 0.f;
+        for (int k = 0; k < ngrp; ++k) tot += red[k * C + tid];
+        if (out_rec) out_rec[base + 2 * M + (size_t)g * C + tid] = tot;
+        // IrregularMesh.py:186-188 with slice_norm == sum_n softmax == 1
+        if (finalize) S[(size_t)bhg * C + tid] = (tot / lsum) / (1.0f + 1e-5f);
+    }
+    if (tid == 0) {
         if (out_rec) {
             out_rec[base + g] = mx;
             out_rec[base + M + g] = lsum;
@@ -86,7 +110,9 @@ extern "C" int haet_slice_merge(const float* records, int R, int B, int H, int C
     if (finalize && (!col_max || !col_sum || !S))
         return fail(HAET_E_ARG, "slice_merge: finalize needs col_max, col_sum and S");
     if (!finalize && !out_record) return fail(HAET_E_ARG, "slice_merge: out_record is NULL");
-    hipLaunchKernelGGL(slice_merge_kernel, dim3(B * H * M), dim3(64), 0, as_stream(stream), records,
+    if (R > kMergeMaxR) return fail(HAET_E_ARG, "slice_merge: R=%d records > %d", R, kMergeMaxR);
+    if (C > 256 || 256 % C) return fail(HAET_E_ARG, "slice_merge: C=%d must divide 256", C);
+    hipLaunchKernelGGL(slice_merge_kernel, dim3(B * H * M), dim3(256), 0, as_stream(stream), records,
                        R, B * H, C, M, finalize, out_record, col_max, col_sum, S);
     return check_launch("slice_merge_kernel");
 }

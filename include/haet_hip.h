@@ -123,14 +123,15 @@ int haet_balltree_build(const float* pos /*[n_clouds*M, d]*/, int n_clouds, int 
 #define HAET_ERWIN_MAX_DEPTH 4
 
 typedef struct {
-    /* offsets (in floats) into the packed weight blob; Linear weights are stored
-     * TRANSPOSED, [in][out], so that consecutive lanes read consecutive outputs */
+    /* offsets (in floats) into the packed weight blob.  Linear weights keep PyTorch's
+     * [out][in] layout with every row zero-padded to roundup(in, 32) floats (one lane of the
+     * MFMA B operand reads 8 consecutive k of one output row); pe_w is transposed [d][c]. */
     int32_t norm1, norm2;            /* [c] */
     int32_t pe_w, pe_b;              /* [d][c], [c] */
-    int32_t qkv_w, qkv_b;            /* [c][3c], [3c] */
-    int32_t proj_w, proj_b;          /* [c][c], [c] */
-    int32_t w1_w, w1_b, w2_w, w2_b;  /* [c][hidden], [hidden] */
-    int32_t w3_w, w3_b;              /* [hidden][c], [c] */
+    int32_t qkv_w, qkv_b;            /* [3c][c~], [3c] */
+    int32_t proj_w, proj_b;          /* [c][c~], [c] */
+    int32_t w1_w, w1_b, w2_w, w2_b;  /* [hidden][c~], [hidden] */
+    int32_t w3_w, w3_b;              /* [c][hidden~], [c] */
 } haet_erwin_block_w;
 
 typedef struct {
@@ -140,7 +141,7 @@ typedef struct {
 
 typedef struct {
     int32_t stride;
-    int32_t w, b;               /* Linear, [K][out] / [out] */
+    int32_t w, b;               /* Linear, [out][K~] / [out] */
     int32_t bn_scale, bn_shift; /* eval BatchNorm as y*scale+shift, [c_out] */
 } haet_erwin_resample;
 

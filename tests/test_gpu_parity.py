@@ -90,7 +90,17 @@ def _check_tree(ti, tm, rot, sizes, exp_ti, exp_tm, exp_rots):
             off += n
 
 
-def test_balltree_device_vs_reference_fixtures(hip_device):
+@pytest.fixture(params=["auto", "lds"])
+def tree_path(request):
+    """'auto' = register-resident wave kernel for power-of-two clouds <= 64, 'lds' = generic kernel."""
+    import os
+
+    os.environ["HAET_TREE_LDS"] = "1" if request.param == "lds" else "0"
+    yield request.param
+    os.environ.pop("HAET_TREE_LDS", None)
+
+
+def test_balltree_device_vs_reference_fixtures(hip_device, tree_path):
     """All 432 tree cases produced by the reference's build_balltree_with_rotations."""
     from haet_amd import ops
 
@@ -105,7 +115,7 @@ def test_balltree_device_vs_reference_fixtures(hip_device):
 
 
 @pytest.mark.parametrize("name", EVAL_CASES)
-def test_balltree_on_fixture_positions(name, hip_device):
+def test_balltree_on_fixture_positions(name, hip_device, tree_path):
     from haet_amd import ops
 
     x, sd, meta, exp, cfg, tr, _ = _oracle_trace(name)

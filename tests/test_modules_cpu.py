@@ -64,13 +64,15 @@ def test_pack_erwin_layout():
     assert (e0.c, e0.heads, e0.ball, e0.depth, e0.hidden) == (32, 4, 32, 2, 128)
     assert (e1.c, e1.heads, e1.ball, e1.depth, e1.hidden) == (64, 8, 16, 2, 256)
     assert (d0.c, d0.heads, d0.ball, d0.depth) == (32, 4, 32, 2)
-    # transposed Linear: blob[qkv_w + k*3c + o] == qkv.weight[o, k]
+    # [out][in] rows padded to a multiple of 32 floats: blob[qkv_w + o*32 + k] == qkv.weight[o, k]
     blk = m.erwin.encoder[0].blocks[1]
     w = e0.blocks[1]
-    assert torch.equal(blob[w.qkv_w:w.qkv_w + 32 * 96].view(32, 96), blk.BMSA.qkv.weight.t())
+    assert torch.equal(blob[w.qkv_w:w.qkv_w + 96 * 32].view(96, 32), blk.BMSA.qkv.weight)
     assert w.qkv_w % 4 == 0 and w.w3_w % 4 == 0
-    pool = m.erwin.encoder[0].pool
-    assert torch.equal(blob[desc.pool[0].w:desc.pool[0].w + 70 * 64].view(70, 64), pool.proj.weight.t())
+    pool = m.erwin.encoder[0].pool  # K = 70 -> padded to 96
+    pw = blob[desc.pool[0].w:desc.pool[0].w + 64 * 96].view(64, 96)
+    assert torch.equal(pw[:, :70], pool.proj.weight) and (pw[:, 70:] == 0).all()
+    assert torch.equal(blob[w.pe_w:w.pe_w + 3 * 32].view(3, 32), blk.BMSA.pe_proj.weight.t())
     from haet_amd import _lib
     import ctypes
     assert 0 < _lib.load().haet_erwin_lds_bytes(ctypes.byref(desc), 64) < 160 * 1024
