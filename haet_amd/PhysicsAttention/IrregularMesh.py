@@ -19,4 +19,5 @@ class Physics_Attention_Irregular_Mesh(PhysicsAttentionBase):
                           rotate, decode, mlp_ratio, mp_steps, embed)
 
     def project(self, x):
-        return self.in_project_x(x)  # [B, N, H*C]; no [B,H,N,C] transpose is ever made
+        # [B, N, H*C]; no [B,H,N,C] transpose is ever made
+        return self._linear("in_project_x", self.in_project_x, x)

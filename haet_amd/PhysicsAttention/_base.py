@@ -87,6 +87,21 @@ class PhysicsAttentionBase(nn.Module):
     def project(self, x: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
 
+    def _split_linear(self, name: str, lin: nn.Linear):
+        """haet_linear_fwd operand of a Linear (cached per weight version), or None when the shape
+        is outside the MFMA GEMM's envelope (then the stock rocBLAS GEMM runs)."""
+        if not ops.linear_supported(lin.in_features, lin.out_features):
+            return None
+        cache = self.__dict__.setdefault("_split_cache", {})
+        key = (lin.weight.data_ptr(), lin.weight._version, lin.bias.data_ptr(), lin.bias._version)
+        if name not in cache or cache[name][0] != key:
+            cache[name] = (key, ops.SplitLinear(lin.weight, lin.bias))
+        return cache[name][1]
+
+    def _linear(self, name: str, lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+        w = self._split_linear(name, lin)
+        return lin(x) if w is None else ops.linear(x, w)
+
     def _slice_params(self) -> ops.SliceParams:
         ps = (self.in_project_slice.weight, self.in_project_slice.bias,
               self.ada_temp_linear.weight, self.ada_temp_linear.bias)
@@ -130,7 +145,7 @@ class PhysicsAttentionBase(nn.Module):
         with ev("deslice"):
             out_x = ops.deslice(x_lin, sp, col_max, col_sum, S2, H, C, G)  # [B, N, H*C]
         with ev("to_out"):
-            out = self.to_out(out_x.to(x.dtype))
+            out = self.to_out[1](self._linear("to_out", self.to_out[0], out_x)).to(x.dtype)
         if return_intermediates:
             return out, dict(x_lin=x_lin, col_max=col_max, col_sum=col_sum, eidetic=S, pos=pos,
                              processed=S2, out_x=out_x)

@@ -48,6 +48,9 @@ _P = c_void_p
 SIGNATURES = {
     "haet_abi_version": (c_int, []),
     "haet_last_error_string": (c_char_p, []),
+    "haet_split_bf16": (c_int, [_P, c_size_t, _P, _P, _P]),
+    "haet_linear_supported": (c_int, [c_int, c_int]),
+    "haet_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
     "haet_slice_num_parts": (c_int, [c_int] * 5),
     "haet_slice_part_floats": (c_size_t, [c_int] * 4),
     "haet_slice_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float] + [c_int] * 5 + [_P, _P]),

@@ -153,3 +153,32 @@ def deslice(x_lin: Tensor, p: SliceParams, col_max: Tensor, col_sum: Tensor, S2:
                                _p(col_max), _p(col_sum), _p(_f32(S2, "S2")), B, N, H, C, M, _p(out),
                                _stream()), "haet_deslice_fwd")
     return out
+
+
+class SplitLinear:
+    """A Linear layer's weight as bf16 hi/lo planes for haet_linear_fwd (built once per weight
+    version by haet_split_bf16 on the device)."""
+
+    def __init__(self, weight: Tensor, bias: Optional[Tensor]):
+        lib = _lib.load()
+        w = _f32(weight.detach(), "weight")
+        self.O, self.K = w.shape
+        self.hi = torch.empty((self.O, self.K), dtype=torch.int16, device=w.device)
+        self.lo = torch.empty_like(self.hi)
+        check(lib.haet_split_bf16(_p(w), w.numel(), _p(self.hi), _p(self.lo), _stream()), "haet_split_bf16")
+        self.bias = None if bias is None else _f32(bias.detach(), "bias")
+
+
+def linear_supported(K: int, O: int) -> bool:
+    return bool(_lib.load().haet_linear_supported(int(K), int(O)))
+
+
+def linear(x: Tensor, w: SplitLinear) -> Tensor:
+    """out[..., O] = x[..., K] @ W^T + b on the matrix cores (split-bf16, fp32-class accuracy)."""
+    lib = _lib.load()
+    x = _f32(x, "x")
+    rows = x.numel() // w.K
+    out = torch.empty(x.shape[:-1] + (w.O,), dtype=torch.float32, device=x.device)
+    check(lib.haet_linear_fwd(_p(x), _p(w.hi), _p(w.lo), _p(w.bias), rows, w.K, w.O, _p(out), _stream()),
+          "haet_linear_fwd")
+    return out

@@ -46,6 +46,21 @@ typedef void* haet_stream_t;
 int haet_abi_version(void);
 const char* haet_last_error_string(void);
 
+/* ------------------------------------------------------------------ per-point projections
+ * in_project_x (models/PhysicsAttention/IrregularMesh.py:157-158) and to_out (:235) are
+ * plain Linear layers, fp32 cuBLAS GEMMs in the reference.  haet_linear_fwd computes
+ *     out[n, o] = sum_k x[n, k] W[o, k] + bias[o]
+ * on the bf16 matrix cores as split-bf16 (3 MFMAs per fp32 product, fp32 accumulate,
+ * ~2^-16 operand error), which turns the GEMM from compute-bound (fp32 rate) into HBM-bound.
+ * W is passed pre-split: haet_split_bf16 writes bf16 hi = RNE(w), lo = RNE(w - hi) planes
+ * ([O][K] each) once per weight version.  Supported when haet_linear_supported(K, O) != 0
+ * (K % 32 == 0, O % 128 == 0); callers use a library GEMM otherwise.                    */
+int haet_split_bf16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, haet_stream_t stream);
+int haet_linear_supported(int K, int O);
+int haet_linear_fwd(const float* x /*[Nrows,K]*/, const uint16_t* W_hi, const uint16_t* W_lo,
+                    const float* bias /*[O] or NULL*/, int Nrows, int K, int O,
+                    float* out /*[Nrows,O]*/, haet_stream_t stream);
+
 /* ------------------------------------------------------------------ slice pass
  * Replaces the materialised Rep-Slice softmax + eidetic einsum of
  * models/PhysicsAttention/IrregularMesh.py:168-188 (Ada-Temp, logits, softmax over

@@ -321,3 +321,25 @@ def test_ragged_point_counts_mfma_shapes(N, H, M, hip_device):
     out = ops.deslice(x_lin.to(hip_device), sp, cm, cs, S2.to(hip_device), H, C, M)
     ref = torch.einsum("bhgc,bhng->bhnc", S2.double().reshape(B, H, M, C), w).permute(0, 2, 1, 3).reshape(B, N, H * C)
     assert O.rel_l2(out.cpu(), ref) < 5e-5
+
+
+@pytest.mark.parametrize("rows,K,O", [(1, 32, 128), (127, 64, 256), (1000, 256, 256), (513, 256, 384),
+                                      (4096, 256, 512), (300, 128, 128)])
+def test_split_bf16_linear_vs_fp64(rows, K, O, hip_device):
+    """haet_linear_fwd (in_project_x / to_out): split-bf16 MFMA GEMM against an fp64 reference
+    (and, as the sanity anchor, against the fp32 library GEMM it replaces)."""
+    from haet_amd import ops
+
+    torch.manual_seed(rows + K + O)
+    x = torch.randn(rows, K) * 1.7
+    W, b = torch.randn(O, K) * 0.05, torch.randn(O)
+    ref = x.double() @ W.double().t() + b.double()
+    w = ops.SplitLinear(W.to(hip_device), b.to(hip_device))
+    out = ops.linear(x.to(hip_device), w).cpu()
+    err = O_rel(out, ref)
+    err_fp32 = O_rel(torch.nn.functional.linear(x, W, b), ref)
+    assert err < 2e-5, (err, err_fp32)
+
+
+def O_rel(a, b):
+    return O.rel_l2(a, b)
