@@ -127,7 +127,8 @@ def main():
                        "points": N, "slices": 64, "sharding": f"points/{world}"},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None},
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic_bytes(dom, N) if world == 1 else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             res.update(cpu_leg(mod, x_full, out))
@@ -135,6 +136,21 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic_bytes(kernel, n_points):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*pmc_traffic.json:
+    FETCH_SIZE corrected x2 for gfx950 + WRITE_SIZE), or None if they were taken at another size."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    k = d.get("kernels", {}).get(kernel)
+    if not k or d.get("points") != n_points:
+        return None
+    return (2.0 * k["fetch_kb_raw"] + k["write_kb"]) * 1024.0
 
 
 def host_cores():
