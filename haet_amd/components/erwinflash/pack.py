@@ -1,46 +1,63 @@
-"""Pack an ErwinTransformer's parameters into the single fp32 blob + descriptor that
+"""Pack an ErwinTransformer's parameters into the single blob + descriptor that
 haet_erwin_fwd consumes (layout contract: include/haet_hip.h, haet_erwin_desc).
 
-Linear weights keep PyTorch's [out][in] layout with rows zero-padded to a multiple of 32
-floats (one lane of the MFMA B operand reads 8 consecutive k of one output row); eval-mode BatchNorm1d is folded to y*scale + shift
-(scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale;
-models/components/erwinflash/components/pooling.py:23,38,56,68)."""
+Blob = [ copy of the descriptor | tensors ], offsets in floats from the blob start.
+* Linear weights: PyTorch [out][in] layout, rows zero-padded to Kp = roundup(in, 32), stored
+  pre-split as two bf16 planes -- hi = RNE(w) at the offset, lo = RNE(w - hi) O*Kp bf16 later --
+  so the kernel feeds them to the MFMA without conversion (3 products hi*hi + hi*lo + lo*hi
+  give fp32-class accuracy).
+* pe_proj (2/3 inputs) stays fp32, transposed [d][c]; biases / norm weights fp32.
+* eval-mode BatchNorm1d is folded to y*scale + shift (scale = gamma / sqrt(running_var + eps),
+  shift = beta - running_mean * scale; models/components/erwinflash/components/pooling.py:23,38,56,68).
+"""
 from __future__ import annotations
+
+import ctypes
 
 import torch
 
 from ..._lib import MAX_DEPTH, MAX_LEVELS, ErwinDesc, HaetError
 
+HEADER_FLOATS = (ctypes.sizeof(ErwinDesc) + 15) // 16 * 4
+
 
 class _Blob:
-    def __init__(self):
-        self.chunks, self.n = [], 0
+    def __init__(self, device):
+        self.device = device
+        self.chunks, self.n = [], HEADER_FLOATS
 
     def add(self, t: torch.Tensor) -> int:
-        t = t.detach().float().reshape(-1)
+        t = t.detach().reshape(-1)
+        if t.dtype != torch.float32:
+            raise HaetError("blob tensors are appended as fp32 words")
         pad = (-self.n) % 4  # keep every tensor 16-byte aligned
         if pad:
-            self.chunks.append(torch.zeros(pad, device=t.device))
+            self.chunks.append(torch.zeros(pad, device=self.device))
             self.n += pad
         off = self.n
-        self.chunks.append(t)
+        self.chunks.append(t.to(self.device))
         self.n += t.numel()
         return off
 
     def lin(self, linear):
-        """[out][in] rows zero-padded to a multiple of 32 floats (MFMA k-step)."""
+        """[out][in~32] bf16 hi plane followed by the lo plane (see module docstring)."""
         w = linear.weight.detach().float()
         pad = (-w.shape[1]) % 32
         if pad:
             w = torch.nn.functional.pad(w, (0, pad))
-        return self.add(w.contiguous()), self.add(linear.bias)
+        hi = w.to(torch.bfloat16)
+        lo = (w - hi.float()).to(torch.bfloat16)
+        planes = torch.cat([hi.reshape(-1), lo.reshape(-1)]).contiguous()
+        return self.add(planes.view(torch.float32)), self.add(linear.bias.detach().float())
 
     def lin_t(self, linear):
-        """transposed [in][out] (the 2/3-wide positional projection, evaluated on the VALU)."""
-        return self.add(linear.weight.t().contiguous()), self.add(linear.bias)
+        """fp32, transposed [in][out] (the 2/3-wide positional projection, evaluated on the VALU)."""
+        return self.add(linear.weight.detach().float().t().contiguous()), self.add(linear.bias.detach().float())
 
-    def tensor(self):
-        return torch.cat(self.chunks).contiguous()
+    def tensor(self, desc):
+        hdr = torch.frombuffer(bytearray(bytes(desc)) + bytearray(HEADER_FLOATS * 4 - ctypes.sizeof(desc)),
+                               dtype=torch.float32).to(self.device)
+        return torch.cat([hdr] + self.chunks).contiguous()
 
 
 def _fill_layer(dst, layer, blob):
@@ -50,7 +67,7 @@ def _fill_layer(dst, layer, blob):
         raise HaetError(f"Erwin layer depth {dst.depth} > {MAX_DEPTH}")
     for j, blk in enumerate(layer.blocks):
         w = dst.blocks[j]
-        w.norm1, w.norm2 = blob.add(blk.norm1.weight), blob.add(blk.norm2.weight)
+        w.norm1, w.norm2 = blob.add(blk.norm1.weight.float()), blob.add(blk.norm2.weight.float())
         w.pe_w, w.pe_b = blob.lin_t(blk.BMSA.pe_proj)
         w.qkv_w, w.qkv_b = blob.lin(blk.BMSA.qkv)
         w.proj_w, w.proj_b = blob.lin(blk.BMSA.proj)
@@ -63,16 +80,17 @@ def _fill_resample(dst, mod, blob):
     dst.stride = mod.stride
     dst.w, dst.b = blob.lin(mod.proj)
     bn = mod.norm
-    scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+    scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
     dst.bn_scale = blob.add(scale)
-    dst.bn_shift = blob.add(bn.bias.detach() - bn.running_mean * scale)
+    dst.bn_shift = blob.add(bn.bias.detach().float() - bn.running_mean.float() * scale)
 
 
 def pack_erwin(erwin):
     n_levels = len(erwin.encoder) + 1
     if n_levels > MAX_LEVELS:
         raise HaetError(f"Erwin with {n_levels} levels > {MAX_LEVELS}")
-    desc, blob = ErwinDesc(), _Blob()
+    device = next(erwin.parameters()).device
+    desc, blob = ErwinDesc(), _Blob(device)
     desc.n_levels, desc.d = n_levels, erwin.dimensionality
     desc.rotate, desc.decode = int(erwin.rotate > 0), int(bool(erwin.decode))
     for i, layer in enumerate(erwin.encoder):
@@ -84,4 +102,4 @@ def pack_erwin(erwin):
         lvl = n_levels - 2 - k
         _fill_layer(desc.dec[lvl], layer, blob)
         _fill_resample(desc.unpool[lvl], layer.unpool, blob)
-    return blob.tensor(), desc
+    return blob.tensor(desc), desc

@@ -130,17 +130,19 @@ int haet_balltree_build(const float* pos /*[n_clouds*M, d]*/, int n_clouds, int 
  * flash_attn_qkvpacked_func call :82-84; SwiGLU mlp.py:8-18; BallPooling/
  * BallUnpooling pooling.py:25-72) for eval-mode BatchNorm, one workgroup per cloud.
  *
- * `desc` (host, passed to the kernel by value) describes the network; `weights` (device) is
- * ONE packed fp32 blob laid out by haet_amd/erwin_pack.py.  Returns HAET_E_RESOURCE when the
- * token state of one cloud does not fit the 160 KiB LDS of a CU.
+ * `desc` (host) describes the network and is used for validation and LDS sizing; `weights`
+ * (device) is ONE packed blob that BEGINS WITH A COPY OF *desc (sizeof(haet_erwin_desc) bytes,
+ * padded to 16) followed by the tensors, laid out by haet_amd/components/erwinflash/pack.py.
+ * Returns HAET_E_RESOURCE when the token state of one cloud does not fit the 160 KiB LDS of a CU.
  */
 #define HAET_ERWIN_MAX_LEVELS 4
 #define HAET_ERWIN_MAX_DEPTH 4
 
 typedef struct {
-    /* offsets (in floats) into the packed weight blob.  Linear weights keep PyTorch's
-     * [out][in] layout with every row zero-padded to roundup(in, 32) floats (one lane of the
-     * MFMA B operand reads 8 consecutive k of one output row); pe_w is transposed [d][c]. */
+    /* offsets (in floats) from the start of the blob.  Linear weights keep PyTorch's [out][in]
+     * layout, rows zero-padded to in~ = roundup(in, 32), pre-split into two bf16 planes: hi =
+     * RNE(w) at the offset, lo = RNE(w - hi) out*in~ bf16 later (one lane of the MFMA B operand
+     * reads 8 consecutive k of one output row).  pe_w is fp32, transposed [d][c].              */
     int32_t norm1, norm2;            /* [c] */
     int32_t pe_w, pe_b;              /* [d][c], [c] */
     int32_t qkv_w, qkv_b;            /* [3c][c~], [3c] */

@@ -64,14 +64,20 @@ def test_pack_erwin_layout():
     assert (e0.c, e0.heads, e0.ball, e0.depth, e0.hidden) == (32, 4, 32, 2, 128)
     assert (e1.c, e1.heads, e1.ball, e1.depth, e1.hidden) == (64, 8, 16, 2, 256)
     assert (d0.c, d0.heads, d0.ball, d0.depth) == (32, 4, 32, 2)
-    # [out][in] rows padded to a multiple of 32 floats: blob[qkv_w + o*32 + k] == qkv.weight[o, k]
+    # blob starts with a copy of the descriptor
+    import ctypes
+    from haet_amd.components.erwinflash.pack import HEADER_FLOATS
+    assert bytes(blob[:HEADER_FLOATS].numpy().tobytes()[:ctypes.sizeof(desc)]) == bytes(desc)
+    # Linear: [out][in~32] bf16 hi plane, then lo plane; hi + lo reproduces the fp32 weight to ~2^-16
     blk = m.erwin.encoder[0].blocks[1]
     w = e0.blocks[1]
-    assert torch.equal(blob[w.qkv_w:w.qkv_w + 96 * 32].view(96, 32), blk.BMSA.qkv.weight)
+    planes = blob[w.qkv_w:w.qkv_w + 96 * 32].view(torch.bfloat16).view(2, 96, 32).float()
+    assert torch.allclose(planes[0] + planes[1], blk.BMSA.qkv.weight, rtol=2e-5, atol=1e-9)
     assert w.qkv_w % 4 == 0 and w.w3_w % 4 == 0
     pool = m.erwin.encoder[0].pool  # K = 70 -> padded to 96
-    pw = blob[desc.pool[0].w:desc.pool[0].w + 64 * 96].view(64, 96)
-    assert torch.equal(pw[:, :70], pool.proj.weight) and (pw[:, 70:] == 0).all()
+    pw = blob[desc.pool[0].w:desc.pool[0].w + 64 * 96].view(torch.bfloat16).view(2, 64, 96).float()
+    assert torch.allclose(pw[0, :, :70] + pw[1, :, :70], pool.proj.weight, rtol=2e-5, atol=1e-9)
+    assert (pw[:, :, 70:] == 0).all()
     assert torch.equal(blob[w.pe_w:w.pe_w + 3 * 32].view(3, 32), blk.BMSA.pe_proj.weight.t())
     from haet_amd import _lib
     import ctypes
