@@ -57,7 +57,9 @@ class _Blob:
     def tensor(self, desc):
         hdr = torch.frombuffer(bytearray(bytes(desc)) + bytearray(HEADER_FLOATS * 4 - ctypes.sizeof(desc)),
                                dtype=torch.float32).to(self.device)
-        return torch.cat([hdr] + self.chunks).contiguous()
+        pad = (-self.n) % 4  # whole 16-byte chunks: the kernel walks the blob with 16-B loads
+        tail = [torch.zeros(pad, device=self.device)] if pad else []
+        return torch.cat([hdr] + self.chunks + tail).contiguous()
 
 
 def _fill_layer(dst, layer, blob):

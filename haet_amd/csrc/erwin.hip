@@ -321,9 +321,21 @@ __host__ __device__ inline int erwin_layout(const haet_erwin_desc& D, int Mp, in
 __global__ __launch_bounds__(512) void erwin_kernel(
     const float* __restrict__ tokens, const float* __restrict__ pos,
     const int32_t* __restrict__ tree_idx, const uint8_t* __restrict__ tree_mask,
-    const int32_t* __restrict__ rot, const float* __restrict__ W, int M, int Mp,
+    const int32_t* __restrict__ rot, const float* __restrict__ W, int w_chunks, int M, int Mp,
     float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // Warm this XCD's L2 with the whole weight blob (~0.5 MB) before anything depends on it: the
+    // 7 GB the streaming passes move between two forwards evict it, and the Linear chain below
+    // is a sequence of ~70 dependent weight fetches per cloud (2-3 us each from HBM, ~0.6 us
+    // from L2).  The loads are issued back to back and only consumed at the very end.
+    unsigned warm = 0;
+    {
+        const u32x4* w16 = reinterpret_cast<const u32x4*>(W);
+        for (int i = threadIdx.x; i < w_chunks; i += blockDim.x) {
+            const u32x4 v = w16[i];  // plain (cached) load: the point is to leave the line in L2
+            warm ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+        }
+    }
     const haet_erwin_desc& D = *reinterpret_cast<const haet_erwin_desc*>(W);
     const int cloud = blockIdx.x, n_clouds = gridDim.x, d = D.d, nl = D.n_levels;
     Lds s;
@@ -454,6 +466,7 @@ __global__ __launch_bounds__(512) void erwin_kernel(
         const size_t g = (size_t)cloud * Mp + slot;
         if (tree_mask[g]) out[(size_t)tree_idx[g] * c0 + ch] = s.X[0][slot * s.ld[0] + ch];
     }
+    if (warm == 0x9E3779B9u && M < 0) out[0] = 0.f;  // keeps the warm-up loads alive; never taken
 }
 
 static int erwin_validate(const haet_erwin_desc* D, int Mp) {
@@ -501,8 +514,10 @@ extern "C" size_t haet_erwin_lds_bytes(const haet_erwin_desc* desc, int Mp) {
 
 extern "C" int haet_erwin_fwd(const float* tokens, const float* pos, const int32_t* tree_idx,
                               const uint8_t* tree_mask, const int32_t* rot, const float* weights,
-                              const haet_erwin_desc* desc, int n_clouds, int M, float* out,
-                              haet_stream_t stream) {
+                              size_t weight_floats, const haet_erwin_desc* desc, int n_clouds, int M,
+                              float* out, haet_stream_t stream) {
+    if (weight_floats * 4 < sizeof(haet_erwin_desc))
+        return fail(HAET_E_ARG, "erwin: weight blob smaller than its descriptor header");
     if (!tokens || !pos || !tree_idx || !tree_mask || !weights || !out || n_clouds < 1 || M < 2)
         return fail(HAET_E_ARG, "erwin: null pointer or bad sizes");
     int depth = 0;
@@ -523,6 +538,6 @@ extern "C" int haet_erwin_fwd(const float* tokens, const float* pos, const int32
         attr_set = bytes;
     }
     hipLaunchKernelGGL(erwin_kernel, dim3(n_clouds), dim3(512), bytes, as_stream(stream), tokens,
-                       pos, tree_idx, tree_mask, rot, weights, M, Mp, out);
+                       pos, tree_idx, tree_mask, rot, weights, (int)(weight_floats / 4), M, Mp, out);
     return check_launch("erwin_kernel");
 }

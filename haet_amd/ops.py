@@ -139,7 +139,8 @@ def erwin_fwd(tokens: Tensor, pos: Tensor, tree_idx: Tensor, tree_mask: Tensor, 
     tokens, pos = _f32(tokens, "tokens"), _f32(pos, "pos")
     out = torch.empty_like(tokens)
     check(lib.haet_erwin_fwd(_p(tokens), _p(pos), _p(tree_idx), _p(tree_mask), _p(rot), _p(weights),
-                             ctypes.byref(desc), n_clouds, M, _p(out), _stream()), "haet_erwin_fwd")
+                             weights.numel(), ctypes.byref(desc), n_clouds, M, _p(out), _stream()),
+          "haet_erwin_fwd")
     return out
 
 

@@ -177,8 +177,9 @@ size_t haet_erwin_lds_bytes(const haet_erwin_desc* desc, int Mp);
 
 int haet_erwin_fwd(const float* tokens /*[n_clouds*M, c0]*/, const float* pos /*[n_clouds*M, d]*/,
                    const int32_t* tree_idx, const uint8_t* tree_mask, const int32_t* rot,
-                   const float* weights, const haet_erwin_desc* desc,
-                   int n_clouds, int M, float* out /*[n_clouds*M, c0]*/, haet_stream_t stream);
+                   const float* weights, size_t weight_floats /* length of the blob */,
+                   const haet_erwin_desc* desc, int n_clouds, int M,
+                   float* out /*[n_clouds*M, c0]*/, haet_stream_t stream);
 
 /* ------------------------------------------------------------------ de-slice pass
  * Replaces einsum('bhgc,bhng->bhnc') + rearrange 'b h n d -> b n (h d)'
