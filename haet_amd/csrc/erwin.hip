@@ -233,10 +233,13 @@ __device__ void erwin_block(const Lds& s, int lvl, const haet_erwin_layer& L,
     const Img ia = {s.ia, img_stride(c), n * img_stride(c)};
     const Img ih = {s.wide, img_stride(hid), n * img_stride(hid)};
     // x~ = RMSNorm(x) + pe_proj(pos - ball centre)            (attention.py:59-61)
+    STAMP(16);
     ball_rel_pos(s.P[lvl], n, d, L.ball, perm, s.rel);
     __syncthreads();
+    STAMP(17);
     norm_rows(X, ld, n, c, W + w.norm1, s.rel, d, W + w.pe_w, W + w.pe_b, ia);
     __syncthreads();
+    STAMP(18);
     {
         const float* qb = W + w.qkv_b;
         float* Q = reinterpret_cast<float*>(s.wide);
@@ -244,15 +247,18 @@ __device__ void erwin_block(const Lds& s, int lvl, const haet_erwin_layer& L,
                        [=](int t, int o, float v, float) { Q[t * ldq + o] = v + qb[o]; });
     }
     __syncthreads();
+    STAMP(19);
     attention_dispatch(c / L.heads, reinterpret_cast<const float*>(s.wide), ldq, n, c, L.heads, L.ball,
                        perm, ia);
     __syncthreads();
+    STAMP(20);
     {
         const float* pb = W + w.proj_b;
         linear_mfma<1>(ia, n, c, wptr(W, w.proj_w), nullptr, c,
                        [=](int t, int o, float v, float) { X[t * ld + o] += v + pb[o]; });
     }
     __syncthreads();
+    STAMP(21);
     // x += W3( W2 x^ * silu(W1 x^) ),  x^ = RMSNorm(x)          (mlp.py:17-18)
     norm_rows(X, ld, n, c, W + w.norm2, nullptr, 0, nullptr, nullptr, ia);
     {
@@ -260,6 +266,7 @@ __device__ void erwin_block(const Lds& s, int lvl, const haet_erwin_layer& L,
         for (int i = threadIdx.x; i < n * padk; i += blockDim.x) ih.put(i / padk, hid + i % padk, 0.f);
     }
     __syncthreads();
+    STAMP(22);
     {
         const float* b1 = W + w.w1_b;
         const float* b2 = W + w.w2_b;
@@ -269,12 +276,14 @@ __device__ void erwin_block(const Lds& s, int lvl, const haet_erwin_layer& L,
         });
     }
     __syncthreads();
+    STAMP(23);
     {
         const float* b3 = W + w.w3_b;
         linear_mfma<1>(ih, n, hid, wptr(W, w.w3_w), nullptr, c,
                        [=](int t, int o, float v, float) { X[t * ld + o] += v + b3[o]; });
     }
     __syncthreads();
+    STAMP(24);
 }
 
 __device__ void run_layer(const Lds& s, int lvl, const haet_erwin_layer& L,
@@ -284,6 +293,21 @@ __device__ void run_layer(const Lds& s, int lvl, const haet_erwin_layer& L,
         erwin_block(s, lvl, L, L.blocks[j], W, d, rot ? s.rot[lvl] : s.ident);
     }
 }
+
+#ifdef HAET_STAMPS
+// Diagnostic build only (make EXTRA=-DHAET_STAMPS; tools/erwin_stamps.py): s_memtime at phase
+// boundaries of cloud 0, written to a buffer nothing else reads.  Never quote this build's run time.
+__device__ unsigned long long haet_stamps[64];
+#define STAMP(i)                                                                        \
+    do {                                                                                \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                      \
+            haet_stamps[i] = __builtin_amdgcn_s_memtime();                              \
+            haet_stamps[32 + (i)] = __builtin_amdgcn_s_memrealtime();                   \
+        }                                                                               \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 // LDS carve-up shared by host (sizing) and device; returns the total in floats
 __host__ __device__ inline int erwin_layout(const haet_erwin_desc& D, int Mp, int* ia_bytes,
@@ -324,6 +348,7 @@ __global__ __launch_bounds__(512) void erwin_kernel(
     const int32_t* __restrict__ rot, const float* __restrict__ W, int w_chunks, int M, int Mp,
     float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    STAMP(0);
     // Warm this XCD's L2 with the whole weight blob (~0.5 MB) before anything depends on it: the
     // 7 GB the streaming passes move between two forwards evict it, and the Linear chain below
     // is a sequence of ~70 dependent weight fetches per cloud (2-3 us each from HBM, ~0.6 us
@@ -336,6 +361,7 @@ __global__ __launch_bounds__(512) void erwin_kernel(
             warm ^= v[0] ^ v[1] ^ v[2] ^ v[3];
         }
     }
+    STAMP(1);
     const haet_erwin_desc& D = *reinterpret_cast<const haet_erwin_desc*>(W);
     const int cloud = blockIdx.x, n_clouds = gridDim.x, d = D.d, nl = D.n_levels;
     Lds s;
@@ -388,10 +414,12 @@ __global__ __launch_bounds__(512) void erwin_kernel(
         }
     }
     __syncthreads();
+    STAMP(2);
 
     // encoder: blocks then BallPooling (pooling.py:25-40)
     for (int l = 0; l < nl - 1; ++l) {
         run_layer(s, l, D.enc[l], W, d, D.rotate);
+        STAMP(3 + l);
         const haet_erwin_resample& R = D.pool[l];
         const int st = R.stride, n2 = s.n[l + 1], c = D.enc[l].c, K = st * c + st * d;
         const Img rows = {s.wide, img_stride(K), n2 * img_stride(K)};
@@ -426,7 +454,9 @@ __global__ __launch_bounds__(512) void erwin_kernel(
         }
         __syncthreads();
     }
+    STAMP(8);
     run_layer(s, nl - 1, D.enc[nl - 1], W, d, D.rotate);
+    STAMP(9);
     // decoder: BallUnpooling (pooling.py:58-72) then blocks
     for (int l = nl - 2; l >= 0; --l) {
         const haet_erwin_resample& R = D.unpool[l];
@@ -458,7 +488,9 @@ __global__ __launch_bounds__(512) void erwin_kernel(
             });
         }
         __syncthreads();
+        STAMP(10);
         run_layer(s, l, D.dec[l], W, d, D.rotate);
+        STAMP(11);
     }
     // node.x[tree_mask][argsort(tree_idx[tree_mask])]  (erwin_flash.py:193)
     for (int i = threadIdx.x; i < Mp * c0; i += blockDim.x) {
@@ -466,6 +498,7 @@ __global__ __launch_bounds__(512) void erwin_kernel(
         const size_t g = (size_t)cloud * Mp + slot;
         if (tree_mask[g]) out[(size_t)tree_idx[g] * c0 + ch] = s.X[0][slot * s.ld[0] + ch];
     }
+    STAMP(12);
     if (warm == 0x9E3779B9u && M < 0) out[0] = 0.f;  // keeps the warm-up loads alive; never taken
 }
 
@@ -505,6 +538,12 @@ static int erwin_validate(const haet_erwin_desc* D, int Mp) {
 }  // namespace haet
 
 using namespace haet;
+
+#ifdef HAET_STAMPS
+extern "C" int haet_debug_read_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(haet_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" size_t haet_erwin_lds_bytes(const haet_erwin_desc* desc, int Mp) {
     if (erwin_validate(desc, Mp) != HAET_OK) return 0;

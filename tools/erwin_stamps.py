@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does one cloud of the Erwin kernel spend its cycles?
+Needs the stamped build:  make -C haet_amd/csrc clean all EXTRA=-DHAET_STAMPS   (GPU box only;
+rebuild without EXTRA afterwards).  Prints s_memtime deltas between phase boundaries of cloud 0
+and the shader clock derived from s_memrealtime (100 MHz)."""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from haet_amd import _lib
+from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+mod = Physics_Attention_Irregular_Mesh(256, heads=8, dim_head=32, slice_num=64, rotate=45).eval().to(dev)
+x = torch.randn(1, 200_000, 256, device=dev)
+big = torch.empty(256 * 1024 * 1024, device=dev)  # flush caches between forwards like the 1M-point run
+with torch.no_grad():
+    for _ in range(3):
+        big.fill_(1.0)
+        mod(x)
+torch.cuda.synchronize()
+lib = _lib.load()
+buf = (ctypes.c_ulonglong * 64)()
+assert lib.haet_debug_read_stamps(buf) == 0
+t = list(buf)
+names = {0: "start", 1: "after L2 warm", 2: "after gather", 3: "enc0 blocks done", 8: "pool done",
+         9: "bottleneck done", 10: "unpool done", 11: "dec0 blocks done", 12: "end"}
+clk = (t[12] - t[0]) / max(1, (t[32 + 12] - t[32 + 0])) * 100.0
+print(f"shader clock during the kernel: {clk:.0f} MHz; total {t[12]-t[0]} cycles = {(t[32+12]-t[32])/100.0:.1f} us")
+prev = 0
+for i in (1, 2, 3, 8, 9, 10, 11, 12):
+    print(f"  {names[i]:22s} +{t[i]-t[prev]:8d} cycles")
+    prev = i
+print("last block (dec0 block 1) phases:")
+bn = {17: "rel_pos", 18: "norm1+pe", 19: "qkv", 20: "attention", 21: "proj", 22: "norm2", 23: "w1w2", 24: "w3"}
+for i in range(17, 25):
+    print(f"  {bn[i]:10s} {t[i]-t[i-1]:8d} cycles")
