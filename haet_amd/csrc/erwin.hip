@@ -30,6 +30,21 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
+#ifdef HAET_STAMPS
+// Diagnostic build only (make EXTRA=-DHAET_STAMPS; tools/erwin_stamps.py): s_memtime at phase
+// boundaries of cloud 0, written to a buffer nothing else reads.  Never quote this build's run time.
+__device__ unsigned long long haet_stamps[64];
+#define STAMP(i)                                                                        \
+    do {                                                                                \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                      \
+            haet_stamps[i] = __builtin_amdgcn_s_memtime();                              \
+            haet_stamps[32 + (i)] = __builtin_amdgcn_s_memrealtime();                   \
+        }                                                                               \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ unsigned short bf16_rne(float a) {
     f32x2 v = {a, 0.f};
     return (unsigned short)__builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
@@ -293,21 +308,6 @@ __device__ void run_layer(const Lds& s, int lvl, const haet_erwin_layer& L,
         erwin_block(s, lvl, L, L.blocks[j], W, d, rot ? s.rot[lvl] : s.ident);
     }
 }
-
-#ifdef HAET_STAMPS
-// Diagnostic build only (make EXTRA=-DHAET_STAMPS; tools/erwin_stamps.py): s_memtime at phase
-// boundaries of cloud 0, written to a buffer nothing else reads.  Never quote this build's run time.
-__device__ unsigned long long haet_stamps[64];
-#define STAMP(i)                                                                        \
-    do {                                                                                \
-        if (blockIdx.x == 0 && threadIdx.x == 0) {                                      \
-            haet_stamps[i] = __builtin_amdgcn_s_memtime();                              \
-            haet_stamps[32 + (i)] = __builtin_amdgcn_s_memrealtime();                   \
-        }                                                                               \
-    } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
 
 // LDS carve-up shared by host (sizing) and device; returns the total in floats
 __host__ __device__ inline int erwin_layout(const haet_erwin_desc& D, int Mp, int* ia_bytes,
