@@ -24,7 +24,7 @@ class HaetError(RuntimeError):
 class ErwinBlockW(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in (
         "norm1", "norm2", "pe_w", "pe_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
-        "w1_w", "w1_b", "w2_w", "w2_b", "w3_w", "w3_b")]
+        "w1_w", "w1_b", "w2_w", "w2_b", "w3_w", "w3_b", "small_off", "small_len")]
 
 
 class ErwinLayer(ctypes.Structure):
@@ -34,7 +34,7 @@ class ErwinLayer(ctypes.Structure):
 
 class ErwinResample(ctypes.Structure):
     _fields_ = [("stride", c_int32), ("w", c_int32), ("b", c_int32),
-                ("bn_scale", c_int32), ("bn_shift", c_int32)]
+                ("bn_scale", c_int32), ("bn_shift", c_int32), ("small_off", c_int32), ("small_len", c_int32)]
 
 
 class ErwinDesc(ctypes.Structure):

@@ -39,7 +39,7 @@ class _Blob:
         self.n += t.numel()
         return off
 
-    def lin(self, linear):
+    def planes(self, linear):
         """[out][in~32] bf16 hi plane followed by the lo plane (see module docstring)."""
         w = linear.weight.detach().float()
         pad = (-w.shape[1]) % 32
@@ -48,11 +48,15 @@ class _Blob:
         hi = w.to(torch.bfloat16)
         lo = (w - hi.float()).to(torch.bfloat16)
         planes = torch.cat([hi.reshape(-1), lo.reshape(-1)]).contiguous()
-        return self.add(planes.view(torch.float32)), self.add(linear.bias.detach().float())
+        return self.add(planes.view(torch.float32))
 
-    def lin_t(self, linear):
-        """fp32, transposed [in][out] (the 2/3-wide positional projection, evaluated on the VALU)."""
-        return self.add(linear.weight.detach().float().t().contiguous()), self.add(linear.bias.detach().float())
+    def end_group(self, start):
+        """Close a small-parameter group: pad to 16 bytes, return (offset, length in floats)."""
+        pad = (-self.n) % 4
+        if pad:
+            self.chunks.append(torch.zeros(pad, device=self.device))
+            self.n += pad
+        return start, self.n - start
 
     def tensor(self, desc):
         hdr = torch.frombuffer(bytearray(bytes(desc)) + bytearray(HEADER_FLOATS * 4 - ctypes.sizeof(desc)),
@@ -67,24 +71,36 @@ def _fill_layer(dst, layer, blob):
     dst.depth, dst.hidden = len(layer.blocks), layer.hidden_dim * layer.mlp_ratio
     if dst.depth > MAX_DEPTH:
         raise HaetError(f"Erwin layer depth {dst.depth} > {MAX_DEPTH}")
+    f = lambda t: t.detach().float()
     for j, blk in enumerate(layer.blocks):
         w = dst.blocks[j]
-        w.norm1, w.norm2 = blob.add(blk.norm1.weight.float()), blob.add(blk.norm2.weight.float())
-        w.pe_w, w.pe_b = blob.lin_t(blk.BMSA.pe_proj)
-        w.qkv_w, w.qkv_b = blob.lin(blk.BMSA.qkv)
-        w.proj_w, w.proj_b = blob.lin(blk.BMSA.proj)
-        w.w1_w, w.w1_b = blob.lin(blk.swiglu.w1)
-        w.w2_w, w.w2_b = blob.lin(blk.swiglu.w2)
-        w.w3_w, w.w3_b = blob.lin(blk.swiglu.w3)
+        # small fp32 parameters, contiguous: the kernel copies this group to LDS in one go
+        w.norm1 = blob.add(f(blk.norm1.weight))
+        w.norm2 = blob.add(f(blk.norm2.weight))
+        w.pe_w = blob.add(f(blk.BMSA.pe_proj.weight).t().contiguous())  # [d][c]
+        w.pe_b = blob.add(f(blk.BMSA.pe_proj.bias))
+        w.qkv_b = blob.add(f(blk.BMSA.qkv.bias))
+        w.proj_b = blob.add(f(blk.BMSA.proj.bias))
+        w.w1_b = blob.add(f(blk.swiglu.w1.bias))
+        w.w2_b = blob.add(f(blk.swiglu.w2.bias))
+        w.w3_b = blob.add(f(blk.swiglu.w3.bias))
+        w.small_off, w.small_len = blob.end_group(w.norm1)
+        w.qkv_w = blob.planes(blk.BMSA.qkv)
+        w.proj_w = blob.planes(blk.BMSA.proj)
+        w.w1_w = blob.planes(blk.swiglu.w1)
+        w.w2_w = blob.planes(blk.swiglu.w2)
+        w.w3_w = blob.planes(blk.swiglu.w3)
 
 
 def _fill_resample(dst, mod, blob):
     dst.stride = mod.stride
-    dst.w, dst.b = blob.lin(mod.proj)
     bn = mod.norm
     scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+    dst.b = blob.add(mod.proj.bias.detach().float())
     dst.bn_scale = blob.add(scale)
     dst.bn_shift = blob.add(bn.bias.detach().float() - bn.running_mean.float() * scale)
+    dst.small_off, dst.small_len = blob.end_group(dst.b)
+    dst.w = blob.planes(mod.proj)
 
 
 def pack_erwin(erwin):

@@ -74,8 +74,15 @@ struct Lds {
     char* ia;    // split image of a width-c Linear input
     char* wide;  // qkv fp32 [n][3c+4] | split image of hidden / pooling rows
     float* rel;  // [n][d]
+    float* par;  // the current block's / resample's small fp32 parameters
     int* ident;
 };
+
+// copy `len` floats (16-B aligned, multiple of 4) of small parameters into LDS
+__device__ __forceinline__ void stage_params(float* dst, const float* __restrict__ src, int len) {
+    for (int i = threadIdx.x * 4; i < len; i += blockDim.x * 4)
+        *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(src + i);
+}
 
 __device__ __forceinline__ f32x4 mfma3(u32x4 ah, u32x4 al, u32x4 bh, u32x4 bl, f32x4 c) {
     const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah), a_l = __builtin_bit_cast(bf16x8, al);
@@ -102,30 +109,30 @@ __device__ __forceinline__ void linear_mfma(const Img x, int n, int K,
     const int items = my_tiles * nks;
     if (items == 0) return;
 
-    u32x4 wah, wal, wbh = {0, 0, 0, 0}, wbl = {0, 0, 0, 0};  // weights of the prefetched item
-    auto fetch = [&](int it) {
+    // weights of the two items in flight behind the one being multiplied
+    u32x4 w0[4], w1[4];
+    auto fetch = [&](int it, u32x4 (&wv)[4]) {
         const int tile = wave + nwaves * (it / nks), ks = it % nks;
         const int ot = tile % nto;
         const size_t off = (size_t)min(ot * 16 + l15, O - 1) * Kp + 32 * ks + 8 * kq;
-        wah = *reinterpret_cast<const u32x4*>(Wa + off);
-        wal = *reinterpret_cast<const u32x4*>(Wa + plane + off);
+        wv[0] = *reinterpret_cast<const u32x4*>(Wa + off);
+        wv[1] = *reinterpret_cast<const u32x4*>(Wa + plane + off);
         if (NMAT == 2) {
-            wbh = *reinterpret_cast<const u32x4*>(Wb + off);
-            wbl = *reinterpret_cast<const u32x4*>(Wb + plane + off);
+            wv[2] = *reinterpret_cast<const u32x4*>(Wb + off);
+            wv[3] = *reinterpret_cast<const u32x4*>(Wb + plane + off);
         }
     };
-    fetch(0);
+    fetch(0, w0);
+    if (items > 1) fetch(1, w1);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    for (int it = 0; it < items; ++it) {
+    auto step = [&](int it, const u32x4 (&wv)[4]) {
         const int tile = wave + nwaves * (it / nks), ks = it % nks;
         const int tt = tile / nto, ot = tile - tt * nto;
-        const u32x4 cah = wah, cal = wal, cbh = wbh, cbl = wbl;
-        if (it + 1 < items) fetch(it + 1);
         const char* xr = x.base + min(tt * 16 + l15, n - 1) * x.S + (32 * ks + 8 * kq) * 2;
         const u32x4 xh = *reinterpret_cast<const u32x4*>(xr);
         const u32x4 xl = *reinterpret_cast<const u32x4*>(xr + x.plane);
-        acc0 = mfma3(xh, xl, cah, cal, acc0);
-        if (NMAT == 2) acc1 = mfma3(xh, xl, cbh, cbl, acc1);
+        acc0 = mfma3(xh, xl, wv[0], wv[1], acc0);
+        if (NMAT == 2) acc1 = mfma3(xh, xl, wv[2], wv[3], acc1);
         if (ks == nks - 1) {
             const int o = ot * 16 + l15;
             if (o < O) {
@@ -138,14 +145,23 @@ __device__ __forceinline__ void linear_mfma(const Img x, int n, int K,
             acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
             acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    };
+    for (int it = 0; it < items; it += 2) {  // two named register sets, statically indexed
+        u32x4 c0[4] = {w0[0], w0[1], w0[2], w0[3]};
+        if (it + 2 < items) fetch(it + 2, w0);
+        step(it, c0);
+        if (it + 1 < items) {
+            u32x4 c1[4] = {w1[0], w1[1], w1[2], w1[3]};
+            if (it + 3 < items) fetch(it + 3, w1);
+            step(it + 1, c1);
+        }
     }
 }
 
 // ia[t][:] = split( RMSNorm(X[t][:]) * w  [+ pe_b + rel[t] . pe_w] ); 4 threads per token row.
 // nn.RMSNorm(eps=None): eps = finfo(float32).eps (layers.py:25-26); PE: attention.py:59-61.
-__device__ void norm_rows(const float* X, int ldx, int n, int c, const float* __restrict__ w,
-                          const float* rel, int d, const float* __restrict__ pe_w,
-                          const float* __restrict__ pe_b, const Img out) {
+__device__ void norm_rows(const float* X, int ldx, int n, int c, const float* w, const float* rel,
+                          int d, const float* pe_w, const float* pe_b, const Img out) {
     const int sub = threadIdx.x & 3, cp = round32(c);
     for (int t = threadIdx.x >> 2; t < n; t += (blockDim.x >> 2)) {
         const float* xr = X + t * ldx;
@@ -169,8 +185,23 @@ __device__ void norm_rows(const float* X, int ldx, int n, int c, const float* __
     }
 }
 
-// rel[tok] = P[tok] - mean over its ball (attention.py:35-40); ball b = places [b*ball, ..)
+// rel[tok] = P[tok] - mean over its ball (attention.py:35-40); ball b = places [b*ball, ..).
+// One thread per (dimension, place): a ball's places are `ball` consecutive lanes, so for the
+// power-of-two ball sizes (<= 64) the ball sum is a segmented xor-butterfly.
 __device__ void ball_rel_pos(const float* P, int n, int d, int ball, const int* perm, float* rel) {
+    if (ball <= 64 && (ball & (ball - 1)) == 0) {
+        const int total = (n * d + 63) & ~63;  // whole waves: every lane takes part in the shuffles
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            const int j = i / n, p = i - j * n;
+            const bool ok = j < d;
+            const int tok = ok ? perm[p] : 0;
+            const float v = ok ? P[tok * d + j] : 0.f;
+            float sum = v;
+            for (int off = 1; off < ball; off <<= 1) sum += __shfl_xor(sum, off);
+            if (ok) rel[tok * d + j] = v - sum / (float)ball;
+        }
+        return;
+    }
     const int nb = n / ball;
     for (int i = threadIdx.x; i < nb * d; i += blockDim.x) {
         const int b = i / d, j = i % d;
@@ -191,6 +222,7 @@ __device__ void ball_rel_pos(const float* P, int n, int d, int ball, const int* 
 template <int HD>
 __device__ void ball_attention(const float* qkv, int ldq, int n, int c, int heads, int ball,
                                const int* perm, const Img out) {
+    constexpr int KC = 8;  // keys per step: 8 independent score chains, one rescale per step
     const float scale = 1.0f / sqrtf((float)HD);
     for (int i = threadIdx.x; i < n * heads; i += blockDim.x) {
         const int place = i / heads, h = i % heads;
@@ -202,18 +234,36 @@ __device__ void ball_attention(const float* qkv, int ldq, int n, int c, int head
             acc[e] = 0.f;
         }
         float m = -INFINITY, l = 0.f;
-        for (int p = 0; p < ball; ++p) {
-            const float* kr = qkv + perm[b0 + p] * ldq + c + h * HD;
-            float s = 0.f;
+        for (int p0 = 0; p0 < ball; p0 += KC) {
+            const float* kr[KC];
+            float sc[KC];
+            float mx = m;
 #pragma unroll
-            for (int e = 0; e < HD; ++e) s = fmaf(q[e], kr[e], s);
-            const float mn = fmaxf(m, s);
-            const float a = __expf(m - mn), pr = __expf(s - mn);
-            l = l * a + pr;
-            const float* vr = kr + c;
+            for (int u = 0; u < KC; ++u) {
+                const int p = min(p0 + u, ball - 1);
+                kr[u] = qkv + perm[b0 + p] * ldq + c + h * HD;
+            }
 #pragma unroll
-            for (int e = 0; e < HD; ++e) acc[e] = fmaf(pr, vr[e], acc[e] * a);
-            m = mn;
+            for (int u = 0; u < KC; ++u) {
+                float sv = 0.f;
+#pragma unroll
+                for (int e = 0; e < HD; ++e) sv = fmaf(q[e], kr[u][e], sv);
+                sc[u] = (p0 + u < ball) ? sv : -INFINITY;
+                mx = fmaxf(mx, sc[u]);
+            }
+            const float a = __expf(m - mx);  // m = -inf on the first step -> 0
+            l *= a;
+#pragma unroll
+            for (int e = 0; e < HD; ++e) acc[e] *= a;
+#pragma unroll
+            for (int u = 0; u < KC; ++u) {
+                const float pr = __expf(sc[u] - mx);
+                l += pr;
+                const float* vr = kr[u] + c;
+#pragma unroll
+                for (int e = 0; e < HD; ++e) acc[e] = fmaf(pr, vr[e], acc[e]);
+            }
+            m = mx;
         }
         const float inv = 1.0f / l;
 #pragma unroll
@@ -247,16 +297,20 @@ __device__ void erwin_block(const Lds& s, int lvl, const haet_erwin_layer& L,
     const int ldq = 3 * c + kPad;
     const Img ia = {s.ia, img_stride(c), n * img_stride(c)};
     const Img ih = {s.wide, img_stride(hid), n * img_stride(hid)};
-    // x~ = RMSNorm(x) + pe_proj(pos - ball centre)            (attention.py:59-61)
+    // norm weights, positional projection and every bias of this block: one coalesced copy to LDS
+    // (they are re-read per token / per tile; from global each use is a dependent L2/HBM trip)
+    const float* par = s.par - w.small_off;  // par + <blob offset> addresses the LDS copy
     STAMP(16);
+    stage_params(s.par, W + w.small_off, w.small_len);
+    // x~ = RMSNorm(x) + pe_proj(pos - ball centre)            (attention.py:59-61)
     ball_rel_pos(s.P[lvl], n, d, L.ball, perm, s.rel);
     __syncthreads();
     STAMP(17);
-    norm_rows(X, ld, n, c, W + w.norm1, s.rel, d, W + w.pe_w, W + w.pe_b, ia);
+    norm_rows(X, ld, n, c, par + w.norm1, s.rel, d, par + w.pe_w, par + w.pe_b, ia);
     __syncthreads();
     STAMP(18);
     {
-        const float* qb = W + w.qkv_b;
+        const float* qb = par + w.qkv_b;
         float* Q = reinterpret_cast<float*>(s.wide);
         linear_mfma<1>(ia, n, c, wptr(W, w.qkv_w), nullptr, 3 * c,
                        [=](int t, int o, float v, float) { Q[t * ldq + o] = v + qb[o]; });
@@ -268,14 +322,14 @@ __device__ void erwin_block(const Lds& s, int lvl, const haet_erwin_layer& L,
     __syncthreads();
     STAMP(20);
     {
-        const float* pb = W + w.proj_b;
+        const float* pb = par + w.proj_b;
         linear_mfma<1>(ia, n, c, wptr(W, w.proj_w), nullptr, c,
                        [=](int t, int o, float v, float) { X[t * ld + o] += v + pb[o]; });
     }
     __syncthreads();
     STAMP(21);
     // x += W3( W2 x^ * silu(W1 x^) ),  x^ = RMSNorm(x)          (mlp.py:17-18)
-    norm_rows(X, ld, n, c, W + w.norm2, nullptr, 0, nullptr, nullptr, ia);
+    norm_rows(X, ld, n, c, par + w.norm2, nullptr, 0, nullptr, nullptr, ia);
     {
         const int padk = round32(hid) - hid;  // zero the k padding of the hidden image
         for (int i = threadIdx.x; i < n * padk; i += blockDim.x) ih.put(i / padk, hid + i % padk, 0.f);
@@ -283,8 +337,8 @@ __device__ void erwin_block(const Lds& s, int lvl, const haet_erwin_layer& L,
     __syncthreads();
     STAMP(22);
     {
-        const float* b1 = W + w.w1_b;
-        const float* b2 = W + w.w2_b;
+        const float* b1 = par + w.w1_b;
+        const float* b2 = par + w.w2_b;
         linear_mfma<2>(ia, n, c, wptr(W, w.w1_w), wptr(W, w.w2_w), hid, [=](int t, int o, float u, float v) {
             const float g = u + b1[o];
             ih.put(t, o, (v + b2[o]) * (g / (1.0f + __expf(-g))));
@@ -293,7 +347,7 @@ __device__ void erwin_block(const Lds& s, int lvl, const haet_erwin_layer& L,
     __syncthreads();
     STAMP(23);
     {
-        const float* b3 = W + w.w3_b;
+        const float* b3 = par + w.w3_b;
         linear_mfma<1>(ih, n, hid, wptr(W, w.w3_w), nullptr, c,
                        [=](int t, int o, float v, float) { X[t * ld + o] += v + b3[o]; });
     }
@@ -307,6 +361,20 @@ __device__ void run_layer(const Lds& s, int lvl, const haet_erwin_layer& L,
         const bool rot = rotate && L.depth > 1 && (j & 1);  // layers.py:66,75-89
         erwin_block(s, lvl, L, L.blocks[j], W, d, rot ? s.rot[lvl] : s.ident);
     }
+}
+
+// largest small-parameter group (floats, multiple of 4)
+__host__ __device__ inline int erwin_max_small(const haet_erwin_desc& D) {
+    int m = 0;
+    for (int l = 0; l < D.n_levels; ++l) {
+        for (int j = 0; j < D.enc[l].depth; ++j) m = m > D.enc[l].blocks[j].small_len ? m : D.enc[l].blocks[j].small_len;
+        if (l < D.n_levels - 1) {
+            for (int j = 0; j < D.dec[l].depth; ++j) m = m > D.dec[l].blocks[j].small_len ? m : D.dec[l].blocks[j].small_len;
+            m = m > D.pool[l].small_len ? m : D.pool[l].small_len;
+            m = m > D.unpool[l].small_len ? m : D.unpool[l].small_len;
+        }
+    }
+    return (m + 3) & ~3;
 }
 
 // LDS carve-up shared by host (sizing) and device; returns the total in floats
@@ -337,7 +405,7 @@ __host__ __device__ inline int erwin_layout(const haet_erwin_desc& D, int Mp, in
     }
     *ia_bytes = (ia + 15) & ~15;
     *wide_bytes = (wide + 15) & ~15;
-    tot += (*ia_bytes + *wide_bytes) / 4 + ((Mp * d + 3) & ~3) + idx + Mp;
+    tot += (*ia_bytes + *wide_bytes) / 4 + ((Mp * d + 3) & ~3) + erwin_max_small(D) + idx + Mp;
     return tot;
 }
 
@@ -345,22 +413,10 @@ __host__ __device__ inline int erwin_layout(const haet_erwin_desc& D, int Mp, in
 __global__ __launch_bounds__(512) void erwin_kernel(
     const float* __restrict__ tokens, const float* __restrict__ pos,
     const int32_t* __restrict__ tree_idx, const uint8_t* __restrict__ tree_mask,
-    const int32_t* __restrict__ rot, const float* __restrict__ W, int w_chunks, int M, int Mp,
+    const int32_t* __restrict__ rot, const float* __restrict__ W, int M, int Mp,
     float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     STAMP(0);
-    // Warm this XCD's L2 with the whole weight blob (~0.5 MB) before anything depends on it: the
-    // 7 GB the streaming passes move between two forwards evict it, and the Linear chain below
-    // is a sequence of ~70 dependent weight fetches per cloud (2-3 us each from HBM, ~0.6 us
-    // from L2).  The loads are issued back to back and only consumed at the very end.
-    unsigned warm = 0;
-    {
-        const u32x4* w16 = reinterpret_cast<const u32x4*>(W);
-        for (int i = threadIdx.x; i < w_chunks; i += blockDim.x) {
-            const u32x4 v = w16[i];  // plain (cached) load: the point is to leave the line in L2
-            warm ^= v[0] ^ v[1] ^ v[2] ^ v[3];
-        }
-    }
     STAMP(1);
     const haet_erwin_desc& D = *reinterpret_cast<const haet_erwin_desc*>(W);
     const int cloud = blockIdx.x, n_clouds = gridDim.x, d = D.d, nl = D.n_levels;
@@ -387,6 +443,8 @@ __global__ __launch_bounds__(512) void erwin_kernel(
         p += wide_bytes / 4;
         s.rel = p;
         p += ((Mp * d + 3) & ~3);
+        s.par = p;
+        p += erwin_max_small(D);
         int* q = reinterpret_cast<int*>(p);
         for (int l = 0; l < nl; ++l) {
             s.rot[l] = q;
@@ -423,6 +481,7 @@ __global__ __launch_bounds__(512) void erwin_kernel(
         const haet_erwin_resample& R = D.pool[l];
         const int st = R.stride, n2 = s.n[l + 1], c = D.enc[l].c, K = st * c + st * d;
         const Img rows = {s.wide, img_stride(K), n2 * img_stride(K)};
+        stage_params(s.par, W + R.small_off, R.small_len);
         for (int i = threadIdx.x; i < n2 * d; i += blockDim.x) {
             const int p = i / d, j = i % d;
             float sum = 0.f;
@@ -446,9 +505,10 @@ __global__ __launch_bounds__(512) void erwin_kernel(
         {
             float* Y = s.X[l + 1];
             const int ldy = s.ld[l + 1];
-            const float* b = W + R.b;
-            const float* sc = W + R.bn_scale;
-            const float* sh = W + R.bn_shift;
+            const float* par = s.par - R.small_off;
+            const float* b = par + R.b;
+            const float* sc = par + R.bn_scale;
+            const float* sh = par + R.bn_shift;
             linear_mfma<1>(rows, n2, K, wptr(W, R.w), nullptr, D.enc[l + 1].c,
                            [=](int t, int o, float v, float) { Y[t * ldy + o] = (v + b[o]) * sc[o] + sh[o]; });
         }
@@ -463,6 +523,7 @@ __global__ __launch_bounds__(512) void erwin_kernel(
         const int st = R.stride, n2 = s.n[l + 1], c2 = D.enc[l + 1].c, c = D.enc[l].c;
         const int K = c2 + st * d, Kp = round32(K);
         const Img rows = {s.wide, img_stride(K), n2 * img_stride(K)};
+        stage_params(s.par, W + R.small_off, R.small_len);
         for (int i = threadIdx.x; i < n2 * Kp; i += blockDim.x) {
             const int p = i / Kp, k = i % Kp;
             float v = 0.f;
@@ -478,9 +539,10 @@ __global__ __launch_bounds__(512) void erwin_kernel(
         {
             float* Y = s.X[l];
             const int ldy = s.ld[l];
-            const float* b = W + R.b;
-            const float* sc = W + R.bn_scale;
-            const float* sh = W + R.bn_shift;
+            const float* par = s.par - R.small_off;
+            const float* b = par + R.b;
+            const float* sc = par + R.bn_scale;
+            const float* sh = par + R.bn_shift;
             linear_mfma<1>(rows, n2, K, wptr(W, R.w), nullptr, st * c, [=](int t, int o, float v, float) {
                 const int q = o / c, ch = o % c;  // 'n (m d) -> (n m) d'
                 float* y = Y + (t * st + q) * ldy + ch;
@@ -499,7 +561,6 @@ __global__ __launch_bounds__(512) void erwin_kernel(
         if (tree_mask[g]) out[(size_t)tree_idx[g] * c0 + ch] = s.X[0][slot * s.ld[0] + ch];
     }
     STAMP(12);
-    if (warm == 0x9E3779B9u && M < 0) out[0] = 0.f;  // keeps the warm-up loads alive; never taken
 }
 
 static int erwin_validate(const haet_erwin_desc* D, int Mp) {
@@ -523,6 +584,9 @@ static int erwin_validate(const haet_erwin_desc* D, int Mp) {
             if (L.ball < 1 || n % L.ball)
                 return fail(HAET_E_ARG, "erwin: ball size %d does not divide %d tokens", L.ball, n);
             if (L.hidden < 1) return fail(HAET_E_ARG, "erwin: hidden=%d", L.hidden);
+            for (int j = 0; j < L.depth; ++j)
+                if (L.blocks[j].small_len < 1 || (L.blocks[j].small_len & 3) || (L.blocks[j].small_off & 3))
+                    return fail(HAET_E_ARG, "erwin: block small-parameter group not packed (pack.py)");
         }
         if (l < D->n_levels - 1) {
             if (D->dec[l].c != D->enc[l].c) return fail(HAET_E_ARG, "erwin: decoder width mismatch");
@@ -577,6 +641,6 @@ extern "C" int haet_erwin_fwd(const float* tokens, const float* pos, const int32
         attr_set = bytes;
     }
     hipLaunchKernelGGL(erwin_kernel, dim3(n_clouds), dim3(512), bytes, as_stream(stream), tokens,
-                       pos, tree_idx, tree_mask, rot, weights, (int)(weight_floats / 4), M, Mp, out);
+                       pos, tree_idx, tree_mask, rot, weights, M, Mp, out);
     return check_launch("erwin_kernel");
 }

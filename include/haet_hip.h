@@ -149,6 +149,9 @@ typedef struct {
     int32_t proj_w, proj_b;          /* [c][c~], [c] */
     int32_t w1_w, w1_b, w2_w, w2_b;  /* [hidden][c~], [hidden] */
     int32_t w3_w, w3_b;              /* [c][hidden~], [c] */
+    /* norm1, norm2, pe_w, pe_b and the five biases are packed contiguously (each 16-B aligned) in
+     * blob[small_off, small_off + small_len): the kernel copies that group to LDS per block */
+    int32_t small_off, small_len;
 } haet_erwin_block_w;
 
 typedef struct {
@@ -160,6 +163,7 @@ typedef struct {
     int32_t stride;
     int32_t w, b;               /* Linear, [out][K~] / [out] */
     int32_t bn_scale, bn_shift; /* eval BatchNorm as y*scale+shift, [c_out] */
+    int32_t small_off, small_len; /* b | bn_scale | bn_shift, contiguous like above */
 } haet_erwin_resample;
 
 typedef struct {

@@ -47,7 +47,7 @@ def test_binding_loads_and_reports_errors_without_gpu():
 def test_erwin_desc_struct_matches_header_size():
     from haet_amd import _lib
 
-    # 4 ints + 8 layers of (5 + 4*14) ints + 8 resamples of 5 ints
-    assert ctypes.sizeof(_lib.ErwinDesc) == 4 * (4 + 8 * (5 + 4 * 14) + 8 * 5)
+    # 4 ints + 8 layers of (5 + 4*16) ints + 8 resamples of 7 ints
+    assert ctypes.sizeof(_lib.ErwinDesc) == 4 * (4 + 8 * (5 + 4 * 16) + 8 * 7)
     d = _lib.ErwinDesc()
     assert _lib.load().haet_erwin_lds_bytes(ctypes.byref(d), 64) == 0  # invalid desc -> 0
