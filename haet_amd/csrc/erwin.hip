@@ -93,13 +93,30 @@ __device__ __forceinline__ f32x4 mfma3(u32x4 ah, u32x4 al, u32x4 bh, u32x4 bl, f
     return c;
 }
 
+// CODE SIZE IS LATENCY HERE.  The kernel runs once per forward with cold instruction caches
+// (7 GB of data stream through L2 between two forwards), and measured ~3 cycles per byte of
+// DISTINCT code executed (stamped build: 159 KB fully inlined = 504k cycles, whatever the
+// arithmetic).  So the stage is built from a few NON-INLINED routines that every block / level
+// re-executes from the instruction cache: one Linear core (runtime epilogue mode), one norm,
+// one ball-centre, one attention per head_dim, one block body, one pool, one unpool, driven by
+// an op list.
+enum EpiMode {
+    EP_QKV = 0,     // dst[t][o]  = acc + b0[o]                      (fp32 rows, ld = ldd)
+    EP_RESID = 1,   // dst[t][o] += acc + b0[o]
+    EP_SWIGLU = 2,  // img[t][o]  = (acc1 + b1[o]) * silu(acc0 + b0[o])   (two matrices)
+    EP_BN = 3,      // dst[t][o]  = (acc + b0[o]) * sc[o] + sh[o]
+    EP_UNPOOL = 4,  // dst[t*st + o/aux][o%aux] = (old + acc + b0[o]) * sc[o%aux] + sh[o%aux]
+};
+
 // Y[t][o] = sum_k X[t][k] W[o][k].  X: split image (n rows, K~32 columns, pad columns zero).
-// W: global bf16 planes [O][Kp] (hi at Wa, lo at Wa + O*Kp); NMAT = 2 adds a second matrix
-// Wb on the same activations (SwiGLU w1 / w2).  epi(t, o, acc_a, acc_b) finishes the element.
-template <int NMAT, typename Epi>
-__device__ __forceinline__ void linear_mfma(const Img x, int n, int K,
-                                            const unsigned short* __restrict__ Wa,
-                                            const unsigned short* __restrict__ Wb, int O, Epi epi) {
+// W: global bf16 planes [O][Kp] (hi at Wa, lo at Wa + O*Kp); EP_SWIGLU adds a second matrix Wb on
+// the same activations.  Two items (tile, k-step) of weights are in flight behind the one being
+// multiplied.
+__device__ __attribute__((noinline)) void linear_core(
+    const char* xbase, int xS, int xplane, int n, int K, const unsigned short* __restrict__ Wa,
+    const unsigned short* __restrict__ Wb, int O, int mode, float* dst, int ldd, const float* b0,
+    const float* b1, const float* sc, const float* sh, char* dimg, int dS, int dplane, int aux,
+    int st) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const int Kp = round32(K), nks = Kp >> 5;
@@ -107,9 +124,9 @@ __device__ __forceinline__ void linear_mfma(const Img x, int n, int K,
     const size_t plane = (size_t)O * Kp;
     const int my_tiles = ntiles > wave ? (ntiles - wave + nwaves - 1) / nwaves : 0;
     const int items = my_tiles * nks;
+    const bool dual = mode == EP_SWIGLU;
     if (items == 0) return;
 
-    // weights of the two items in flight behind the one being multiplied
     u32x4 w0[4], w1[4];
     auto fetch = [&](int it, u32x4 (&wv)[4]) {
         const int tile = wave + nwaves * (it / nks), ks = it % nks;
@@ -117,35 +134,51 @@ __device__ __forceinline__ void linear_mfma(const Img x, int n, int K,
         const size_t off = (size_t)min(ot * 16 + l15, O - 1) * Kp + 32 * ks + 8 * kq;
         wv[0] = *reinterpret_cast<const u32x4*>(Wa + off);
         wv[1] = *reinterpret_cast<const u32x4*>(Wa + plane + off);
-        if (NMAT == 2) {
+        if (dual) {
             wv[2] = *reinterpret_cast<const u32x4*>(Wb + off);
             wv[3] = *reinterpret_cast<const u32x4*>(Wb + plane + off);
         }
     };
-    fetch(0, w0);
-    if (items > 1) fetch(1, w1);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const Img di = {dimg, dS, dplane};
     auto step = [&](int it, const u32x4 (&wv)[4]) {
         const int tile = wave + nwaves * (it / nks), ks = it % nks;
         const int tt = tile / nto, ot = tile - tt * nto;
-        const char* xr = x.base + min(tt * 16 + l15, n - 1) * x.S + (32 * ks + 8 * kq) * 2;
+        const char* xr = xbase + min(tt * 16 + l15, n - 1) * xS + (32 * ks + 8 * kq) * 2;
         const u32x4 xh = *reinterpret_cast<const u32x4*>(xr);
-        const u32x4 xl = *reinterpret_cast<const u32x4*>(xr + x.plane);
+        const u32x4 xl = *reinterpret_cast<const u32x4*>(xr + xplane);
         acc0 = mfma3(xh, xl, wv[0], wv[1], acc0);
-        if (NMAT == 2) acc1 = mfma3(xh, xl, wv[2], wv[3], acc1);
+        if (dual) acc1 = mfma3(xh, xl, wv[2], wv[3], acc1);
         if (ks == nks - 1) {
             const int o = ot * 16 + l15;
             if (o < O) {
-#pragma unroll
+                const float bo = b0[o];
                 for (int r = 0; r < 4; ++r) {
                     const int t = tt * 16 + 4 * kq + r;
-                    if (t < n) epi(t, o, acc0[r], acc1[r]);
+                    if (t < n) {
+                        const float v = acc0[r] + bo;
+                        if (mode == EP_QKV) {
+                            dst[t * ldd + o] = v;
+                        } else if (mode == EP_RESID) {
+                            dst[t * ldd + o] += v;
+                        } else if (mode == EP_SWIGLU) {
+                            di.put(t, o, (acc1[r] + b1[o]) * (v / (1.0f + __expf(-v))));
+                        } else if (mode == EP_BN) {
+                            dst[t * ldd + o] = v * sc[o] + sh[o];
+                        } else {
+                            const int q = o / aux, ch = o - q * aux;  // 'n (m d) -> (n m) d'
+                            float* y = dst + (t * st + q) * ldd + ch;
+                            *y = (*y + v) * sc[ch] + sh[ch];
+                        }
+                    }
                 }
             }
             acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
             acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
+    fetch(0, w0);
+    if (items > 1) fetch(1, w1);
     for (int it = 0; it < items; it += 2) {  // two named register sets, statically indexed
         u32x4 c0[4] = {w0[0], w0[1], w0[2], w0[3]};
         if (it + 2 < items) fetch(it + 2, w0);
@@ -160,7 +193,7 @@ __device__ __forceinline__ void linear_mfma(const Img x, int n, int K,
 
 // ia[t][:] = split( RMSNorm(X[t][:]) * w  [+ pe_b + rel[t] . pe_w] ); 4 threads per token row.
 // nn.RMSNorm(eps=None): eps = finfo(float32).eps (layers.py:25-26); PE: attention.py:59-61.
-__device__ void norm_rows(const float* X, int ldx, int n, int c, const float* w, const float* rel,
+__device__ __attribute__((noinline)) void norm_rows(const float* X, int ldx, int n, int c, const float* w, const float* rel,
                           int d, const float* pe_w, const float* pe_b, const Img out) {
     const int sub = threadIdx.x & 3, cp = round32(c);
     for (int t = threadIdx.x >> 2; t < n; t += (blockDim.x >> 2)) {
@@ -188,7 +221,7 @@ __device__ void norm_rows(const float* X, int ldx, int n, int c, const float* w,
 // rel[tok] = P[tok] - mean over its ball (attention.py:35-40); ball b = places [b*ball, ..).
 // One thread per (dimension, place): a ball's places are `ball` consecutive lanes, so for the
 // power-of-two ball sizes (<= 64) the ball sum is a segmented xor-butterfly.
-__device__ void ball_rel_pos(const float* P, int n, int d, int ball, const int* perm, float* rel) {
+__device__ __attribute__((noinline)) void ball_rel_pos(const float* P, int n, int d, int ball, const int* perm, float* rel) {
     if (ball <= 64 && (ball & (ball - 1)) == 0) {
         const int total = (n * d + 63) & ~63;  // whole waves: every lane takes part in the shuffles
         for (int i = threadIdx.x; i < total; i += blockDim.x) {
@@ -220,7 +253,7 @@ __device__ void ball_rel_pos(const float* P, int n, int d, int ball, const int* 
 // [q(h,hd) | k(h,hd) | v(h,hd)] ("(three h d)").  The output goes straight into the split
 // image that feeds the proj Linear.
 template <int HD>
-__device__ void ball_attention(const float* qkv, int ldq, int n, int c, int heads, int ball,
+__device__ __attribute__((noinline)) void ball_attention(const float* qkv, int ldq, int n, int c, int heads, int ball,
                                const int* perm, const Img out) {
     constexpr int KC = 8;  // keys per step: 8 independent score chains, one rescale per step
     const float scale = 1.0f / sqrtf((float)HD);
@@ -271,7 +304,7 @@ __device__ void ball_attention(const float* qkv, int ldq, int n, int c, int head
     }
 }
 
-__device__ void attention_dispatch(int hd, const float* qkv, int ldq, int n, int c, int heads,
+__device__ __attribute__((noinline)) void attention_dispatch(int hd, const float* qkv, int ldq, int n, int c, int heads,
                                    int ball, const int* perm, const Img out) {
     switch (hd) {
         case 1: ball_attention<1>(qkv, ldq, n, c, heads, ball, perm, out); break;
@@ -289,7 +322,7 @@ __device__ __forceinline__ const unsigned short* wptr(const float* W, int off) {
 }
 
 // ErwinTransformerBlock (layers.py:30-32) on the tokens of one level, in place
-__device__ void erwin_block(const Lds& s, int lvl, const haet_erwin_layer& L,
+__device__ __attribute__((noinline)) void erwin_block(const Lds& s, int lvl, const haet_erwin_layer& L,
                             const haet_erwin_block_w& w, const float* __restrict__ W, int d,
                             const int* perm) {
     float* X = s.X[lvl];
@@ -309,23 +342,17 @@ __device__ void erwin_block(const Lds& s, int lvl, const haet_erwin_layer& L,
     norm_rows(X, ld, n, c, par + w.norm1, s.rel, d, par + w.pe_w, par + w.pe_b, ia);
     __syncthreads();
     STAMP(18);
-    {
-        const float* qb = par + w.qkv_b;
-        float* Q = reinterpret_cast<float*>(s.wide);
-        linear_mfma<1>(ia, n, c, wptr(W, w.qkv_w), nullptr, 3 * c,
-                       [=](int t, int o, float v, float) { Q[t * ldq + o] = v + qb[o]; });
-    }
+    linear_core(ia.base, ia.S, ia.plane, n, c, wptr(W, w.qkv_w), nullptr, 3 * c, EP_QKV,
+                reinterpret_cast<float*>(s.wide), ldq, par + w.qkv_b, nullptr, nullptr, nullptr, nullptr,
+                0, 0, 0, 0);
     __syncthreads();
     STAMP(19);
     attention_dispatch(c / L.heads, reinterpret_cast<const float*>(s.wide), ldq, n, c, L.heads, L.ball,
                        perm, ia);
     __syncthreads();
     STAMP(20);
-    {
-        const float* pb = par + w.proj_b;
-        linear_mfma<1>(ia, n, c, wptr(W, w.proj_w), nullptr, c,
-                       [=](int t, int o, float v, float) { X[t * ld + o] += v + pb[o]; });
-    }
+    linear_core(ia.base, ia.S, ia.plane, n, c, wptr(W, w.proj_w), nullptr, c, EP_RESID, X, ld,
+                par + w.proj_b, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0);
     __syncthreads();
     STAMP(21);
     // x += W3( W2 x^ * silu(W1 x^) ),  x^ = RMSNorm(x)          (mlp.py:17-18)
@@ -336,31 +363,74 @@ __device__ void erwin_block(const Lds& s, int lvl, const haet_erwin_layer& L,
     }
     __syncthreads();
     STAMP(22);
-    {
-        const float* b1 = par + w.w1_b;
-        const float* b2 = par + w.w2_b;
-        linear_mfma<2>(ia, n, c, wptr(W, w.w1_w), wptr(W, w.w2_w), hid, [=](int t, int o, float u, float v) {
-            const float g = u + b1[o];
-            ih.put(t, o, (v + b2[o]) * (g / (1.0f + __expf(-g))));
-        });
-    }
+    linear_core(ia.base, ia.S, ia.plane, n, c, wptr(W, w.w1_w), wptr(W, w.w2_w), hid, EP_SWIGLU, nullptr,
+                0, par + w.w1_b, par + w.w2_b, nullptr, nullptr, ih.base, ih.S, ih.plane, 0, 0);
     __syncthreads();
     STAMP(23);
-    {
-        const float* b3 = par + w.w3_b;
-        linear_mfma<1>(ih, n, hid, wptr(W, w.w3_w), nullptr, c,
-                       [=](int t, int o, float v, float) { X[t * ld + o] += v + b3[o]; });
-    }
+    linear_core(ih.base, ih.S, ih.plane, n, hid, wptr(W, w.w3_w), nullptr, c, EP_RESID, X, ld,
+                par + w.w3_b, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0);
     __syncthreads();
     STAMP(24);
 }
 
-__device__ void run_layer(const Lds& s, int lvl, const haet_erwin_layer& L,
-                          const float* __restrict__ W, int d, int rotate) {
-    for (int j = 0; j < L.depth; ++j) {
-        const bool rot = rotate && L.depth > 1 && (j & 1);  // layers.py:66,75-89
-        erwin_block(s, lvl, L, L.blocks[j], W, d, rot ? s.rot[lvl] : s.ident);
+// BallPooling (pooling.py:25-40): level l -> l+1
+__device__ __attribute__((noinline)) void erwin_pool(const Lds& s, int l, const haet_erwin_desc& D,
+                                                     const float* __restrict__ W) {
+    const haet_erwin_resample& R = D.pool[l];
+    const int d = D.d, st = R.stride, n2 = s.n[l + 1], c = D.enc[l].c, K = st * c + st * d;
+    const Img rows = {s.wide, img_stride(K), n2 * img_stride(K)};
+    stage_params(s.par, W + R.small_off, R.small_len);
+    for (int i = threadIdx.x; i < n2 * d; i += blockDim.x) {
+        const int p = i / d, j = i % d;
+        float sum = 0.f;
+        for (int q = 0; q < st; ++q) sum += s.P[l][(p * st + q) * d + j];
+        s.P[l + 1][i] = sum / (float)st;
     }
+    __syncthreads();
+    const int Kp = round32(K);
+    for (int i = threadIdx.x; i < n2 * Kp; i += blockDim.x) {
+        const int p = i / Kp, k = i % Kp;
+        float v = 0.f;
+        if (k < st * c) {
+            v = s.X[l][(p * st + k / c) * s.ld[l] + k % c];
+        } else if (k < K) {
+            const int r = k - st * c, q = r / d, j = r % d;
+            v = s.P[l][(p * st + q) * d + j] - s.P[l + 1][p * d + j];
+        }
+        rows.put(p, k, v);
+    }
+    __syncthreads();
+    const float* par = s.par - R.small_off;
+    linear_core(rows.base, rows.S, rows.plane, n2, K, wptr(W, R.w), nullptr, D.enc[l + 1].c, EP_BN,
+                s.X[l + 1], s.ld[l + 1], par + R.b, nullptr, par + R.bn_scale, par + R.bn_shift, nullptr,
+                0, 0, 0, 0);
+    __syncthreads();
+}
+
+// BallUnpooling (pooling.py:58-72): level l+1 -> l
+__device__ __attribute__((noinline)) void erwin_unpool(const Lds& s, int l, const haet_erwin_desc& D,
+                                                       const float* __restrict__ W) {
+    const haet_erwin_resample& R = D.unpool[l];
+    const int d = D.d, st = R.stride, n2 = s.n[l + 1], c2 = D.enc[l + 1].c, c = D.enc[l].c;
+    const int K = c2 + st * d, Kp = round32(K);
+    const Img rows = {s.wide, img_stride(K), n2 * img_stride(K)};
+    stage_params(s.par, W + R.small_off, R.small_len);
+    for (int i = threadIdx.x; i < n2 * Kp; i += blockDim.x) {
+        const int p = i / Kp, k = i % Kp;
+        float v = 0.f;
+        if (k < c2) {
+            v = s.X[l + 1][p * s.ld[l + 1] + k];
+        } else if (k < K) {
+            const int r = k - c2, q = r / d, j = r % d;
+            v = s.P[l][(p * st + q) * d + j] - s.P[l + 1][p * d + j];
+        }
+        rows.put(p, k, v);
+    }
+    __syncthreads();
+    const float* par = s.par - R.small_off;
+    linear_core(rows.base, rows.S, rows.plane, n2, K, wptr(W, R.w), nullptr, st * c, EP_UNPOOL, s.X[l],
+                s.ld[l], par + R.b, nullptr, par + R.bn_scale, par + R.bn_shift, nullptr, 0, 0, c, st);
+    __syncthreads();
 }
 
 // largest small-parameter group (floats, multiple of 4)
@@ -474,85 +544,42 @@ __global__ __launch_bounds__(512) void erwin_kernel(
     __syncthreads();
     STAMP(2);
 
-    // encoder: blocks then BallPooling (pooling.py:25-40)
-    for (int l = 0; l < nl - 1; ++l) {
-        run_layer(s, l, D.enc[l], W, d, D.rotate);
-        STAMP(3 + l);
-        const haet_erwin_resample& R = D.pool[l];
-        const int st = R.stride, n2 = s.n[l + 1], c = D.enc[l].c, K = st * c + st * d;
-        const Img rows = {s.wide, img_stride(K), n2 * img_stride(K)};
-        stage_params(s.par, W + R.small_off, R.small_len);
-        for (int i = threadIdx.x; i < n2 * d; i += blockDim.x) {
-            const int p = i / d, j = i % d;
-            float sum = 0.f;
-            for (int q = 0; q < st; ++q) sum += s.P[l][(p * st + q) * d + j];
-            s.P[l + 1][i] = sum / (float)st;
+    // Op list (erwin_flash.py:183-192): [blocks_l, pool_l]* , bottleneck blocks, [unpool_l, blocks_l]*.
+    // kind 0 = block (a = level, b = block index | decoder flag << 8), 1 = pool, 2 = unpool.
+    int nops = 0;
+    auto op_at = [&](int want, int& kind, int& a, int& b) {
+        int i = 0;
+        for (int l = 0; l < nl; ++l) {  // encoder + bottleneck
+            for (int j = 0; j < D.enc[l].depth; ++j, ++i)
+                if (i == want) { kind = 0; a = l; b = j; }
+            if (l < nl - 1) { if (i == want) { kind = 1; a = l; b = 0; } ++i; }
         }
-        __syncthreads();
-        const int Kp = round32(K);
-        for (int i = threadIdx.x; i < n2 * Kp; i += blockDim.x) {
-            const int p = i / Kp, k = i % Kp;
-            float v = 0.f;
-            if (k < st * c) {
-                v = s.X[l][(p * st + k / c) * s.ld[l] + k % c];
-            } else if (k < K) {
-                const int r = k - st * c, q = r / d, j = r % d;
-                v = s.P[l][(p * st + q) * d + j] - s.P[l + 1][p * d + j];
-            }
-            rows.put(p, k, v);
+        for (int l = nl - 2; l >= 0; --l) {
+            if (i == want) { kind = 2; a = l; b = 0; }
+            ++i;
+            for (int j = 0; j < D.dec[l].depth; ++j, ++i)
+                if (i == want) { kind = 0; a = l; b = j | 256; }
         }
-        __syncthreads();
-        {
-            float* Y = s.X[l + 1];
-            const int ldy = s.ld[l + 1];
-            const float* par = s.par - R.small_off;
-            const float* b = par + R.b;
-            const float* sc = par + R.bn_scale;
-            const float* sh = par + R.bn_shift;
-            linear_mfma<1>(rows, n2, K, wptr(W, R.w), nullptr, D.enc[l + 1].c,
-                           [=](int t, int o, float v, float) { Y[t * ldy + o] = (v + b[o]) * sc[o] + sh[o]; });
-        }
-        __syncthreads();
+        return i;
+    };
+    {
+        int k, a, b;
+        nops = op_at(-1, k, a, b);
     }
-    STAMP(8);
-    run_layer(s, nl - 1, D.enc[nl - 1], W, d, D.rotate);
-    STAMP(9);
-    // decoder: BallUnpooling (pooling.py:58-72) then blocks
-    for (int l = nl - 2; l >= 0; --l) {
-        const haet_erwin_resample& R = D.unpool[l];
-        const int st = R.stride, n2 = s.n[l + 1], c2 = D.enc[l + 1].c, c = D.enc[l].c;
-        const int K = c2 + st * d, Kp = round32(K);
-        const Img rows = {s.wide, img_stride(K), n2 * img_stride(K)};
-        stage_params(s.par, W + R.small_off, R.small_len);
-        for (int i = threadIdx.x; i < n2 * Kp; i += blockDim.x) {
-            const int p = i / Kp, k = i % Kp;
-            float v = 0.f;
-            if (k < c2) {
-                v = s.X[l + 1][p * s.ld[l + 1] + k];
-            } else if (k < K) {
-                const int r = k - c2, q = r / d, j = r % d;
-                v = s.P[l][(p * st + q) * d + j] - s.P[l + 1][p * d + j];
-            }
-            rows.put(p, k, v);
+    for (int op = 0; op < nops; ++op) {
+        int kind = 0, a = 0, b = 0;
+        op_at(op, kind, a, b);
+        if (kind == 0) {
+            const haet_erwin_layer& L = (b & 256) ? D.dec[a] : D.enc[a];
+            const int j = b & 255;
+            const bool rot = D.rotate && L.depth > 1 && (j & 1);  // layers.py:66,75-89
+            erwin_block(s, a, L, L.blocks[j], W, d, rot ? s.rot[a] : s.ident);
+        } else if (kind == 1) {
+            erwin_pool(s, a, D, W);
+        } else {
+            erwin_unpool(s, a, D, W);
         }
-        __syncthreads();
-        {
-            float* Y = s.X[l];
-            const int ldy = s.ld[l];
-            const float* par = s.par - R.small_off;
-            const float* b = par + R.b;
-            const float* sc = par + R.bn_scale;
-            const float* sh = par + R.bn_shift;
-            linear_mfma<1>(rows, n2, K, wptr(W, R.w), nullptr, st * c, [=](int t, int o, float v, float) {
-                const int q = o / c, ch = o % c;  // 'n (m d) -> (n m) d'
-                float* y = Y + (t * st + q) * ldy + ch;
-                *y = (*y + v + b[o]) * sc[ch] + sh[ch];
-            });
-        }
-        __syncthreads();
-        STAMP(10);
-        run_layer(s, l, D.dec[l], W, d, D.rotate);
-        STAMP(11);
+        STAMP(3 + (op < 9 ? op : 9));
     }
     // node.x[tree_mask][argsort(tree_idx[tree_mask])]  (erwin_flash.py:193)
     for (int i = threadIdx.x; i < Mp * c0; i += blockDim.x) {

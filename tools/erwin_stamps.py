@@ -27,15 +27,16 @@ lib = _lib.load()
 buf = (ctypes.c_ulonglong * 64)()
 assert lib.haet_debug_read_stamps(buf) == 0
 t = list(buf)
-names = {0: "start", 1: "after L2 warm", 2: "after gather", 3: "enc0 blocks done", 8: "pool done",
-         9: "bottleneck done", 10: "unpool done", 11: "dec0 blocks done", 12: "end"}
 clk = (t[12] - t[0]) / max(1, (t[32 + 12] - t[32 + 0])) * 100.0
 print(f"shader clock during the kernel: {clk:.0f} MHz; total {t[12]-t[0]} cycles = {(t[32+12]-t[32])/100.0:.1f} us")
+names = {1: "prologue", 2: "gather to tree order", 3: "enc0 block 0", 4: "enc0 block 1", 5: "pool",
+         6: "bottleneck block 0", 7: "bottleneck block 1", 8: "unpool", 9: "dec0 block 0",
+         10: "dec0 block 1", 12: "scatter out"}
 prev = 0
-for i in (1, 2, 3, 8, 9, 10, 11, 12):
+for i in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12):
     print(f"  {names[i]:22s} +{t[i]-t[prev]:8d} cycles")
     prev = i
 print("last block (dec0 block 1) phases:")
-bn = {17: "rel_pos", 18: "norm1+pe", 19: "qkv", 20: "attention", 21: "proj", 22: "norm2", 23: "w1w2", 24: "w3"}
+bn = {17: "params+rel_pos", 18: "norm1+pe", 19: "qkv", 20: "attention", 21: "proj", 22: "norm2", 23: "w1w2", 24: "w3"}
 for i in range(17, 25):
-    print(f"  {bn[i]:10s} {t[i]-t[i-1]:8d} cycles")
+    print(f"  {bn[i]:14s} {t[i]-t[i-1]:8d} cycles")
