@@ -15,8 +15,8 @@
 // hi*lo + lo*hi, fp32 accumulate): producers write their output already split into bf16
 // hi/lo LDS images, weights are pre-split on the host ([out][in~32] bf16 planes), so a
 // 16-token x 16-output tile step is 2 ds_read_b128 + 2 global 16-B loads + 3 MFMAs with no
-// conversion work; the weight loads of the next (tile, k-step) are in flight while the
-// current one is multiplied.
+// conversion work; the weight loads of the next two (tile, k-step) items are in flight while
+// the current one is multiplied.
 #include "common.h"
 
 namespace haet {
@@ -50,38 +50,39 @@ __device__ __forceinline__ unsigned short bf16_rne(float a) {
     return (unsigned short)__builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
+// ALL LDS addressing is by BYTE OFFSET into this one array.  Generic pointers to LDS (pointers kept
+// in structs / arrays / passed to non-inlined routines) make hipcc emit flat_load/flat_store, and a
+// flat access must wait vmcnt(0) AND lgkmcnt(0): the first version of this kernel had 1038 flat
+// and 4 ds instructions and every phase ran at one memory latency per access.
+extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ float& F(int off) { return *reinterpret_cast<float*>(smem + off); }
+__device__ __forceinline__ int& I(int off) { return *reinterpret_cast<int*>(smem + off); }
+
 // split-bf16 image: hi plane, then lo plane `plane` bytes later; rows `S` bytes apart
 struct Img {
-    char* base;
+    int base;  // byte offset in smem
     int S, plane;
     __device__ __forceinline__ void put(int t, int k, float v) const {
         const unsigned short h = bf16_rne(v);
         const unsigned short l = bf16_rne(v - __uint_as_float((unsigned)h << 16));
-        *reinterpret_cast<unsigned short*>(base + t * S + 2 * k) = h;
-        *reinterpret_cast<unsigned short*>(base + plane + t * S + 2 * k) = l;
+        *reinterpret_cast<unsigned short*>(smem + base + t * S + 2 * k) = h;
+        *reinterpret_cast<unsigned short*>(smem + base + plane + t * S + 2 * k) = l;
     }
 };
 
 __host__ __device__ inline int round32(int k) { return (k + 31) & ~31; }
 __host__ __device__ inline int img_stride(int K) { return round32(K) * 2 + kImgPad; }
 
-struct Lds {
-    float* X[HAET_ERWIN_MAX_LEVELS];
-    float* P[HAET_ERWIN_MAX_LEVELS];
-    int* rot[HAET_ERWIN_MAX_LEVELS];
-    int n[HAET_ERWIN_MAX_LEVELS];
-    int ld[HAET_ERWIN_MAX_LEVELS];
-    char* ia;    // split image of a width-c Linear input
-    char* wide;  // qkv fp32 [n][3c+4] | split image of hidden / pooling rows
-    float* rel;  // [n][d]
-    float* par;  // the current block's / resample's small fp32 parameters
-    int* ident;
-};
+// LDS directory, itself in LDS (ints at smem[0..]): per level l the BYTE offsets of X_l, P_l,
+// rot_l and n_l, ld_l (floats); then the shared regions.
+constexpr int T_X = 0, T_P = 4, T_ROT = 8, T_N = 12, T_LD = 16;  // + level
+constexpr int T_IA = 20, T_WIDE = 21, T_REL = 22, T_PAR = 23, T_IDENT = 24, T_WORDS = 32;
+__device__ __forceinline__ int T(int i) { return I(4 * i); }
 
 // copy `len` floats (16-B aligned, multiple of 4) of small parameters into LDS
-__device__ __forceinline__ void stage_params(float* dst, const float* __restrict__ src, int len) {
+__device__ __forceinline__ void stage_params(int dst, const float* __restrict__ src, int len) {
     for (int i = threadIdx.x * 4; i < len; i += blockDim.x * 4)
-        *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(src + i);
+        *reinterpret_cast<f32x4*>(smem + dst + 4 * i) = *reinterpret_cast<const f32x4*>(src + i);
 }
 
 __device__ __forceinline__ f32x4 mfma3(u32x4 ah, u32x4 al, u32x4 bh, u32x4 bl, f32x4 c) {
@@ -93,13 +94,6 @@ __device__ __forceinline__ f32x4 mfma3(u32x4 ah, u32x4 al, u32x4 bh, u32x4 bl, f
     return c;
 }
 
-// CODE SIZE IS LATENCY HERE.  The kernel runs once per forward with cold instruction caches
-// (7 GB of data stream through L2 between two forwards), and measured ~3 cycles per byte of
-// DISTINCT code executed (stamped build: 159 KB fully inlined = 504k cycles, whatever the
-// arithmetic).  So the stage is built from a few NON-INLINED routines that every block / level
-// re-executes from the instruction cache: one Linear core (runtime epilogue mode), one norm,
-// one ball-centre, one attention per head_dim, one block body, one pool, one unpool, driven by
-// an op list.
 enum EpiMode {
     EP_QKV = 0,     // dst[t][o]  = acc + b0[o]                      (fp32 rows, ld = ldd)
     EP_RESID = 1,   // dst[t][o] += acc + b0[o]
@@ -108,15 +102,15 @@ enum EpiMode {
     EP_UNPOOL = 4,  // dst[t*st + o/aux][o%aux] = (old + acc + b0[o]) * sc[o%aux] + sh[o%aux]
 };
 
-// Y[t][o] = sum_k X[t][k] W[o][k].  X: split image (n rows, K~32 columns, pad columns zero).
-// W: global bf16 planes [O][Kp] (hi at Wa, lo at Wa + O*Kp); EP_SWIGLU adds a second matrix Wb on
-// the same activations.  Two items (tile, k-step) of weights are in flight behind the one being
-// multiplied.
+// Y[t][o] = sum_k X[t][k] W[o][k] on the matrix cores.  X: split image in LDS (n rows, K~32
+// columns, pad columns zero).  W: global bf16 planes [O][Kp] (hi at Wa, lo at Wa + O*Kp);
+// EP_SWIGLU adds a second matrix Wb on the same activations.  Two (tile, k-step) items of weights
+// are in flight behind the one being multiplied.  dst / b0 / b1 / sc / sh are LDS byte offsets.
+// One shared routine (runtime epilogue mode) keeps the kernel's instruction footprint small.
 __device__ __attribute__((noinline)) void linear_core(
-    const char* xbase, int xS, int xplane, int n, int K, const unsigned short* __restrict__ Wa,
-    const unsigned short* __restrict__ Wb, int O, int mode, float* dst, int ldd, const float* b0,
-    const float* b1, const float* sc, const float* sh, char* dimg, int dS, int dplane, int aux,
-    int st) {
+    const Img x, int n, int K, const unsigned short* __restrict__ Wa,
+    const unsigned short* __restrict__ Wb, int O, int mode, int dst, int ldd, int b0, int b1, int sc,
+    int sh, const Img di, int aux, int st) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const int Kp = round32(K), nks = Kp >> 5;
@@ -132,43 +126,45 @@ __device__ __attribute__((noinline)) void linear_core(
         const int tile = wave + nwaves * (it / nks), ks = it % nks;
         const int ot = tile % nto;
         const size_t off = (size_t)min(ot * 16 + l15, O - 1) * Kp + 32 * ks + 8 * kq;
-        wv[0] = *reinterpret_cast<const u32x4*>(Wa + off);
-        wv[1] = *reinterpret_cast<const u32x4*>(Wa + plane + off);
+        // explicit global address space: a generic pointer argument would become flat_load,
+        // which waits for LDS and global traffic alike and kills the prefetch
+        typedef const __attribute__((address_space(1))) u32x4* gv4;
+        wv[0] = *(gv4)(Wa + off);
+        wv[1] = *(gv4)(Wa + plane + off);
         if (dual) {
-            wv[2] = *reinterpret_cast<const u32x4*>(Wb + off);
-            wv[3] = *reinterpret_cast<const u32x4*>(Wb + plane + off);
+            wv[2] = *(gv4)(Wb + off);
+            wv[3] = *(gv4)(Wb + plane + off);
         }
     };
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const Img di = {dimg, dS, dplane};
     auto step = [&](int it, const u32x4 (&wv)[4]) {
         const int tile = wave + nwaves * (it / nks), ks = it % nks;
         const int tt = tile / nto, ot = tile - tt * nto;
-        const char* xr = xbase + min(tt * 16 + l15, n - 1) * xS + (32 * ks + 8 * kq) * 2;
-        const u32x4 xh = *reinterpret_cast<const u32x4*>(xr);
-        const u32x4 xl = *reinterpret_cast<const u32x4*>(xr + xplane);
+        const int xo = x.base + min(tt * 16 + l15, n - 1) * x.S + (32 * ks + 8 * kq) * 2;
+        const u32x4 xh = *reinterpret_cast<const u32x4*>(smem + xo);
+        const u32x4 xl = *reinterpret_cast<const u32x4*>(smem + xo + x.plane);
         acc0 = mfma3(xh, xl, wv[0], wv[1], acc0);
         if (dual) acc1 = mfma3(xh, xl, wv[2], wv[3], acc1);
         if (ks == nks - 1) {
             const int o = ot * 16 + l15;
             if (o < O) {
-                const float bo = b0[o];
+                const float bo = F(b0 + 4 * o);
                 for (int r = 0; r < 4; ++r) {
                     const int t = tt * 16 + 4 * kq + r;
                     if (t < n) {
                         const float v = acc0[r] + bo;
                         if (mode == EP_QKV) {
-                            dst[t * ldd + o] = v;
+                            F(dst + 4 * (t * ldd + o)) = v;
                         } else if (mode == EP_RESID) {
-                            dst[t * ldd + o] += v;
+                            F(dst + 4 * (t * ldd + o)) += v;
                         } else if (mode == EP_SWIGLU) {
-                            di.put(t, o, (acc1[r] + b1[o]) * (v / (1.0f + __expf(-v))));
+                            di.put(t, o, (acc1[r] + F(b1 + 4 * o)) * (v / (1.0f + __expf(-v))));
                         } else if (mode == EP_BN) {
-                            dst[t * ldd + o] = v * sc[o] + sh[o];
+                            F(dst + 4 * (t * ldd + o)) = v * F(sc + 4 * o) + F(sh + 4 * o);
                         } else {
                             const int q = o / aux, ch = o - q * aux;  // 'n (m d) -> (n m) d'
-                            float* y = dst + (t * st + q) * ldd + ch;
-                            *y = (*y + v) * sc[ch] + sh[ch];
+                            float& y = F(dst + 4 * ((t * st + q) * ldd + ch));
+                            y = (y + v) * F(sc + 4 * ch) + F(sh + 4 * ch);
                         }
                     }
                 }
@@ -193,23 +189,24 @@ __device__ __attribute__((noinline)) void linear_core(
 
 // ia[t][:] = split( RMSNorm(X[t][:]) * w  [+ pe_b + rel[t] . pe_w] ); 4 threads per token row.
 // nn.RMSNorm(eps=None): eps = finfo(float32).eps (layers.py:25-26); PE: attention.py:59-61.
-__device__ __attribute__((noinline)) void norm_rows(const float* X, int ldx, int n, int c, const float* w, const float* rel,
-                          int d, const float* pe_w, const float* pe_b, const Img out) {
+// X, w, rel, pe_w, pe_b: LDS byte offsets (pe_w < 0: no positional term).
+__device__ __attribute__((noinline)) void norm_rows(int X, int ldx, int n, int c, int w, int rel,
+                                                    int d, int pe_w, int pe_b, const Img out) {
     const int sub = threadIdx.x & 3, cp = round32(c);
     for (int t = threadIdx.x >> 2; t < n; t += (blockDim.x >> 2)) {
-        const float* xr = X + t * ldx;
+        const int xr = X + 4 * t * ldx;
         float ss = 0.f;
-        for (int ch = sub; ch < c; ch += 4) ss = fmaf(xr[ch], xr[ch], ss);
+        for (int ch = sub; ch < c; ch += 4) ss = fmaf(F(xr + 4 * ch), F(xr + 4 * ch), ss);
         ss += __shfl_xor(ss, 1);
         ss += __shfl_xor(ss, 2);
         const float r = rsqrtf(ss / (float)c + 1.1920928955078125e-07f);
         for (int ch = sub; ch < cp; ch += 4) {
             float v = 0.f;
             if (ch < c) {
-                v = xr[ch] * r * w[ch];
-                if (pe_w) {
-                    float pe = pe_b[ch];
-                    for (int j = 0; j < d; ++j) pe = fmaf(rel[t * d + j], pe_w[j * c + ch], pe);
+                v = F(xr + 4 * ch) * r * F(w + 4 * ch);
+                if (pe_w >= 0) {
+                    float pe = F(pe_b + 4 * ch);
+                    for (int j = 0; j < d; ++j) pe = fmaf(F(rel + 4 * (t * d + j)), F(pe_w + 4 * (j * c + ch)), pe);
                     v += pe;
                 }
             }
@@ -221,66 +218,66 @@ __device__ __attribute__((noinline)) void norm_rows(const float* X, int ldx, int
 // rel[tok] = P[tok] - mean over its ball (attention.py:35-40); ball b = places [b*ball, ..).
 // One thread per (dimension, place): a ball's places are `ball` consecutive lanes, so for the
 // power-of-two ball sizes (<= 64) the ball sum is a segmented xor-butterfly.
-__device__ __attribute__((noinline)) void ball_rel_pos(const float* P, int n, int d, int ball, const int* perm, float* rel) {
+__device__ __attribute__((noinline)) void ball_rel_pos(int P, int n, int d, int ball, int perm, int rel) {
     if (ball <= 64 && (ball & (ball - 1)) == 0) {
         const int total = (n * d + 63) & ~63;  // whole waves: every lane takes part in the shuffles
         for (int i = threadIdx.x; i < total; i += blockDim.x) {
             const int j = i / n, p = i - j * n;
             const bool ok = j < d;
-            const int tok = ok ? perm[p] : 0;
-            const float v = ok ? P[tok * d + j] : 0.f;
+            const int tok = ok ? I(perm + 4 * p) : 0;
+            const float v = ok ? F(P + 4 * (tok * d + j)) : 0.f;
             float sum = v;
             for (int off = 1; off < ball; off <<= 1) sum += __shfl_xor(sum, off);
-            if (ok) rel[tok * d + j] = v - sum / (float)ball;
+            if (ok) F(rel + 4 * (tok * d + j)) = v - sum / (float)ball;
         }
         return;
     }
     const int nb = n / ball;
     for (int i = threadIdx.x; i < nb * d; i += blockDim.x) {
         const int b = i / d, j = i % d;
-        float s = 0.f;
-        for (int p = 0; p < ball; ++p) s += P[perm[b * ball + p] * d + j];
-        const float mean = s / (float)ball;
+        float sm = 0.f;
+        for (int p = 0; p < ball; ++p) sm += F(P + 4 * (I(perm + 4 * (b * ball + p)) * d + j));
+        const float mean = sm / (float)ball;
         for (int p = 0; p < ball; ++p) {
-            const int tok = perm[b * ball + p];
-            rel[tok * d + j] = P[tok * d + j] - mean;
+            const int tok = I(perm + 4 * (b * ball + p));
+            F(rel + 4 * (tok * d + j)) = F(P + 4 * (tok * d + j)) - mean;
         }
     }
 }
 
 // exact softmax(q k^T / sqrt(hd)) v inside each ball (attention.py:68-84; the reference calls
-// flash_attn_qkvpacked_func here).  One thread per (place, head); qkv rows are
-// [q(h,hd) | k(h,hd) | v(h,hd)] ("(three h d)").  The output goes straight into the split
-// image that feeds the proj Linear.
+// flash_attn_qkvpacked_func here).  One thread per (place, head); qkv rows (fp32, LDS) are
+// [q(h,hd) | k(h,hd) | v(h,hd)] ("(three h d)").  The output goes straight into the split image
+// that feeds the proj Linear.
 template <int HD>
-__device__ __attribute__((noinline)) void ball_attention(const float* qkv, int ldq, int n, int c, int heads, int ball,
-                               const int* perm, const Img out) {
+__device__ __attribute__((noinline)) void ball_attention(int qkv, int ldq, int n, int c, int heads,
+                                                         int ball, int perm, const Img out) {
     constexpr int KC = 8;  // keys per step: 8 independent score chains, one rescale per step
     const float scale = 1.0f / sqrtf((float)HD);
     for (int i = threadIdx.x; i < n * heads; i += blockDim.x) {
         const int place = i / heads, h = i % heads;
-        const int tq = perm[place], b0 = (place / ball) * ball;
+        const int tq = I(perm + 4 * place), b0 = (place / ball) * ball;
         float q[HD], acc[HD];
 #pragma unroll
         for (int e = 0; e < HD; ++e) {
-            q[e] = qkv[tq * ldq + h * HD + e] * scale;
+            q[e] = F(qkv + 4 * (tq * ldq + h * HD + e)) * scale;
             acc[e] = 0.f;
         }
         float m = -INFINITY, l = 0.f;
         for (int p0 = 0; p0 < ball; p0 += KC) {
-            const float* kr[KC];
+            int kr[KC];
             float sc[KC];
             float mx = m;
 #pragma unroll
             for (int u = 0; u < KC; ++u) {
                 const int p = min(p0 + u, ball - 1);
-                kr[u] = qkv + perm[b0 + p] * ldq + c + h * HD;
+                kr[u] = qkv + 4 * (I(perm + 4 * (b0 + p)) * ldq + c + h * HD);
             }
 #pragma unroll
             for (int u = 0; u < KC; ++u) {
                 float sv = 0.f;
 #pragma unroll
-                for (int e = 0; e < HD; ++e) sv = fmaf(q[e], kr[u][e], sv);
+                for (int e = 0; e < HD; ++e) sv = fmaf(q[e], F(kr[u] + 4 * e), sv);
                 sc[u] = (p0 + u < ball) ? sv : -INFINITY;
                 mx = fmaxf(mx, sc[u]);
             }
@@ -292,9 +289,8 @@ __device__ __attribute__((noinline)) void ball_attention(const float* qkv, int l
             for (int u = 0; u < KC; ++u) {
                 const float pr = __expf(sc[u] - mx);
                 l += pr;
-                const float* vr = kr[u] + c;
 #pragma unroll
-                for (int e = 0; e < HD; ++e) acc[e] = fmaf(pr, vr[e], acc[e]);
+                for (int e = 0; e < HD; ++e) acc[e] = fmaf(pr, F(kr[u] + 4 * (c + e)), acc[e]);
             }
             m = mx;
         }
@@ -304,8 +300,8 @@ __device__ __attribute__((noinline)) void ball_attention(const float* qkv, int l
     }
 }
 
-__device__ __attribute__((noinline)) void attention_dispatch(int hd, const float* qkv, int ldq, int n, int c, int heads,
-                                   int ball, const int* perm, const Img out) {
+__device__ __attribute__((noinline)) void attention_dispatch(int hd, int qkv, int ldq, int n, int c,
+                                                             int heads, int ball, int perm, const Img out) {
     switch (hd) {
         case 1: ball_attention<1>(qkv, ldq, n, c, heads, ball, perm, out); break;
         case 2: ball_attention<2>(qkv, ldq, n, c, heads, ball, perm, out); break;
@@ -322,69 +318,69 @@ __device__ __forceinline__ const unsigned short* wptr(const float* W, int off) {
 }
 
 // ErwinTransformerBlock (layers.py:30-32) on the tokens of one level, in place
-__device__ __attribute__((noinline)) void erwin_block(const Lds& s, int lvl, const haet_erwin_layer& L,
-                            const haet_erwin_block_w& w, const float* __restrict__ W, int d,
-                            const int* perm) {
-    float* X = s.X[lvl];
-    const int n = s.n[lvl], c = L.c, ld = s.ld[lvl], hid = L.hidden;
-    const int ldq = 3 * c + kPad;
-    const Img ia = {s.ia, img_stride(c), n * img_stride(c)};
-    const Img ih = {s.wide, img_stride(hid), n * img_stride(hid)};
+__device__ __attribute__((noinline)) void erwin_block(int lvl, const haet_erwin_layer& L,
+                                                      const haet_erwin_block_w& w,
+                                                      const float* __restrict__ W, int d, int perm) {
+    const int X = T(T_X + lvl), n = T(T_N + lvl), ld = T(T_LD + lvl), c = L.c, hid = L.hidden;
+    const int ldq = 3 * c + kPad, wide = T(T_WIDE);
+    const Img ia = {T(T_IA), img_stride(c), n * img_stride(c)};
+    const Img ih = {wide, img_stride(hid), n * img_stride(hid)};
+    const Img none = {0, 0, 0};
     // norm weights, positional projection and every bias of this block: one coalesced copy to LDS
     // (they are re-read per token / per tile; from global each use is a dependent L2/HBM trip)
-    const float* par = s.par - w.small_off;  // par + <blob offset> addresses the LDS copy
+    const int par = T(T_PAR) - 4 * w.small_off;  // par + 4 * <blob offset> addresses the LDS copy
     STAMP(16);
-    stage_params(s.par, W + w.small_off, w.small_len);
+    stage_params(T(T_PAR), W + w.small_off, w.small_len);
     // x~ = RMSNorm(x) + pe_proj(pos - ball centre)            (attention.py:59-61)
-    ball_rel_pos(s.P[lvl], n, d, L.ball, perm, s.rel);
+    ball_rel_pos(T(T_P + lvl), n, d, L.ball, perm, T(T_REL));
     __syncthreads();
     STAMP(17);
-    norm_rows(X, ld, n, c, par + w.norm1, s.rel, d, par + w.pe_w, par + w.pe_b, ia);
+    norm_rows(X, ld, n, c, par + 4 * w.norm1, T(T_REL), d, par + 4 * w.pe_w, par + 4 * w.pe_b, ia);
     __syncthreads();
     STAMP(18);
-    linear_core(ia.base, ia.S, ia.plane, n, c, wptr(W, w.qkv_w), nullptr, 3 * c, EP_QKV,
-                reinterpret_cast<float*>(s.wide), ldq, par + w.qkv_b, nullptr, nullptr, nullptr, nullptr,
-                0, 0, 0, 0);
+    linear_core(ia, n, c, wptr(W, w.qkv_w), nullptr, 3 * c, EP_QKV, wide, ldq, par + 4 * w.qkv_b, 0, 0, 0,
+                none, 0, 0);
     __syncthreads();
     STAMP(19);
-    attention_dispatch(c / L.heads, reinterpret_cast<const float*>(s.wide), ldq, n, c, L.heads, L.ball,
-                       perm, ia);
+    attention_dispatch(c / L.heads, wide, ldq, n, c, L.heads, L.ball, perm, ia);
     __syncthreads();
     STAMP(20);
-    linear_core(ia.base, ia.S, ia.plane, n, c, wptr(W, w.proj_w), nullptr, c, EP_RESID, X, ld,
-                par + w.proj_b, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0);
+    linear_core(ia, n, c, wptr(W, w.proj_w), nullptr, c, EP_RESID, X, ld, par + 4 * w.proj_b, 0, 0, 0, none,
+                0, 0);
     __syncthreads();
     STAMP(21);
     // x += W3( W2 x^ * silu(W1 x^) ),  x^ = RMSNorm(x)          (mlp.py:17-18)
-    norm_rows(X, ld, n, c, par + w.norm2, nullptr, 0, nullptr, nullptr, ia);
+    norm_rows(X, ld, n, c, par + 4 * w.norm2, 0, 0, -1, 0, ia);
     {
         const int padk = round32(hid) - hid;  // zero the k padding of the hidden image
         for (int i = threadIdx.x; i < n * padk; i += blockDim.x) ih.put(i / padk, hid + i % padk, 0.f);
     }
     __syncthreads();
     STAMP(22);
-    linear_core(ia.base, ia.S, ia.plane, n, c, wptr(W, w.w1_w), wptr(W, w.w2_w), hid, EP_SWIGLU, nullptr,
-                0, par + w.w1_b, par + w.w2_b, nullptr, nullptr, ih.base, ih.S, ih.plane, 0, 0);
+    linear_core(ia, n, c, wptr(W, w.w1_w), wptr(W, w.w2_w), hid, EP_SWIGLU, 0, 0, par + 4 * w.w1_b,
+                par + 4 * w.w2_b, 0, 0, ih, 0, 0);
     __syncthreads();
     STAMP(23);
-    linear_core(ih.base, ih.S, ih.plane, n, hid, wptr(W, w.w3_w), nullptr, c, EP_RESID, X, ld,
-                par + w.w3_b, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0);
+    linear_core(ih, n, hid, wptr(W, w.w3_w), nullptr, c, EP_RESID, X, ld, par + 4 * w.w3_b, 0, 0, 0, none, 0,
+                0);
     __syncthreads();
     STAMP(24);
 }
 
 // BallPooling (pooling.py:25-40): level l -> l+1
-__device__ __attribute__((noinline)) void erwin_pool(const Lds& s, int l, const haet_erwin_desc& D,
+__device__ __attribute__((noinline)) void erwin_pool(int l, const haet_erwin_desc& D,
                                                      const float* __restrict__ W) {
     const haet_erwin_resample& R = D.pool[l];
-    const int d = D.d, st = R.stride, n2 = s.n[l + 1], c = D.enc[l].c, K = st * c + st * d;
-    const Img rows = {s.wide, img_stride(K), n2 * img_stride(K)};
-    stage_params(s.par, W + R.small_off, R.small_len);
+    const int d = D.d, st = R.stride, n2 = T(T_N + l + 1), c = D.enc[l].c, K = st * c + st * d;
+    const int X0 = T(T_X + l), ld0 = T(T_LD + l), P0 = T(T_P + l), P1 = T(T_P + l + 1);
+    const Img rows = {T(T_WIDE), img_stride(K), n2 * img_stride(K)};
+    const Img none = {0, 0, 0};
+    stage_params(T(T_PAR), W + R.small_off, R.small_len);
     for (int i = threadIdx.x; i < n2 * d; i += blockDim.x) {
         const int p = i / d, j = i % d;
         float sum = 0.f;
-        for (int q = 0; q < st; ++q) sum += s.P[l][(p * st + q) * d + j];
-        s.P[l + 1][i] = sum / (float)st;
+        for (int q = 0; q < st; ++q) sum += F(P0 + 4 * ((p * st + q) * d + j));
+        F(P1 + 4 * i) = sum / (float)st;
     }
     __syncthreads();
     const int Kp = round32(K);
@@ -392,44 +388,45 @@ __device__ __attribute__((noinline)) void erwin_pool(const Lds& s, int l, const 
         const int p = i / Kp, k = i % Kp;
         float v = 0.f;
         if (k < st * c) {
-            v = s.X[l][(p * st + k / c) * s.ld[l] + k % c];
+            v = F(X0 + 4 * ((p * st + k / c) * ld0 + k % c));
         } else if (k < K) {
             const int r = k - st * c, q = r / d, j = r % d;
-            v = s.P[l][(p * st + q) * d + j] - s.P[l + 1][p * d + j];
+            v = F(P0 + 4 * ((p * st + q) * d + j)) - F(P1 + 4 * (p * d + j));
         }
         rows.put(p, k, v);
     }
     __syncthreads();
-    const float* par = s.par - R.small_off;
-    linear_core(rows.base, rows.S, rows.plane, n2, K, wptr(W, R.w), nullptr, D.enc[l + 1].c, EP_BN,
-                s.X[l + 1], s.ld[l + 1], par + R.b, nullptr, par + R.bn_scale, par + R.bn_shift, nullptr,
-                0, 0, 0, 0);
+    const int par = T(T_PAR) - 4 * R.small_off;
+    linear_core(rows, n2, K, wptr(W, R.w), nullptr, D.enc[l + 1].c, EP_BN, T(T_X + l + 1), T(T_LD + l + 1),
+                par + 4 * R.b, 0, par + 4 * R.bn_scale, par + 4 * R.bn_shift, none, 0, 0);
     __syncthreads();
 }
 
 // BallUnpooling (pooling.py:58-72): level l+1 -> l
-__device__ __attribute__((noinline)) void erwin_unpool(const Lds& s, int l, const haet_erwin_desc& D,
+__device__ __attribute__((noinline)) void erwin_unpool(int l, const haet_erwin_desc& D,
                                                        const float* __restrict__ W) {
     const haet_erwin_resample& R = D.unpool[l];
-    const int d = D.d, st = R.stride, n2 = s.n[l + 1], c2 = D.enc[l + 1].c, c = D.enc[l].c;
+    const int d = D.d, st = R.stride, n2 = T(T_N + l + 1), c2 = D.enc[l + 1].c, c = D.enc[l].c;
     const int K = c2 + st * d, Kp = round32(K);
-    const Img rows = {s.wide, img_stride(K), n2 * img_stride(K)};
-    stage_params(s.par, W + R.small_off, R.small_len);
+    const int X1 = T(T_X + l + 1), ld1 = T(T_LD + l + 1), P0 = T(T_P + l), P1 = T(T_P + l + 1);
+    const Img rows = {T(T_WIDE), img_stride(K), n2 * img_stride(K)};
+    const Img none = {0, 0, 0};
+    stage_params(T(T_PAR), W + R.small_off, R.small_len);
     for (int i = threadIdx.x; i < n2 * Kp; i += blockDim.x) {
         const int p = i / Kp, k = i % Kp;
         float v = 0.f;
         if (k < c2) {
-            v = s.X[l + 1][p * s.ld[l + 1] + k];
+            v = F(X1 + 4 * (p * ld1 + k));
         } else if (k < K) {
             const int r = k - c2, q = r / d, j = r % d;
-            v = s.P[l][(p * st + q) * d + j] - s.P[l + 1][p * d + j];
+            v = F(P0 + 4 * ((p * st + q) * d + j)) - F(P1 + 4 * (p * d + j));
         }
         rows.put(p, k, v);
     }
     __syncthreads();
-    const float* par = s.par - R.small_off;
-    linear_core(rows.base, rows.S, rows.plane, n2, K, wptr(W, R.w), nullptr, st * c, EP_UNPOOL, s.X[l],
-                s.ld[l], par + R.b, nullptr, par + R.bn_scale, par + R.bn_shift, nullptr, 0, 0, c, st);
+    const int par = T(T_PAR) - 4 * R.small_off;
+    linear_core(rows, n2, K, wptr(W, R.w), nullptr, st * c, EP_UNPOOL, T(T_X + l), T(T_LD + l), par + 4 * R.b, 0,
+                par + 4 * R.bn_scale, par + 4 * R.bn_shift, none, c, st);
     __syncthreads();
 }
 
@@ -450,7 +447,7 @@ __host__ __device__ inline int erwin_max_small(const haet_erwin_desc& D) {
 // LDS carve-up shared by host (sizing) and device; returns the total in floats
 __host__ __device__ inline int erwin_layout(const haet_erwin_desc& D, int Mp, int* ia_bytes,
                                             int* wide_bytes) {
-    int n = Mp, ia = 0, wide = 0, tot = 0, idx = 0;
+    int n = Mp, ia = 0, wide = 0, tot = T_WORDS, idx = 0;
     const int d = D.d;
     for (int l = 0; l < D.n_levels; ++l) {
         const haet_erwin_layer& L = D.enc[l];
@@ -485,60 +482,58 @@ __global__ __launch_bounds__(512) void erwin_kernel(
     const int32_t* __restrict__ tree_idx, const uint8_t* __restrict__ tree_mask,
     const int32_t* __restrict__ rot, const float* __restrict__ W, int M, int Mp,
     float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     STAMP(0);
-    STAMP(1);
     const haet_erwin_desc& D = *reinterpret_cast<const haet_erwin_desc*>(W);
     const int cloud = blockIdx.x, n_clouds = gridDim.x, d = D.d, nl = D.n_levels;
-    Lds s;
-    {
+    if (threadIdx.x == 0) {  // LDS directory
         int ia_bytes, wide_bytes;
         erwin_layout(D, Mp, &ia_bytes, &wide_bytes);
-        float* p = lds;
-        int n = Mp;
+        int p = 4 * T_WORDS, n = Mp;
         for (int l = 0; l < nl; ++l) {
-            s.n[l] = n;
-            s.ld[l] = D.enc[l].c + kPad;
-            s.X[l] = p;
-            p += n * s.ld[l];
+            I(4 * (T_N + l)) = n;
+            I(4 * (T_LD + l)) = D.enc[l].c + kPad;
+            I(4 * (T_X + l)) = p;
+            p += 4 * n * (D.enc[l].c + kPad);
             if (l < nl - 1) n /= D.pool[l].stride;
         }
         for (int l = 0; l < nl; ++l) {
-            s.P[l] = p;
-            p += ((s.n[l] * d + 3) & ~3);
+            I(4 * (T_P + l)) = p;
+            p += 4 * ((I(4 * (T_N + l)) * d + 3) & ~3);
         }
-        s.ia = reinterpret_cast<char*>(p);
-        p += ia_bytes / 4;
-        s.wide = reinterpret_cast<char*>(p);
-        p += wide_bytes / 4;
-        s.rel = p;
-        p += ((Mp * d + 3) & ~3);
-        s.par = p;
-        p += erwin_max_small(D);
-        int* q = reinterpret_cast<int*>(p);
+        I(4 * T_IA) = p;
+        p += ia_bytes;
+        I(4 * T_WIDE) = p;
+        p += wide_bytes;
+        I(4 * T_REL) = p;
+        p += 4 * ((Mp * d + 3) & ~3);
+        I(4 * T_PAR) = p;
+        p += 4 * erwin_max_small(D);
         for (int l = 0; l < nl; ++l) {
-            s.rot[l] = q;
-            q += s.n[l];
+            I(4 * (T_ROT + l)) = p;
+            p += 4 * I(4 * (T_N + l));
         }
-        s.ident = q;
+        I(4 * T_IDENT) = p;
     }
+    __syncthreads();
+    STAMP(1);
     // gather the cloud into tree order (erwin_flash.py:176-181)
-    const int c0 = D.enc[0].c;
+    const int c0 = D.enc[0].c, X0 = T(T_X), ld0 = T(T_LD), P0 = T(T_P), ident = T(T_IDENT);
     for (int i = threadIdx.x; i < Mp * c0; i += blockDim.x) {
         const int slot = i / c0, ch = i % c0;
-        s.X[0][slot * s.ld[0] + ch] = tokens[(size_t)tree_idx[(size_t)cloud * Mp + slot] * c0 + ch];
+        F(X0 + 4 * (slot * ld0 + ch)) = tokens[(size_t)tree_idx[(size_t)cloud * Mp + slot] * c0 + ch];
     }
     for (int i = threadIdx.x; i < Mp * d; i += blockDim.x) {
         const int slot = i / d, j = i % d;
-        s.P[0][i] = pos[(size_t)tree_idx[(size_t)cloud * Mp + slot] * d + j];
+        F(P0 + 4 * i) = pos[(size_t)tree_idx[(size_t)cloud * Mp + slot] * d + j];
     }
-    for (int i = threadIdx.x; i < Mp; i += blockDim.x) s.ident[i] = i;
+    for (int i = threadIdx.x; i < Mp; i += blockDim.x) I(ident + 4 * i) = i;
     if (D.rotate) {
         size_t off = 0;
         for (int l = 0; l < nl; ++l) {
-            for (int i = threadIdx.x; i < s.n[l]; i += blockDim.x)
-                s.rot[l][i] = rot[off + (size_t)cloud * s.n[l] + i] - cloud * s.n[l];
-            off += (size_t)n_clouds * s.n[l];
+            const int nlv = T(T_N + l), ro = T(T_ROT + l);
+            for (int i = threadIdx.x; i < nlv; i += blockDim.x)
+                I(ro + 4 * i) = rot[off + (size_t)cloud * nlv + i] - cloud * nlv;
+            off += (size_t)n_clouds * nlv;
         }
     }
     __syncthreads();
@@ -546,7 +541,6 @@ __global__ __launch_bounds__(512) void erwin_kernel(
 
     // Op list (erwin_flash.py:183-192): [blocks_l, pool_l]* , bottleneck blocks, [unpool_l, blocks_l]*.
     // kind 0 = block (a = level, b = block index | decoder flag << 8), 1 = pool, 2 = unpool.
-    int nops = 0;
     auto op_at = [&](int want, int& kind, int& a, int& b) {
         int i = 0;
         for (int l = 0; l < nl; ++l) {  // encoder + bottleneck
@@ -562,6 +556,7 @@ __global__ __launch_bounds__(512) void erwin_kernel(
         }
         return i;
     };
+    int nops;
     {
         int k, a, b;
         nops = op_at(-1, k, a, b);
@@ -572,20 +567,20 @@ __global__ __launch_bounds__(512) void erwin_kernel(
         if (kind == 0) {
             const haet_erwin_layer& L = (b & 256) ? D.dec[a] : D.enc[a];
             const int j = b & 255;
-            const bool rot = D.rotate && L.depth > 1 && (j & 1);  // layers.py:66,75-89
-            erwin_block(s, a, L, L.blocks[j], W, d, rot ? s.rot[a] : s.ident);
+            const bool rt = D.rotate && L.depth > 1 && (j & 1);  // layers.py:66,75-89
+            erwin_block(a, L, L.blocks[j], W, d, rt ? T(T_ROT + a) : ident);
         } else if (kind == 1) {
-            erwin_pool(s, a, D, W);
+            erwin_pool(a, D, W);
         } else {
-            erwin_unpool(s, a, D, W);
+            erwin_unpool(a, D, W);
         }
-        STAMP(3 + (op < 9 ? op : 9));
+        STAMP(3 + (op < 8 ? op : 8));
     }
     // node.x[tree_mask][argsort(tree_idx[tree_mask])]  (erwin_flash.py:193)
     for (int i = threadIdx.x; i < Mp * c0; i += blockDim.x) {
         const int slot = i / c0, ch = i % c0;
         const size_t g = (size_t)cloud * Mp + slot;
-        if (tree_mask[g]) out[(size_t)tree_idx[g] * c0 + ch] = s.X[0][slot * s.ld[0] + ch];
+        if (tree_mask[g]) out[(size_t)tree_idx[g] * c0 + ch] = F(X0 + 4 * (slot * ld0 + ch));
     }
     STAMP(12);
 }
