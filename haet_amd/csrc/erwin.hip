@@ -187,30 +187,41 @@ __device__ __attribute__((noinline)) void linear_core(
     }
 }
 
-// ia[t][:] = split( RMSNorm(X[t][:]) * w  [+ pe_b + rel[t] . pe_w] ); 4 threads per token row.
-// nn.RMSNorm(eps=None): eps = finfo(float32).eps (layers.py:25-26); PE: attention.py:59-61.
-// X, w, rel, pe_w, pe_b: LDS byte offsets (pe_w < 0: no positional term).
+// ia[t][:] = split( RMSNorm(X[t][:]) * w  [+ pe_b + rel[t] . pe_w] ).  A thread owns 4 consecutive
+// channels of one token (one ds_read_b128), the c/4 threads of a row reduce the sum of squares
+// with xor-shuffles: the dependent chain is ~5 LDS round trips whatever c is (it was one per
+// channel).  nn.RMSNorm(eps=None): eps = finfo(float32).eps (layers.py:25-26); PE:
+// attention.py:59-61.  X, w, rel, pe_w, pe_b: LDS byte offsets (pe_w < 0: no positional term).
 __device__ __attribute__((noinline)) void norm_rows(int X, int ldx, int n, int c, int w, int rel,
                                                     int d, int pe_w, int pe_b, const Img out) {
-    const int sub = threadIdx.x & 3, cp = round32(c);
-    for (int t = threadIdx.x >> 2; t < n; t += (blockDim.x >> 2)) {
-        const int xr = X + 4 * t * ldx;
-        float ss = 0.f;
-        for (int ch = sub; ch < c; ch += 4) ss = fmaf(F(xr + 4 * ch), F(xr + 4 * ch), ss);
-        ss += __shfl_xor(ss, 1);
-        ss += __shfl_xor(ss, 2);
+    const int cp = round32(c), tpr = cp >> 2;  // threads per row: 8, 16 or 32 (power of two)
+    const int sub = threadIdx.x & (tpr - 1), ch = 4 * sub;
+    const int rows_per_pass = blockDim.x / tpr;
+    const int passes = (n + rows_per_pass - 1) / rows_per_pass;
+    for (int ps = 0; ps < passes; ++ps) {
+        const int t = ps * rows_per_pass + threadIdx.x / tpr;
+        const bool live = t < n && ch < c;
+        f32x4 xv = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            xv = *reinterpret_cast<const f32x4*>(smem + X + 4 * (t * ldx + ch));
+            wv = *reinterpret_cast<const f32x4*>(smem + w + 4 * ch);
+        }
+        float ss = fmaf(xv[0], xv[0], fmaf(xv[1], xv[1], fmaf(xv[2], xv[2], xv[3] * xv[3])));
+        for (int off = 1; off < tpr; off <<= 1) ss += __shfl_xor(ss, off);
         const float r = rsqrtf(ss / (float)c + 1.1920928955078125e-07f);
-        for (int ch = sub; ch < cp; ch += 4) {
-            float v = 0.f;
-            if (ch < c) {
-                v = F(xr + 4 * ch) * r * F(w + 4 * ch);
-                if (pe_w >= 0) {
-                    float pe = F(pe_b + 4 * ch);
-                    for (int j = 0; j < d; ++j) pe = fmaf(F(rel + 4 * (t * d + j)), F(pe_w + 4 * (j * c + ch)), pe);
-                    v += pe;
-                }
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            v = xv * r * wv;
+            if (pe_w >= 0) {
+                f32x4 pe = *reinterpret_cast<const f32x4*>(smem + pe_b + 4 * ch);
+                for (int j = 0; j < d; ++j)
+                    pe += F(rel + 4 * (t * d + j)) * *reinterpret_cast<const f32x4*>(smem + pe_w + 4 * (j * c + ch));
+                v += pe;
             }
-            out.put(t, ch, v);
+        }
+        if (t < n) {  // pad channels (c..cp) are written as zeros
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out.put(t, ch + e, v[e]);
         }
     }
 }
@@ -480,9 +491,19 @@ __host__ __device__ inline int erwin_layout(const haet_erwin_desc& D, int Mp, in
 __global__ __launch_bounds__(512) void erwin_kernel(
     const float* __restrict__ tokens, const float* __restrict__ pos,
     const int32_t* __restrict__ tree_idx, const uint8_t* __restrict__ tree_mask,
-    const int32_t* __restrict__ rot, const float* __restrict__ W, int M, int Mp,
+    const int32_t* __restrict__ rot, const float* __restrict__ W, int w_lines, int M, int Mp,
     float* __restrict__ out) {
     STAMP(0);
+    // Touch one dword of every 128-B line of the weight blob (~0.5 MB): the streaming passes evict
+    // it from L2/MALL between two forwards, and the Linear chain below is ~70 dependent weight
+    // fetches per cloud, measured at ~4k cycles each from HBM.  The touches are issued back to
+    // back and their sum is only consumed at the end, so they cost one exposed miss in total and
+    // every later weight load hits this XCD's L2.
+    float warm = 0.f;
+    {
+        typedef const __attribute__((address_space(1))) float* gf;
+        for (int i = threadIdx.x; i < w_lines; i += blockDim.x) warm += *((gf)W + 32 * (size_t)i);
+    }
     const haet_erwin_desc& D = *reinterpret_cast<const haet_erwin_desc*>(W);
     const int cloud = blockIdx.x, n_clouds = gridDim.x, d = D.d, nl = D.n_levels;
     if (threadIdx.x == 0) {  // LDS directory
@@ -583,6 +604,7 @@ __global__ __launch_bounds__(512) void erwin_kernel(
         if (tree_mask[g]) out[(size_t)tree_idx[g] * c0 + ch] = F(X0 + 4 * (slot * ld0 + ch));
     }
     STAMP(12);
+    if (warm == 1.2345e38f && M < 0) out[0] = warm;  // keeps the touches alive; never taken
 }
 
 static int erwin_validate(const haet_erwin_desc* D, int Mp) {
@@ -663,6 +685,6 @@ extern "C" int haet_erwin_fwd(const float* tokens, const float* pos, const int32
         attr_set = bytes;
     }
     hipLaunchKernelGGL(erwin_kernel, dim3(n_clouds), dim3(512), bytes, as_stream(stream), tokens,
-                       pos, tree_idx, tree_mask, rot, weights, M, Mp, out);
+                       pos, tree_idx, tree_mask, rot, weights, (int)(weight_floats / 32), M, Mp, out);
     return check_launch("erwin_kernel");
 }
