@@ -33,12 +33,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #ifdef HAET_STAMPS
 // Diagnostic build only (make EXTRA=-DHAET_STAMPS; tools/erwin_stamps.py): s_memtime at phase
 // boundaries of cloud 0, written to a buffer nothing else reads.  Never quote this build's run time.
-__device__ unsigned long long haet_stamps[64];
+__device__ unsigned long long haet_stamps[128];
 #define STAMP(i)                                                                        \
     do {                                                                                \
         if (blockIdx.x == 0 && threadIdx.x == 0) {                                      \
             haet_stamps[i] = __builtin_amdgcn_s_memtime();                              \
-            haet_stamps[32 + (i)] = __builtin_amdgcn_s_memrealtime();                   \
+            haet_stamps[64 + (i)] = __builtin_amdgcn_s_memrealtime();                   \
         }                                                                               \
     } while (0)
 #else
@@ -120,6 +120,12 @@ __device__ __attribute__((noinline)) void linear_core(
     const int items = my_tiles * nks;
     const bool dual = mode == EP_SWIGLU;
     if (items == 0) return;
+#ifdef HAET_STAMPS
+#define LSTAMP(i) do { if (mode == EP_RESID && K <= 64) STAMP(i); } while (0)
+#else
+#define LSTAMP(i) do { } while (0)
+#endif
+    LSTAMP(40);
 
     u32x4 w0[4], w1[4];
     auto fetch = [&](int it, u32x4 (&wv)[4]) {
@@ -143,8 +149,13 @@ __device__ __attribute__((noinline)) void linear_core(
         const int xo = x.base + min(tt * 16 + l15, n - 1) * x.S + (32 * ks + 8 * kq) * 2;
         const u32x4 xh = *reinterpret_cast<const u32x4*>(smem + xo);
         const u32x4 xl = *reinterpret_cast<const u32x4*>(smem + xo + x.plane);
+        LSTAMP(42);
         acc0 = mfma3(xh, xl, wv[0], wv[1], acc0);
         if (dual) acc1 = mfma3(xh, xl, wv[2], wv[3], acc1);
+#ifdef HAET_STAMPS
+        if (mode == EP_RESID && K <= 64) { asm volatile("" :: "v"(acc0)); }
+#endif
+        LSTAMP(43);
         if (ks == nks - 1) {
             const int o = ot * 16 + l15;
             if (o < O) {
@@ -175,6 +186,7 @@ __device__ __attribute__((noinline)) void linear_core(
     };
     fetch(0, w0);
     if (items > 1) fetch(1, w1);
+    LSTAMP(41);
     for (int it = 0; it < items; it += 2) {  // two named register sets, statically indexed
         u32x4 c0[4] = {w0[0], w0[1], w0[2], w0[3]};
         if (it + 2 < items) fetch(it + 2, w0);
@@ -185,6 +197,7 @@ __device__ __attribute__((noinline)) void linear_core(
             step(it + 1, c1);
         }
     }
+    LSTAMP(44);
 }
 
 // ia[t][:] = split( RMSNorm(X[t][:]) * w  [+ pe_b + rel[t] . pe_w] ).  A thread owns 4 consecutive
@@ -649,7 +662,7 @@ using namespace haet;
 
 #ifdef HAET_STAMPS
 extern "C" int haet_debug_read_stamps(unsigned long long* host_out) {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(haet_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(haet_stamps), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -24,11 +24,11 @@ with torch.no_grad():
         mod(x)
 torch.cuda.synchronize()
 lib = _lib.load()
-buf = (ctypes.c_ulonglong * 64)()
+buf = (ctypes.c_ulonglong * 128)()
 assert lib.haet_debug_read_stamps(buf) == 0
 t = list(buf)
-clk = (t[12] - t[0]) / max(1, (t[32 + 12] - t[32 + 0])) * 100.0
-print(f"shader clock during the kernel: {clk:.0f} MHz; total {t[12]-t[0]} cycles = {(t[32+12]-t[32])/100.0:.1f} us")
+clk = (t[12] - t[0]) / max(1, (t[64 + 12] - t[64 + 0])) * 100.0
+print(f"shader clock during the kernel: {clk:.0f} MHz; total {t[12]-t[0]} cycles = {(t[64+12]-t[64])/100.0:.1f} us")
 names = {1: "prologue", 2: "gather to tree order", 3: "enc0 block 0", 4: "enc0 block 1", 5: "pool",
          6: "bottleneck block 0", 7: "bottleneck block 1", 8: "unpool", 9: "dec0 block 0",
          10: "dec0 block 1", 12: "scatter out"}
@@ -40,3 +40,5 @@ print("last block (dec0 block 1) phases:")
 bn = {17: "params+rel_pos", 18: "norm1+pe", 19: "qkv", 20: "attention", 21: "proj", 22: "norm2", 23: "w1w2", 24: "w3"}
 for i in range(17, 25):
     print(f"  {bn[i]:14s} {t[i]-t[i-1]:8d} cycles")
+print("inside the last proj/w3-type Linear call (wave 0): entry -> fetch issued -> operands read -> MFMAs done -> exit")
+print("  ", [t[i] - t[40] for i in range(40, 45)], " (phase entry stamp to linear entry:", t[40] - t[23], ")")
