@@ -54,6 +54,12 @@ struct Frag {
     u32x4 hi, lo;
 };
 
+// ALL LDS addressing is by byte offset into this one array: a generic pointer to LDS (kept in an
+// array like bufs[cur], or passed through a helper) becomes flat_load / flat_store, and a flat
+// access waits vmcnt(0) AND lgkmcnt(0) -- i.e. for the NEXT tile's global prefetch as well, which
+// serialises the load/compute overlap this kernel is built around.
+extern __shared__ __attribute__((aligned(16))) char smem[];
+
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
@@ -118,7 +124,7 @@ struct Loader {
         }
     }
     // split to bf16 hi/lo, write the LDS images, reduce Ada-Temp and write s_n = log2e / tau
-    __device__ __forceinline__ void stage(char* buf, float* sarr, int H, float bt, float base_temp) {
+    __device__ __forceinline__ void stage(int buf, int sarr, int H, float bt, float base_temp) {
         const int cpr = H * 8;
 #pragma unroll
         for (int i = 0; i < LI; ++i) {
@@ -140,38 +146,39 @@ struct Loader {
                 const u32x2 hi = {h01, h23};
                 const u32x2 lo = {pack_bf16(v[0] - a0, v[1] - a1), pack_bf16(v[2] - a2, v[3] - a3)};
                 const int off = img_off(row, q8 >> 1) + ((q8 & 1) << 3);
-                char* img = buf + h * (2 * IMG);
-                *reinterpret_cast<u32x2*>(img + off) = hi;
-                *reinterpret_cast<u32x2*>(img + IMG + off) = lo;
-                if (q8 == 0) sarr[h * TN + row] = kLog2e / ada_temp(t + bt, base_temp);
+                const int img = buf + h * (2 * IMG);
+                *reinterpret_cast<u32x2*>(smem + img + off) = hi;
+                *reinterpret_cast<u32x2*>(smem + img + IMG + off) = lo;
+                if (q8 == 0)
+                    *reinterpret_cast<float*>(smem + sarr + 4 * (h * TN + row)) = kLog2e / ada_temp(t + bt, base_temp);
             }
         }
     }
 };
 
 // split-bf16 fragment of 8 consecutive channels of `row` (A operand of Y = X.Ws, B operand of Yt)
-__device__ __forceinline__ Frag read_rows(const char* img, int row, int chunk) {
+__device__ __forceinline__ Frag read_rows(int img, int row, int chunk) {
     Frag f;
-    const int off = img_off(row, chunk);
-    f.hi = *reinterpret_cast<const u32x4*>(img + off);
-    f.lo = *reinterpret_cast<const u32x4*>(img + IMG + off);
+    const int off = img + img_off(row, chunk);
+    f.hi = *reinterpret_cast<const u32x4*>(smem + off);
+    f.lo = *reinterpret_cast<const u32x4*>(smem + off + IMG);
     return f;
 }
 
 // transposed fragment: lane (c = lane&31, hf) gets X[n = 16s + 8(j>>2) + 4hf + (j&3)][c], j = 0..7
 // -- the k order an accumulator tile has when it is reused as the A operand (guide s.3).
-__device__ __forceinline__ Frag read_cols(const char* img, int s, int lane) {
+__device__ __forceinline__ Frag read_cols(int img, int s, int lane) {
     const int i = lane & 15, cb = (lane >> 4) & 1, hf = lane >> 5;
     const int chunk = 2 * cb + ((i & 3) >> 1), sub = (i & 1) << 3;
     Frag f;
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
-        const char* base = img + part * IMG;
+        const int base = img + part * IMG;
         const int r0 = 16 * s + 4 * hf + (i >> 2), r1 = r0 + 8;
         const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(base + img_off(r0, chunk) + sub));
+            (__attribute__((address_space(3))) s16x4*)(smem + base + img_off(r0, chunk) + sub));
         const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(base + img_off(r1, chunk) + sub));
+            (__attribute__((address_space(3))) s16x4*)(smem + base + img_off(r1, chunk) + sub));
         const u32x2 a2 = __builtin_bit_cast(u32x2, a), b2 = __builtin_bit_cast(u32x2, b);
         const u32x4 v = {a2[0], a2[1], b2[0], b2[1]};
         if (part == 0) f.hi = v;
@@ -182,17 +189,16 @@ __device__ __forceinline__ Frag read_cols(const char* img, int s, int lane) {
 
 // Ws as MB swizzled [32][32] split-bf16 image pairs in LDS (same for every head): both passes
 // re-read their Ws fragments per tile instead of pinning 16 VGPRs per column block.
-__device__ __forceinline__ void stage_ws(char* wimg, const float* __restrict__ Ws, int M) {
+__device__ __forceinline__ void stage_ws(int wimg, const float* __restrict__ Ws, int M) {
     for (int e = threadIdx.x; e < M * 4; e += NTHR) {
         const int g = e >> 2, chunk = e & 3;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = Ws[g * kC + 8 * chunk + j];
         const Frag f = split8(v);
-        char* img = wimg + (g >> 5) * (2 * IMG);
-        const int off = img_off(g & 31, chunk);
-        *reinterpret_cast<u32x4*>(img + off) = f.hi;
-        *reinterpret_cast<u32x4*>(img + IMG + off) = f.lo;
+        const int off = wimg + (g >> 5) * (2 * IMG) + img_off(g & 31, chunk);
+        *reinterpret_cast<u32x4*>(smem + off) = f.hi;
+        *reinterpret_cast<u32x4*>(smem + off + IMG) = f.lo;
     }
 }
 
@@ -203,7 +209,6 @@ __global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ Ws, const float* __restrict__ bs,
     const float* __restrict__ wt, float bt, float base_temp, float c0, int N, int H,
     int tiles_per_chunk, float* __restrict__ parts) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int M = 32 * MB;
     constexpr int IPH = (IPW < MB) ? IPW : MB;  // items of one head handled by this wave
     constexpr int HPW = IPW / IPH;              // heads per wave
@@ -212,12 +217,11 @@ __global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
     const int n_tiles = (N + TN - 1) / TN;
     const int t_begin = blockIdx.x * tiles_per_chunk;
     const int t_end = min(n_tiles, t_begin + tiles_per_chunk);
+    // LDS (byte offsets): tile buffers [2][H][hi|lo] | s_n [2][H][32] | rescale scratch [NW][32] | Ws images
     const int buf_bytes = H * 2 * IMG;
-    char* bufs[2] = {smem, smem + buf_bytes};
-    float* sarr[2] = {reinterpret_cast<float*>(smem + 2 * buf_bytes),
-                      reinterpret_cast<float*>(smem + 2 * buf_bytes) + H * TN};
-    float* scratch = reinterpret_cast<float*>(smem + 2 * buf_bytes) + 2 * H * TN + wave * 32;
-    char* wimg = smem + 2 * buf_bytes + (2 * H * TN + NW * 32) * 4;  // [MB][hi|lo] images of Ws
+    const int sarr0 = 2 * buf_bytes, sarr_bytes = H * TN * 4;
+    const int scratch = sarr0 + 2 * sarr_bytes + wave * 32 * 4;
+    const int wimg = sarr0 + 2 * sarr_bytes + NW * 32 * 4;  // [MB][hi|lo] images of Ws
     const float* xb = x + (size_t)b * N * H * kC;
 
     Loader<LI> ld;
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
     const bool active = item0 < H * MB;
 
     ld.fetch(xb, H, t_begin * TN, N - t_begin * TN);
-    ld.stage(bufs[0], sarr[0], H, bt, base_temp);
+    ld.stage(0, sarr0, H, bt, base_temp);
     __syncthreads();
     int cur = 0;
     for (int t = t_begin; t < t_end; ++t) {
@@ -252,18 +256,19 @@ __global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
 #pragma unroll
             for (int hh = 0; hh < HPW; ++hh) {
                 const int h = (item0 + hh * IPH) / MB;
-                const char* img = bufs[cur] + h * (2 * IMG);
-                const float* sp = sarr[cur] + h * TN;
+                const int img = cur * buf_bytes + h * (2 * IMG);
+                const int sp = sarr0 + cur * sarr_bytes + 4 * (h * TN);
                 // rows of this lane's accumulator registers: n = (r&3) + 8(r>>2) + 4hf
                 f32x4 s4[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s4[i] = *reinterpret_cast<const f32x4*>(sp + 8 * i + 4 * hf);
+                for (int i = 0; i < 4; ++i)
+                    s4[i] = *reinterpret_cast<const f32x4*>(smem + sp + 4 * (8 * i + 4 * hf));
                 const Frag xa0 = read_rows(img, l31, hf), xa1 = read_rows(img, l31, 2 + hf);
                 const Frag xb0 = read_cols(img, 0, lane), xb1 = read_cols(img, 1, lane);
 #pragma unroll
                 for (int kk = 0; kk < IPH; ++kk) {
                     const int k = hh * IPH + kk;
-                    const char* wi = wimg + ((item0 + k) % MB) * (2 * IMG);
+                    const int wi = wimg + ((item0 + k) % MB) * (2 * IMG);
                     f32x16 Y;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) Y[r] = bias[k];
@@ -280,11 +285,11 @@ __global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
                         const float mn = fmaxf(m2[k], tmax);
                         const float a = __builtin_amdgcn_exp2f(m2[k] - mn);  // m2 = -inf -> 0
                         lsum[k] *= a;
-                        if (hf == 0) scratch[l31] = a;
+                        if (hf == 0) *reinterpret_cast<float*>(smem + scratch + 4 * l31) = a;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const f32x4 a4 = *reinterpret_cast<const f32x4*>(scratch + 8 * i + 4 * hf);
+                            const f32x4 a4 = *reinterpret_cast<const f32x4*>(smem + scratch + 4 * (8 * i + 4 * hf));
 #pragma unroll
                             for (int q = 0; q < 4; ++q) Z[k][4 * i + q] *= a4[q];
                         }
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
                 }
             }
         }
-        if (more) ld.stage(bufs[cur ^ 1], sarr[cur ^ 1], H, bt, base_temp);
+        if (more) ld.stage((cur ^ 1) * buf_bytes, sarr0 + (cur ^ 1) * sarr_bytes, H, bt, base_temp);
         __syncthreads();
         cur ^= 1;
     }
@@ -348,26 +353,24 @@ __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
     const float* __restrict__ wt, float bt, float base_temp, float c0,
     const float* __restrict__ col_max, const float* __restrict__ col_sum,
     const float* __restrict__ S2, int N, int H, int tiles_per_chunk, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int M = 32 * MB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y;
     const int n_tiles = (N + TN - 1) / TN;
     const int t_begin = blockIdx.x * tiles_per_chunk;
     const int t_end = min(n_tiles, t_begin + tiles_per_chunk);
+    // LDS (byte offsets): tile buffers | s_n [2][H][32] | bias [H][M] | m2 [H][M] | Ws images
     const int buf_bytes = H * 2 * IMG;
-    char* bufs[2] = {smem, smem + buf_bytes};
-    float* fl = reinterpret_cast<float*>(smem + 2 * buf_bytes);
-    float* sarr[2] = {fl, fl + H * TN};
-    float* biasL = fl + 2 * H * TN;  // [H][M]  bs - c0
-    float* m2L = biasL + H * M;      // [H][M]  col_max * log2e
-    char* wimg = reinterpret_cast<char*>(m2L + H * M);  // [MB][hi|lo] images of Ws
+    const int sarr0 = 2 * buf_bytes, sarr_bytes = H * TN * 4;
+    const int biasL = sarr0 + 2 * sarr_bytes;  // [H][M]  bs - c0
+    const int m2L = biasL + H * M * 4;         // [H][M]  col_max * log2e
+    const int wimg = m2L + H * M * 4;          // [MB][hi|lo] images of Ws
     const float* xb = x + (size_t)b * N * H * kC;
     float* ob = out + (size_t)b * N * H * kC;
 
     for (int i = threadIdx.x; i < H * M; i += NTHR) {
-        biasL[i] = bs[i % M] - c0;
-        m2L[i] = col_max[(size_t)b * H * M + i] * kLog2e;
+        *reinterpret_cast<float*>(smem + biasL + 4 * i) = bs[i % M] - c0;
+        *reinterpret_cast<float*>(smem + m2L + 4 * i) = col_max[(size_t)b * H * M + i] * kLog2e;
     }
     Loader<LI> ld;
     ld.init(wt);
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
     }
 
     ld.fetch(xb, H, t_begin * TN, N - t_begin * TN);
-    ld.stage(bufs[0], sarr[0], H, bt, base_temp);
+    ld.stage(0, sarr0, H, bt, base_temp);
     __syncthreads();
     int cur = 0;
     for (int t = t_begin; t < t_end; ++t) {
@@ -409,26 +412,26 @@ __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
         for (int hh = 0; hh < HPW; ++hh) {
             const int h = head0 + hh;
             if (h < H) {
-                const char* img = bufs[cur] + h * (2 * IMG);
-                const float sn = sarr[cur][h * TN + l31];
+                const int img = cur * buf_bytes + h * (2 * IMG);
+                const float sn = *reinterpret_cast<const float*>(smem + sarr0 + cur * sarr_bytes + 4 * (h * TN + l31));
                 const Frag x0 = read_rows(img, l31, hf), x1 = read_rows(img, l31, 2 + hf);
                 f32x16 O;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) O[r] = 0.f;
 #pragma unroll
                 for (int gb = 0; gb < MB; ++gb) {
-                    const float* bp = biasL + h * M + 32 * gb + 4 * hf;
-                    const float* mp = m2L + h * M + 32 * gb + 4 * hf;
+                    const int bp = biasL + 4 * (h * M + 32 * gb + 4 * hf);
+                    const int mp = m2L + 4 * (h * M + 32 * gb + 4 * hf);
                     f32x16 Y;
                     f32x4 m4[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + 8 * i);
-                        m4[i] = *reinterpret_cast<const f32x4*>(mp + 8 * i);
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(smem + bp + 32 * i);
+                        m4[i] = *reinterpret_cast<const f32x4*>(smem + mp + 32 * i);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) Y[4 * i + q] = b4[q];
                     }
-                    const char* wi = wimg + gb * (2 * IMG);
+                    const int wi = wimg + gb * (2 * IMG);
                     Y = mfma3(read_rows(wi, l31, hf), x0, Y);  // Yt[g,n]: rows g in regs, point on the lane
                     Y = mfma3(read_rows(wi, l31, 2 + hf), x1, Y);
                     float p0[8], p1[8];
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
                 }
             }
         }
-        if (more) ld.stage(bufs[cur ^ 1], sarr[cur ^ 1], H, bt, base_temp);
+        if (more) ld.stage((cur ^ 1) * buf_bytes, sarr0 + (cur ^ 1) * sarr_bytes, H, bt, base_temp);
         __syncthreads();
         cur ^= 1;
     }
