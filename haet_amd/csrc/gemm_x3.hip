@@ -6,11 +6,11 @@
 // (hi*hi + hi*lo + lo*hi, fp32 accumulate, ~2^-16 operand error) runs on the bf16 matrix cores
 // at 3 MFMAs per fp32 product and makes the GEMM HBM-bound again (2 * K * 4 B per point).
 //
-// Workgroup = 128 rows x BN columns, 8 waves as 2 (rows) x 4 (columns); K is walked in 32-wide
-// tiles: x tile fp32 -> {hi, lo} bf16 in the loader, W comes pre-split (haet_split_bf16, done
-// once per weight version), both as swizzled [32][32] bf16 LDS images read with ds_read_b128.
-// Loads of k-tile t+1 are issued into registers before the MFMAs of tile t (2 WGs per CU
-// interleave the rest).
+// Workgroup tile = 128 rows x BN columns, 8 waves as 2 (rows) x 4 (columns); K is walked in
+// 32-wide tiles: x tile fp32 -> {hi, lo} bf16 in the loader, W comes pre-split (haet_split_bf16,
+// done once per weight version), both as swizzled [32][32] bf16 LDS images read with
+// ds_read_b128.  Persistent workgroups with a 3-deep (x) / 2-deep (W) register prefetch keep the
+// HBM stream full across row tiles (see the kernel).
 #include "common.h"
 
 namespace haet {
@@ -37,13 +37,6 @@ __device__ __forceinline__ int g_off(int row, int chunk) {
 struct GFrag {
     u32x4 hi, lo;
 };
-__device__ __forceinline__ GFrag g_read(const char* img, int row, int chunk) {
-    GFrag f;
-    const int off = g_off(row, chunk);
-    f.hi = *reinterpret_cast<const u32x4*>(img + off);
-    f.lo = *reinterpret_cast<const u32x4*>(img + GIMG + off);
-    return f;
-}
 __device__ __forceinline__ f32x16 g_mfma3(const GFrag& a, const GFrag& b, f32x16 c) {
     const bf16x8 ah = __builtin_bit_cast(bf16x8, a.hi), al = __builtin_bit_cast(bf16x8, a.lo);
     const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi), bl = __builtin_bit_cast(bf16x8, b.lo);
@@ -71,124 +64,185 @@ __global__ void split_bf16_kernel(const float* __restrict__ w, size_t n, unsigne
     }
 }
 
-// NCB = BN / 32 column blocks per workgroup (8 -> BN = 256, 4 -> BN = 128)
+// LDS by byte offset only (generic pointers to LDS turn into flat_* accesses, which wait for
+// the global prefetch too).
+extern __shared__ __attribute__((aligned(16))) char gsm[];
+
+__device__ __forceinline__ GFrag g_read(int img, int row, int chunk) {
+    GFrag f;
+    const int off = img + g_off(row, chunk);
+    f.hi = *reinterpret_cast<const u32x4*>(gsm + off);
+    f.lo = *reinterpret_cast<const u32x4*>(gsm + off + GIMG);
+    return f;
+}
+
+// NCB = BN / 32 column blocks per workgroup (8 -> BN = 256, 4 -> BN = 128).
+// Persistent workgroups (one per CU: 8 waves, ~170 VGPRs) walk a flattened stream of
+// (row tile, k-tile) items.  The x loads of item i+3 and the W loads of item i+2 are issued into
+// named register sets while item i is multiplied, so ~48 KB of x per CU are always in flight
+// (HBM latency x per-CU bandwidth ~ 40-50 KB) and the stream never drains at a row-tile boundary.
 template <int NCB>
-__global__ __launch_bounds__(512, 4) void gemm_x3_kernel(
+__global__ __launch_bounds__(512) void gemm_x3_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ Whi,
     const unsigned short* __restrict__ Wlo, const float* __restrict__ bias, int Nrows, int K, int O,
-    float* __restrict__ out) {
+    int n_row_tiles, float* __restrict__ out) {
     constexpr int BN = 32 * NCB;
     constexpr int WCB = NCB / 4;  // column blocks per wave (4 waves across the columns)
-    constexpr int XIMGS = GBM / 32, WLD = (NCB * 4) / 2;  // 16-B W chunks per thread per plane... see below
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ximg = smem;                       // [4 row blocks][hi|lo][2048]
-    char* wimg = smem + XIMGS * 2 * GIMG;    // [NCB col blocks][hi|lo][2048]
+    constexpr int WPT = NCB / 4;  // 16-B W chunks per thread per plane and k-tile
+    constexpr int XIMG = 0, WIMG = (GBM / 32) * 2 * GIMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 2, wn = wave & 3;
-    const int row0 = blockIdx.x * GBM, col0 = blockIdx.y * BN;
-    (void)WLD;
+    const int col0 = blockIdx.y * BN;
+    const int nkt = K / GBK;
+    const int my_tiles = n_row_tiles > (int)blockIdx.x ? (n_row_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int total = my_tiles * nkt;
+    if (total == 0) return;
 
     // loader geometry: x tile = 128 rows x 8 chunks(16 B) -> 2 chunks per thread
-    int xrow[2], xq[2];
-    const float* xp[2];
+    const int xrow0 = tid >> 3, xq = tid & 7;  // second chunk: row + 64
+    const int wrow0 = tid >> 2, wch = tid & 3; // W chunk i: row + 128 i
+    const int x_st0 = XIMG + (xrow0 >> 5) * (2 * GIMG) + g_off(xrow0 & 31, xq >> 1) + ((xq & 1) << 3);
+    const int x_st1 = x_st0 + 2 * (2 * GIMG);  // row + 64 -> two row blocks further, same (row & 31)
+    int w_st[WPT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int e = tid + 512 * i;
-        xrow[i] = e >> 3;
-        xq[i] = e & 7;
-        const int gr = min(row0 + xrow[i], Nrows - 1);
-        xp[i] = x + (size_t)gr * K + 4 * xq[i];
-    }
-    // W tile = BN rows x 4 chunks(16 B of bf16) per plane -> NCB/4 chunks per thread per plane
-    constexpr int WPT = NCB / 4;
-    int wrow[WPT], wch[WPT];
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-        const int e = tid + 512 * i;
-        wrow[i] = e >> 2;
-        wch[i] = e & 3;
-    }
+    for (int i = 0; i < WPT; ++i)
+        w_st[i] = WIMG + ((wrow0 + 128 * i) >> 5) * (2 * GIMG) + g_off(wrow0 & 31, wch);
 
     f32x16 acc[2][WCB];
+    float bv[WCB];  // bias of this lane's output columns: loaded (and waited for) once, up front
+#pragma unroll
+    for (int j = 0; j < WCB; ++j) bv[j] = bias ? bias[col0 + 32 * (WCB * wn + j) + l31] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < WCB; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = bv[j];  // accumulate on top of the bias
 
-    f32x4 xr[2];
-    u32x4 whr[WPT], wlr[WPT];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) xr[i] = *reinterpret_cast<const f32x4*>(xp[i] + k0);
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const size_t o = ((size_t)(col0 + wrow[i]) * K + k0 + 8 * wch[i]);
-            whr[i] = *reinterpret_cast<const u32x4*>(Whi + o);
-            wlr[i] = *reinterpret_cast<const u32x4*>(Wlo + o);
+    // fetch streams (x three items ahead, W two items ahead), each with its own (tile, kt) cursor
+    f32x4 xs0[2], xs1[2], xs2[2];
+    u32x4 ws0[2 * WPT], ws1[2 * WPT];
+    int fx_tile = blockIdx.x, fx_kt = 0, fx_it = 0;
+    int fw_kt = 0, fw_it = 0;
+    auto fetch_x = [&](f32x4 (&d)[2]) {
+        if (fx_it < total) {
+            const int r0 = min(fx_tile * GBM + xrow0, Nrows - 1), r1 = min(fx_tile * GBM + xrow0 + 64, Nrows - 1);
+            d[0] = *reinterpret_cast<const f32x4*>(x + (size_t)r0 * K + fx_kt * GBK + 4 * xq);
+            d[1] = *reinterpret_cast<const f32x4*>(x + (size_t)r1 * K + fx_kt * GBK + 4 * xq);
+        }
+        ++fx_it;
+        if (++fx_kt == nkt) {
+            fx_kt = 0;
+            fx_tile += gridDim.x;
         }
     };
-    auto stage = [&]() {
+    auto fetch_w = [&](u32x4 (&d)[2 * WPT]) {
+        if (fw_it < total) {
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const size_t o = (size_t)(col0 + wrow0 + 128 * i) * K + fw_kt * GBK + 8 * wch;
+                d[2 * i] = *reinterpret_cast<const u32x4*>(Whi + o);
+                d[2 * i + 1] = *reinterpret_cast<const u32x4*>(Wlo + o);
+            }
+        }
+        ++fw_it;
+        if (++fw_kt == nkt) fw_kt = 0;
+    };
+    auto stage = [&](const f32x4 (&xv)[2], const u32x4 (&wv)[2 * WPT]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const f32x4 v = xr[i];
+            const f32x4 v = xv[i];
             const unsigned h01 = g_pack(v[0], v[1]), h23 = g_pack(v[2], v[3]);
             const u32x2 hi = {h01, h23};
             const u32x2 lo = {g_pack(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u)),
                               g_pack(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u))};
-            char* img = ximg + (xrow[i] >> 5) * (2 * GIMG);
-            const int off = g_off(xrow[i] & 31, xq[i] >> 1) + ((xq[i] & 1) << 3);
-            *reinterpret_cast<u32x2*>(img + off) = hi;
-            *reinterpret_cast<u32x2*>(img + GIMG + off) = lo;
+            const int off = i ? x_st1 : x_st0;
+            *reinterpret_cast<u32x2*>(gsm + off) = hi;
+            *reinterpret_cast<u32x2*>(gsm + off + GIMG) = lo;
         }
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            char* img = wimg + (wrow[i] >> 5) * (2 * GIMG);
-            const int off = g_off(wrow[i] & 31, wch[i]);
-            *reinterpret_cast<u32x4*>(img + off) = whr[i];
-            *reinterpret_cast<u32x4*>(img + GIMG + off) = wlr[i];
+            *reinterpret_cast<u32x4*>(gsm + w_st[i]) = wv[2 * i];
+            *reinterpret_cast<u32x4*>(gsm + w_st[i] + GIMG) = wv[2 * i + 1];
         }
     };
-
-    const int nkt = K / GBK;
-    fetch(0);
-    stage();
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) fetch((kt + 1) * GBK);
+    int c_tile = blockIdx.x, c_kt = 0;
+    auto compute = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             GFrag a[2], b[WCB];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = g_read(ximg + (2 * wm + i) * (2 * GIMG), l31, hf + 2 * ks);
+            for (int i = 0; i < 2; ++i) a[i] = g_read(XIMG + (2 * wm + i) * (2 * GIMG), l31, hf + 2 * ks);
 #pragma unroll
-            for (int j = 0; j < WCB; ++j) b[j] = g_read(wimg + (WCB * wn + j) * (2 * GIMG), l31, hf + 2 * ks);
+            for (int j = 0; j < WCB; ++j) b[j] = g_read(WIMG + (WCB * wn + j) * (2 * GIMG), l31, hf + 2 * ks);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < WCB; ++j) acc[i][j] = g_mfma3(a[i], b[j], acc[i][j]);
         }
-        __syncthreads();
-        if (kt + 1 < nkt) {
-            stage();
-            __syncthreads();
-        }
-    }
-    // epilogue: lane = output column, registers = rows
+        if (++c_kt == nkt) {  // row tile finished: lane = output column, registers = rows
+            const int row0 = c_tile * GBM;
+            const bool full = row0 + GBM <= Nrows;  // wave-uniform: no per-store branch (a branch per
+            // store made hipcc wait vmcnt(0) -- prefetch stream included -- before every store)
 #pragma unroll
-    for (int j = 0; j < WCB; ++j) {
-        const int col = col0 + 32 * (WCB * wn + j) + l31;
-        const float bv = bias ? bias[col] : 0.f;
+            for (int j = 0; j < WCB; ++j) {
+                float* oc = out + (size_t)(row0 + 64 * wm + 4 * hf) * O + col0 + 32 * (WCB * wn + j) + l31;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < 2; ++i) {
+                    if (full) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                if (row < Nrows) out[(size_t)row * O + col] = acc[i][j][r] + bv;
+                        for (int r = 0; r < 16; ++r)
+                            oc[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * O] = acc[i][j][r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rr = 32 * i + (r & 3) + 8 * (r >> 2);
+                            if (row0 + 64 * wm + 4 * hf + rr < Nrows) oc[(size_t)rr * O] = acc[i][j][r];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = bv[j];
+                }
             }
+            c_kt = 0;
+            c_tile += gridDim.x;
         }
+    };
+
+    // prologue: x items 0,1,2 and W items 0,1 in flight; item 0 staged; then x item 3 / W item 2
+    fetch_x(xs0);
+    fetch_x(xs1);
+    fetch_x(xs2);
+    fetch_w(ws0);
+    fetch_w(ws1);
+    stage(xs0, ws0);
+    fetch_x(xs0);
+    fetch_w(ws0);
+    __syncthreads();
+    // steady state, unrolled by 6 so that the register sets are statically named:
+    // item it+1 is staged from x set (it+1)%3 and W set (it+1)%2, which are then refilled with
+    // items it+4 (x) and it+3 (W)
+#define GEMM_STEP(XS, WS)                    \
+    if (it < total) {                        \
+        compute();                           \
+        __syncthreads();                     \
+        if (it + 1 < total) {                \
+            stage(XS, WS);                   \
+            fetch_x(XS);                     \
+            fetch_w(WS);                     \
+        }                                    \
+        __syncthreads();                     \
+        ++it;                                \
     }
+    for (int it = 0; it < total;) {
+        GEMM_STEP(xs1, ws1)
+        GEMM_STEP(xs2, ws0)
+        GEMM_STEP(xs0, ws1)
+        GEMM_STEP(xs1, ws0)
+        GEMM_STEP(xs2, ws1)
+        GEMM_STEP(xs0, ws0)
+    }
+#undef GEMM_STEP
 }
 
 }  // namespace haet
@@ -214,17 +268,19 @@ extern "C" int haet_linear_fwd(const float* x, const uint16_t* W_hi, const uint1
     if (!x || !W_hi || !W_lo || !out || Nrows < 1) return fail(HAET_E_ARG, "linear_fwd: bad arguments");
     if (!haet_linear_supported(K, O))
         return fail(HAET_E_ARG, "linear_fwd: K=%d (multiple of 32) / O=%d (multiple of 128) unsupported", K, O);
-    const int gx = (Nrows + GBM - 1) / GBM;
+    const int tiles = (Nrows + GBM - 1) / GBM;
     if (O % 256 == 0) {
+        const int ny = O / 256;
+        const int gx = tiles < 256 / ny ? tiles : (256 / ny > 0 ? 256 / ny : 1);  // one workgroup per CU
         const size_t lds = (GBM / 32 + 8) * 2 * GIMG;
-        auto kern = gemm_x3_kernel<8>;
-        hipLaunchKernelGGL(kern, dim3(gx, O / 256), dim3(512), lds, as_stream(stream), x, W_hi, W_lo,
-                           bias, Nrows, K, O, out);
+        hipLaunchKernelGGL(gemm_x3_kernel<8>, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi,
+                           W_lo, bias, Nrows, K, O, tiles, out);
     } else {
+        const int ny = O / 128;
+        const int gx = tiles < 256 / ny ? tiles : (256 / ny > 0 ? 256 / ny : 1);
         const size_t lds = (GBM / 32 + 4) * 2 * GIMG;
-        auto kern = gemm_x3_kernel<4>;
-        hipLaunchKernelGGL(kern, dim3(gx, O / 128), dim3(512), lds, as_stream(stream), x, W_hi, W_lo,
-                           bias, Nrows, K, O, out);
+        hipLaunchKernelGGL(gemm_x3_kernel<4>, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi,
+                           W_lo, bias, Nrows, K, O, tiles, out);
     }
     return check_launch("gemm_x3_kernel");
 }
