@@ -90,6 +90,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     constexpr int WCB = NCB / 4;  // column blocks per wave (4 waves across the columns)
     constexpr int WPT = NCB / 4;  // 16-B W chunks per thread per plane and k-tile
     constexpr int XIMG = 0, WIMG = (GBM / 32) * 2 * GIMG;
+    constexpr int BUF = (GBM / 32 + NCB) * 2 * GIMG;  // one (x tile, W tile) LDS buffer; two of them
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 2, wn = wave & 3;
     const int col0 = blockIdx.y * BN;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
         ++fw_it;
         if (++fw_kt == nkt) fw_kt = 0;
     };
-    auto stage = [&](const f32x4 (&xv)[2], const u32x4 (&wv)[2 * WPT]) {
+    auto stage = [&](int buf, const f32x4 (&xv)[2], const u32x4 (&wv)[2 * WPT]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const f32x4 v = xv[i];
@@ -156,25 +157,25 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
             const u32x2 hi = {h01, h23};
             const u32x2 lo = {g_pack(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u)),
                               g_pack(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u))};
-            const int off = i ? x_st1 : x_st0;
+            const int off = buf + (i ? x_st1 : x_st0);
             *reinterpret_cast<u32x2*>(gsm + off) = hi;
             *reinterpret_cast<u32x2*>(gsm + off + GIMG) = lo;
         }
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            *reinterpret_cast<u32x4*>(gsm + w_st[i]) = wv[2 * i];
-            *reinterpret_cast<u32x4*>(gsm + w_st[i] + GIMG) = wv[2 * i + 1];
+            *reinterpret_cast<u32x4*>(gsm + buf + w_st[i]) = wv[2 * i];
+            *reinterpret_cast<u32x4*>(gsm + buf + w_st[i] + GIMG) = wv[2 * i + 1];
         }
     };
     int c_tile = blockIdx.x, c_kt = 0;
-    auto compute = [&]() {
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             GFrag a[2], b[WCB];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = g_read(XIMG + (2 * wm + i) * (2 * GIMG), l31, hf + 2 * ks);
+            for (int i = 0; i < 2; ++i) a[i] = g_read(buf + XIMG + (2 * wm + i) * (2 * GIMG), l31, hf + 2 * ks);
 #pragma unroll
-            for (int j = 0; j < WCB; ++j) b[j] = g_read(WIMG + (WCB * wn + j) * (2 * GIMG), l31, hf + 2 * ks);
+            for (int j = 0; j < WCB; ++j) b[j] = g_read(buf + WIMG + (WCB * wn + j) * (2 * GIMG), l31, hf + 2 * ks);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -215,24 +216,24 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     fetch_x(xs2);
     fetch_w(ws0);
     fetch_w(ws1);
-    stage(xs0, ws0);
+    stage(0, xs0, ws0);
     fetch_x(xs0);
     fetch_w(ws0);
     __syncthreads();
-    // steady state, unrolled by 6 so that the register sets are statically named:
-    // item it+1 is staged from x set (it+1)%3 and W set (it+1)%2, which are then refilled with
-    // items it+4 (x) and it+3 (W)
-#define GEMM_STEP(XS, WS)                    \
-    if (it < total) {                        \
-        compute();                           \
-        __syncthreads();                     \
-        if (it + 1 < total) {                \
-            stage(XS, WS);                   \
-            fetch_x(XS);                     \
-            fetch_w(WS);                     \
-        }                                    \
-        __syncthreads();                     \
-        ++it;                                \
+    // steady state, unrolled by 6 so that the register sets are statically named.  Two LDS buffers,
+    // ONE barrier per item: item it+1 is staged (from x set (it+1)%3 / W set (it+1)%2, which are then
+    // refilled with items it+4 / it+3) into the other buffer BEFORE item it is multiplied, so the
+    // two waves of a SIMD overlap one's staging VALU with the other's MFMAs.
+#define GEMM_STEP(XS, WS)                                \
+    if (it < total) {                                    \
+        if (it + 1 < total) {                            \
+            stage(((it + 1) & 1) * BUF, XS, WS);         \
+            fetch_x(XS);                                 \
+            fetch_w(WS);                                 \
+        }                                                \
+        compute((it & 1) * BUF);                         \
+        __syncthreads();                                 \
+        ++it;                                            \
     }
     for (int it = 0; it < total;) {
         GEMM_STEP(xs1, ws1)
@@ -272,13 +273,20 @@ extern "C" int haet_linear_fwd(const float* x, const uint16_t* W_hi, const uint1
     if (O % 256 == 0) {
         const int ny = O / 256;
         const int gx = tiles < 256 / ny ? tiles : (256 / ny > 0 ? 256 / ny : 1);  // one workgroup per CU
-        const size_t lds = (GBM / 32 + 8) * 2 * GIMG;
+        const size_t lds = 2 * (GBM / 32 + 8) * 2 * GIMG;
+        static thread_local bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<8>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail(HAET_E_LAUNCH, "linear_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr = true;
+        }
         hipLaunchKernelGGL(gemm_x3_kernel<8>, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi,
                            W_lo, bias, Nrows, K, O, tiles, out);
     } else {
         const int ny = O / 128;
         const int gx = tiles < 256 / ny ? tiles : (256 / ny > 0 ? 256 / ny : 1);
-        const size_t lds = (GBM / 32 + 4) * 2 * GIMG;
+        const size_t lds = 2 * (GBM / 32 + 4) * 2 * GIMG;
         hipLaunchKernelGGL(gemm_x3_kernel<4>, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi,
                            W_lo, bias, Nrows, K, O, tiles, out);
     }
