@@ -123,13 +123,19 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     // fetch streams (x three items ahead, W two items ahead), each with its own (tile, kt) cursor
     f32x4 xs0[2], xs1[2], xs2[2];
     u32x4 ws0[2 * WPT], ws1[2 * WPT];
+    // Every workgroup walks K in a rotated order (start at k-tile blockIdx % nkt): with all CUs on the
+    // same k-tile at the same time, every access hits bytes [128 kt, 128 kt + 128) of a 1 KB row,
+    // i.e. the same 1/8 of the address-interleaved HBM channels.
+    const int krot = blockIdx.x % nkt;
     int fx_tile = blockIdx.x, fx_kt = 0, fx_it = 0;
     int fw_kt = 0, fw_it = 0;
     auto fetch_x = [&](f32x4 (&d)[2]) {
         if (fx_it < total) {
             const int r0 = min(fx_tile * GBM + xrow0, Nrows - 1), r1 = min(fx_tile * GBM + xrow0 + 64, Nrows - 1);
-            d[0] = *reinterpret_cast<const f32x4*>(x + (size_t)r0 * K + fx_kt * GBK + 4 * xq);
-            d[1] = *reinterpret_cast<const f32x4*>(x + (size_t)r1 * K + fx_kt * GBK + 4 * xq);
+            int kk = fx_kt + krot;
+            kk = (kk >= nkt ? kk - nkt : kk) * GBK;
+            d[0] = *reinterpret_cast<const f32x4*>(x + (size_t)r0 * K + kk + 4 * xq);
+            d[1] = *reinterpret_cast<const f32x4*>(x + (size_t)r1 * K + kk + 4 * xq);
         }
         ++fx_it;
         if (++fx_kt == nkt) {
@@ -140,8 +146,11 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     auto fetch_w = [&](u32x4 (&d)[2 * WPT]) {
         if (fw_it < total) {
 #pragma unroll
+            int kk = fw_kt + krot;
+            kk = (kk >= nkt ? kk - nkt : kk) * GBK;
+#pragma unroll
             for (int i = 0; i < WPT; ++i) {
-                const size_t o = (size_t)(col0 + wrow0 + 128 * i) * K + fw_kt * GBK + 8 * wch;
+                const size_t o = (size_t)(col0 + wrow0 + 128 * i) * K + kk + 8 * wch;
                 d[2 * i] = *reinterpret_cast<const u32x4*>(Whi + o);
                 d[2 * i + 1] = *reinterpret_cast<const u32x4*>(Wlo + o);
             }
