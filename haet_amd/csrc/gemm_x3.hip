@@ -145,7 +145,6 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     };
     auto fetch_w = [&](u32x4 (&d)[2 * WPT]) {
         if (fw_it < total) {
-#pragma unroll
             int kk = fw_kt + krot;
             kk = (kk >= nkt ? kk - nkt : kk) * GBK;
 #pragma unroll
