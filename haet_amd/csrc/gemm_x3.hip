@@ -109,29 +109,16 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     for (int i = 0; i < WPT; ++i)
         w_st[i] = WIMG + ((wrow0 + 128 * i) >> 5) * (2 * GIMG) + g_off(wrow0 & 31, wch);
 
-    // The product is formed TRANSPOSED (A operand = W rows, B operand = x rows): the accumulator
-    // then has the point on the lane and 4 consecutive output columns in 4 consecutive registers,
-    // so the epilogue is 16-B stores (16 per wave and row tile instead of 64 dword stores: the
-    // dword version was store-issue-bound).  The bias is a per-register constant: kept in LDS.
     f32x16 acc[2][WCB];
-    constexpr int BIAS = 2 * BUF;  // [BN] floats behind the two tile buffers
-    for (int i = tid; i < BN; i += 512)
-        *reinterpret_cast<float*>(gsm + BIAS + 4 * i) = bias ? bias[col0 + i] : 0.f;
-    __syncthreads();
-    auto init_acc = [&]() {
+    float bv[WCB];  // bias of this lane's output columns: loaded (and waited for) once, up front
 #pragma unroll
-        for (int j = 0; j < WCB; ++j) {
+    for (int j = 0; j < WCB; ++j) bv[j] = bias ? bias[col0 + 32 * (WCB * wn + j) + l31] : 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(gsm + BIAS + 4 * (32 * (WCB * wn + j) + 8 * q + 4 * hf));
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < WCB; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = b4[e];
-            }
-        }
-    };
-    init_acc();
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = bv[j];  // accumulate on top of the bias
 
     // fetch streams (x three items ahead, W two items ahead), each with its own (tile, kt) cursor
     f32x4 xs0[2], xs1[2], xs2[2];
@@ -200,27 +187,32 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < WCB; ++j) acc[i][j] = g_mfma3(b[j], a[i], acc[i][j]);  // out^T tile
+                for (int j = 0; j < WCB; ++j) acc[i][j] = g_mfma3(a[i], b[j], acc[i][j]);
         }
-        if (++c_kt == nkt) {  // row tile finished: lane = point, registers = output columns
+        if (++c_kt == nkt) {  // row tile finished: lane = output column, registers = rows
             const int row0 = c_tile * GBM;
-            const bool full = row0 + GBM <= Nrows;  // wave-uniform fast path: no per-store branches
+            const bool full = row0 + GBM <= Nrows;  // wave-uniform: no per-store branch (a branch per
+            // store made hipcc wait vmcnt(0) -- prefetch stream included -- before every store)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = row0 + 64 * wm + 32 * i + l31;
-                float* orow = out + (size_t)row * O + col0 + 32 * WCB * wn + 4 * hf;
-                if (full || row < Nrows) {
+            for (int j = 0; j < WCB; ++j) {
+                float* oc = out + (size_t)(row0 + 64 * wm + 4 * hf) * O + col0 + 32 * (WCB * wn + j) + l31;
 #pragma unroll
-                    for (int j = 0; j < WCB; ++j)
+                for (int i = 0; i < 2; ++i) {
+                    if (full) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
-                                             acc[i][j][4 * q + 3]};
-                            *reinterpret_cast<f32x4*>(orow + 32 * j + 8 * q) = v;
+                        for (int r = 0; r < 16; ++r)
+                            oc[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * O] = acc[i][j][r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rr = 32 * i + (r & 3) + 8 * (r >> 2);
+                            if (row0 + 64 * wm + 4 * hf + rr < Nrows) oc[(size_t)rr * O] = acc[i][j][r];
                         }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = bv[j];
                 }
             }
-            init_acc();
             c_kt = 0;
             c_tile += gridDim.x;
         }
@@ -289,7 +281,7 @@ extern "C" int haet_linear_fwd(const float* x, const uint16_t* W_hi, const uint1
     if (O % 256 == 0) {
         const int ny = O / 256;
         const int gx = tiles < 256 / ny ? tiles : (256 / ny > 0 ? 256 / ny : 1);  // one workgroup per CU
-        const size_t lds = 2 * (GBM / 32 + 8) * 2 * GIMG + 256 * 4;
+        const size_t lds = 2 * (GBM / 32 + 8) * 2 * GIMG;
         static thread_local bool attr = false;
         if (!attr) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<8>),
@@ -302,7 +294,7 @@ extern "C" int haet_linear_fwd(const float* x, const uint16_t* W_hi, const uint1
     } else {
         const int ny = O / 128;
         const int gx = tiles < 256 / ny ? tiles : (256 / ny > 0 ? 256 / ny : 1);
-        const size_t lds = 2 * (GBM / 32 + 4) * 2 * GIMG + 128 * 4;
+        const size_t lds = 2 * (GBM / 32 + 4) * 2 * GIMG;
         hipLaunchKernelGGL(gemm_x3_kernel<4>, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi,
                            W_lo, bias, Nrows, K, O, tiles, out);
     }
