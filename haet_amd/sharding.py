@@ -17,6 +17,11 @@ def allgather_records(local_record: torch.Tensor, group=None) -> torch.Tensor:
     """[rec] on each rank -> [R, rec] in rank order on every rank."""
     world = dist.get_world_size(group)
     flat = local_record.contiguous().reshape(-1)
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        # test configuration only (several ranks sharing one GPU): gloo moves host memory
+        host = torch.empty(world * flat.numel(), dtype=flat.dtype)
+        dist.all_gather_into_tensor(host, flat.cpu(), group=group)
+        return host.to(flat.device).view(world, flat.numel())
     out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
     dist.all_gather_into_tensor(out, flat, group=group)  # flat output: accepted by RCCL and gloo
     return out.view(world, flat.numel())
