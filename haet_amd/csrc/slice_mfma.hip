@@ -149,8 +149,9 @@ struct Loader {
                 const int img = buf + h * (2 * IMG);
                 *reinterpret_cast<u32x2*>(smem + img + off) = hi;
                 *reinterpret_cast<u32x2*>(smem + img + IMG + off) = lo;
-                if (q8 == 0)
-                    *reinterpret_cast<float*>(smem + sarr + 4 * (h * TN + row)) = kLog2e / ada_temp(t + bt, base_temp);
+                if (q8 == 0)  // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division
+                    *reinterpret_cast<float*>(smem + sarr + 4 * (h * TN + row)) =
+                        kLog2e * __builtin_amdgcn_rcpf(ada_temp(t + bt, base_temp));
             }
         }
     }
@@ -274,15 +275,23 @@ __global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
                     for (int r = 0; r < 16; ++r) Y[r] = bias[k];
                     Y = mfma3(xa0, read_rows(wi, l31, hf), Y);
                     Y = mfma3(xa1, read_rows(wi, l31, 2 + hf), Y);
+                    // p = exp2(Y s_n - m2): one fma + one v_exp per element.  The running maximum is a
+                    // deferred REFERENCE: only when some exponent exceeds 2^20 (or on the first tile,
+                    // m2 = -inf) is it raised and Z, l rescaled (rare; recomputes the exponents).
+                    float p[16];
                     float tmax = -INFINITY;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        Y[r] *= s4[r >> 2][r & 3];
-                        tmax = fmaxf(tmax, Y[r]);
+                        p[r] = fmaf(Y[r], s4[r >> 2][r & 3], -m2[k]);
+                        tmax = fmaxf(tmax, p[r]);
                     }
                     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-                    if (__any(tmax > m2[k] + kThr2)) {  // deferred rescale (rare)
-                        const float mn = fmaxf(m2[k], tmax);
+                    if (__any(tmax > kThr2)) {
+                        float zmax = -INFINITY;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) zmax = fmaxf(zmax, Y[r] * s4[r >> 2][r & 3]);
+                        zmax = fmaxf(zmax, __shfl_xor(zmax, 32));
+                        const float mn = fmaxf(m2[k], zmax);
                         const float a = __builtin_amdgcn_exp2f(m2[k] - mn);  // m2 = -inf -> 0
                         lsum[k] *= a;
                         if (hf == 0) *reinterpret_cast<float*>(smem + scratch + 4 * l31) = a;
@@ -295,11 +304,13 @@ __global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         m2[k] = mn;
-                    }
-                    float p[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(Y[r] - m2[k]);
-                    if (nvalid < TN) {
+                        for (int r = 0; r < 16; ++r) p[r] = fmaf(Y[r], s4[r >> 2][r & 3], -mn);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(p[r]);
+                    if (nvalid < TN) {  // last tile only; the asm keeps it a branch (no per-element selects)
+                        asm volatile("" ::: "memory");
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
                             if ((r & 3) + 8 * (r >> 2) + 4 * hf >= nvalid) p[r] = 0.f;
