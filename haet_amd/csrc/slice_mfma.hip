@@ -98,39 +98,51 @@ __device__ __forceinline__ float dpp(float v) {
 }
 
 // ----------------------------------------------------------------------------- tile loader
-// LI = ceil(H/2): 16-B chunks per thread per tile (32 rows x H*8 chunks / 512 threads)
+// LI = ceil(H/2): 16-B chunks per thread per tile (32 rows x H*8 chunks / 512 threads).
+// Everything that does not change from tile to tile is computed once in init(): the row / head of
+// each chunk, its LDS offsets, its global pointer (advanced by one tile per fetch).
 template <int LI>
 struct Loader {
     f32x4 xr[LI];
     float wt4[4];
-    int q8;  // chunk index inside the head: c0 = 4*q8
+    const float* src[LI];  // next tile's source of chunk i
+    int row[LI];           // row inside the tile (>= TN: chunk unused for this H)
+    int loff[LI];          // byte offset of the hi 8-B piece inside a tile buffer
+    int soff[LI];          // byte offset of s_n inside an s array (q8 == 0 lanes)
+    int q8;                // chunk index inside the head: c0 = 4*q8
+    size_t tile_stride;    // floats per tile (32 rows)
 
-    __device__ __forceinline__ void init(const float* __restrict__ wt) {
+    __device__ __forceinline__ void init(const float* __restrict__ wt, const float* xb, int H, int row0) {
         q8 = threadIdx.x & 7;
+        const int cpr = H * 8;  // chunks per row
+        tile_stride = (size_t)TN * cpr * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) wt4[i] = wt[4 * q8 + i];
-    }
-    // issue the global loads of one tile (rows >= nvalid read as zero)
-    __device__ __forceinline__ void fetch(const float* __restrict__ xb, int H, int row0, int nvalid) {
-        const int cpr = H * 8;  // chunks per row
 #pragma unroll
         for (int i = 0; i < LI; ++i) {
             const int e = threadIdx.x + NTHR * i;
-            const int row = e / cpr, q = e - row * cpr;
+            const int r = e / cpr, q = e - r * cpr, h = q >> 3;
+            row[i] = r;
+            src[i] = xb + ((size_t)(row0 + r) * cpr + q) * 4;
+            loff[i] = h * (2 * IMG) + img_off(r & (TN - 1), q8 >> 1) + ((q8 & 1) << 3);
+            soff[i] = 4 * (h * TN + (r & (TN - 1)));
+        }
+    }
+    // issue the global loads of the next tile (rows >= nvalid read as zero)
+    __device__ __forceinline__ void fetch(int nvalid) {
+#pragma unroll
+        for (int i = 0; i < LI; ++i) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < TN && row < nvalid)
-                v = *reinterpret_cast<const f32x4*>(xb + ((size_t)(row0 + row) * cpr + q) * 4);
+            if (row[i] < TN && row[i] < nvalid) v = *reinterpret_cast<const f32x4*>(src[i]);
             xr[i] = v;
+            src[i] += tile_stride;
         }
     }
     // split to bf16 hi/lo, write the LDS images, reduce Ada-Temp and write s_n = log2e / tau
-    __device__ __forceinline__ void stage(int buf, int sarr, int H, float bt, float base_temp) {
-        const int cpr = H * 8;
+    __device__ __forceinline__ void stage(int buf, int sarr, float bt, float base_temp) {
 #pragma unroll
         for (int i = 0; i < LI; ++i) {
-            const int e = threadIdx.x + NTHR * i;
-            const int row = e / cpr, q = e - row * cpr;
-            if (row < TN) {
+            if (row[i] < TN) {
                 const f32x4 v = xr[i];
                 float t = v[0] * wt4[0];
                 t = fmaf(v[1], wt4[1], t);
@@ -139,18 +151,15 @@ struct Loader {
                 t += dpp<0xB1>(t);   // quad_perm [1,0,3,2]
                 t += dpp<0x4E>(t);   // quad_perm [2,3,0,1]
                 t += dpp<0x141>(t);  // row_half_mirror: the other quad of the 8-lane group
-                const int h = q >> 3;
                 const unsigned h01 = pack_bf16(v[0], v[1]), h23 = pack_bf16(v[2], v[3]);
                 const float a0 = __uint_as_float(h01 << 16), a1 = __uint_as_float(h01 & 0xffff0000u);
                 const float a2 = __uint_as_float(h23 << 16), a3 = __uint_as_float(h23 & 0xffff0000u);
                 const u32x2 hi = {h01, h23};
                 const u32x2 lo = {pack_bf16(v[0] - a0, v[1] - a1), pack_bf16(v[2] - a2, v[3] - a3)};
-                const int off = img_off(row, q8 >> 1) + ((q8 & 1) << 3);
-                const int img = buf + h * (2 * IMG);
-                *reinterpret_cast<u32x2*>(smem + img + off) = hi;
-                *reinterpret_cast<u32x2*>(smem + img + IMG + off) = lo;
+                *reinterpret_cast<u32x2*>(smem + buf + loff[i]) = hi;
+                *reinterpret_cast<u32x2*>(smem + buf + loff[i] + IMG) = lo;
                 if (q8 == 0)  // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division
-                    *reinterpret_cast<float*>(smem + sarr + 4 * (h * TN + row)) =
+                    *reinterpret_cast<float*>(smem + sarr + soff[i]) =
                         kLog2e * __builtin_amdgcn_rcpf(ada_temp(t + bt, base_temp));
             }
         }
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
     const float* xb = x + (size_t)b * N * H * kC;
 
     Loader<LI> ld;
-    ld.init(wt);
+    ld.init(wt, xb, H, t_begin * TN);
     stage_ws(wimg, Ws, M);
 
     // per-item state (the Ws fragments -- B operand: col g = lane&31, k = c -- come from LDS)
@@ -245,13 +254,13 @@ __global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
     }
     const bool active = item0 < H * MB;
 
-    ld.fetch(xb, H, t_begin * TN, N - t_begin * TN);
-    ld.stage(0, sarr0, H, bt, base_temp);
+    ld.fetch(N - t_begin * TN);
+    ld.stage(0, sarr0, bt, base_temp);
     __syncthreads();
     int cur = 0;
     for (int t = t_begin; t < t_end; ++t) {
         const bool more = t + 1 < t_end;
-        if (more) ld.fetch(xb, H, (t + 1) * TN, N - (t + 1) * TN);
+        if (more) ld.fetch(N - (t + 1) * TN);
         if (active) {
             const int nvalid = N - t * TN;  // >= 32 except on the last tile
 #pragma unroll
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
                 }
             }
         }
-        if (more) ld.stage((cur ^ 1) * buf_bytes, sarr0 + (cur ^ 1) * sarr_bytes, H, bt, base_temp);
+        if (more) ld.stage((cur ^ 1) * buf_bytes, sarr0 + (cur ^ 1) * sarr_bytes, bt, base_temp);
         __syncthreads();
         cur ^= 1;
     }
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
         *reinterpret_cast<float*>(smem + m2L + 4 * i) = col_max[(size_t)b * H * M + i] * kLog2e;
     }
     Loader<LI> ld;
-    ld.init(wt);
+    ld.init(wt, xb, H, t_begin * TN);
     stage_ws(wimg, Ws, M);
 
     // per-head constants: the S'/l fragments (A operand: row c = lane&31, k = g in accumulator
@@ -411,13 +420,13 @@ __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
         }
     }
 
-    ld.fetch(xb, H, t_begin * TN, N - t_begin * TN);
-    ld.stage(0, sarr0, H, bt, base_temp);
+    ld.fetch(N - t_begin * TN);
+    ld.stage(0, sarr0, bt, base_temp);
     __syncthreads();
     int cur = 0;
     for (int t = t_begin; t < t_end; ++t) {
         const bool more = t + 1 < t_end;
-        if (more) ld.fetch(xb, H, (t + 1) * TN, N - (t + 1) * TN);
+        if (more) ld.fetch(N - (t + 1) * TN);
         const int nvalid = N - t * TN;
 #pragma unroll
         for (int hh = 0; hh < HPW; ++hh) {
@@ -464,7 +473,7 @@ __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
                 }
             }
         }
-        if (more) ld.stage((cur ^ 1) * buf_bytes, sarr0 + (cur ^ 1) * sarr_bytes, H, bt, base_temp);
+        if (more) ld.stage((cur ^ 1) * buf_bytes, sarr0 + (cur ^ 1) * sarr_bytes, bt, base_temp);
         __syncthreads();
         cur ^= 1;
     }
