@@ -8,8 +8,11 @@ slice_num=64, rotate=45) over one synthetic cloud of `--points` points resident 
 over the ranks (strong scaling, config C4): one all-gather of the slice records per forward.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline     -- the dominant hand-written kernel: algorithmic bytes / measured duration
-                  (HIP events on the launch stream) against the 8 TB/s HBM peak
+  roofline     -- the dominant hand-written kernel (largest share of the step): algorithmic bytes
+                  / measured duration (HIP events on the launch stream) against the 8 TB/s HBM
+                  peak; `all_kernels_frac` lists the same fraction for every streaming kernel
+  dtype        -- "bf16x3": every product is three bf16 MFMAs (hi*hi + hi*lo + lo*hi) with fp32
+                  accumulation and fp32 I/O, i.e. fp32-class results on the bf16 matrix cores
   cpu_baseline -- the CPU oracle (op-for-op port of the reference's forward) timed on the
                   host cores of this box on the same 1M-point input (rank 0, N = 1 only)
 """
@@ -26,8 +29,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
 STAGES = ("project", "slice", "merge", "token", "erwin", "deslice", "to_out")
-# algorithmic HBM bytes per point of the two streaming kernels (DESIGN.md / SURVEY.md 8d), fp32 I/O
-BYTES_PER_POINT = {"slice": lambda HC: 4 * HC, "deslice": lambda HC: 8 * HC}
+# algorithmic HBM bytes per point of the hand-written streaming kernels (DESIGN.md s.4 / SURVEY.md 8d),
+# fp32 I/O, D = dim = H*C: projection GEMMs read D and write D floats, the slice pass reads D, the
+# de-slice pass reads and writes D.
+BYTES_PER_POINT = {"project": lambda D: 8 * D, "slice": lambda D: 4 * D, "deslice": lambda D: 8 * D,
+                   "to_out": lambda D: 8 * D}
+KERNEL_OF_STAGE = {"project": "gemm_x3", "slice": "slice", "deslice": "deslice", "to_out": "gemm_x3"}
 
 
 def build_module(dev):
@@ -114,21 +121,24 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        dom = max(("slice", "deslice"), key=lambda k: stage_ms[k])
+        # dominant kernel = the hand-written streaming kernel with the largest share of the step
+        dom = max(BYTES_PER_POINT, key=lambda k: stage_ms[k])
         n_local = b - a
         gbs = n_local * BYTES_PER_POINT[dom](256) / (stage_ms[dom] * 1e-3) / 1e9
         res = {
             "metric": "forward points/sec + L2 vs ref, 1M-pt irregular mesh, M=64 slices",
             "value": N * args.steps / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16x3", "data": "synthetic",
             "config": {"workload": "configs[2]: Physics_Attention_Irregular_Mesh forward, "
                        f"N={N} points, dim=256, heads=8, dim_head=32, M=64, Erwin defaults, B=1",
                        "points": N, "slices": 64, "sharding": f"points/{world}"},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_bytes(dom, N) if world == 1 else None},
+            "roofline": {"bound": "hbm", "kernel": KERNEL_OF_STAGE[dom], "stage": dom, "achieved": gbs,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic_bytes(KERNEL_OF_STAGE[dom], N) if world == 1 else None,
+                         "all_kernels_frac": {k: round(n_local * BYTES_PER_POINT[k](256) / (stage_ms[k] * 1e-3)
+                                                       / 1e9 / HBM_PEAK_GBS, 4) for k in BYTES_PER_POINT}},
         }
         if world == 1 and not args.no_cpu_baseline:
             res.update(cpu_leg(mod, x_full, out))

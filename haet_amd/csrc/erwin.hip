@@ -501,7 +501,7 @@ __host__ __device__ inline int erwin_layout(const haet_erwin_desc& D, int Mp, in
 }
 
 // The weight blob starts with a copy of the descriptor (read with scalar loads).
-__global__ __launch_bounds__(1024) void erwin_kernel(
+__global__ __launch_bounds__(512) void erwin_kernel(
     const float* __restrict__ tokens, const float* __restrict__ pos,
     const int32_t* __restrict__ tree_idx, const uint8_t* __restrict__ tree_mask,
     const int32_t* __restrict__ rot, const float* __restrict__ W, int M, int Mp,
@@ -686,7 +686,7 @@ extern "C" int haet_erwin_fwd(const float* tokens, const float* pos, const int32
         if (e != hipSuccess) return fail(HAET_E_LAUNCH, "erwin: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = bytes;
     }
-    hipLaunchKernelGGL(erwin_kernel, dim3(n_clouds), dim3(1024), bytes, as_stream(stream), tokens,
+    hipLaunchKernelGGL(erwin_kernel, dim3(n_clouds), dim3(512), bytes, as_stream(stream), tokens,
                        pos, tree_idx, tree_mask, rot, weights, M, Mp, out);
     return check_launch("erwin_kernel");
 }
