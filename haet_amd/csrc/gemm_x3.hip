@@ -23,7 +23,6 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
-constexpr int GBM = 128;   // rows per workgroup
 constexpr int GBK = 32;    // k-tile
 constexpr int GIMG = 2048; // bytes of one [32][32] bf16 image
 
@@ -81,7 +80,7 @@ __device__ __forceinline__ GFrag g_read(int img, int row, int chunk) {
 // (row tile, k-tile) items.  The x loads of item i+3 and the W loads of item i+2 are issued into
 // named register sets while item i is multiplied, so ~48 KB of x per CU are always in flight
 // (HBM latency x per-CU bandwidth ~ 40-50 KB) and the stream never drains at a row-tile boundary.
-template <int NCB>
+template <int NCB, int RB>  // RB = 32-row blocks per wave: workgroup tile = 64*RB rows x 32*NCB columns
 __global__ __launch_bounds__(512) void gemm_x3_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ Whi,
     const unsigned short* __restrict__ Wlo, const float* __restrict__ bias, int Nrows, int K, int O,
@@ -89,8 +88,10 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     constexpr int BN = 32 * NCB;
     constexpr int WCB = NCB / 4;  // column blocks per wave (4 waves across the columns)
     constexpr int WPT = NCB / 4;  // 16-B W chunks per thread per plane and k-tile
-    constexpr int XIMG = 0, WIMG = (GBM / 32) * 2 * GIMG;
-    constexpr int BUF = (GBM / 32 + NCB) * 2 * GIMG;  // one (x tile, W tile) LDS buffer; two of them
+    constexpr int BM = 64 * RB;   // rows per workgroup tile
+    constexpr int XPT = BM / 64;  // 16-B x chunks per thread and k-tile
+    constexpr int XIMG = 0, WIMG = (BM / 32) * 2 * GIMG;
+    constexpr int BUF = (BM / 32 + NCB) * 2 * GIMG;  // one (x tile, W tile) LDS buffer; two of them
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 2, wn = wave & 3;
     const int col0 = blockIdx.y * BN;
@@ -99,29 +100,28 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     const int total = my_tiles * nkt;
     if (total == 0) return;
 
-    // loader geometry: x tile = 128 rows x 8 chunks(16 B) -> 2 chunks per thread
-    const int xrow0 = tid >> 3, xq = tid & 7;  // second chunk: row + 64
+    // loader geometry: x tile = BM rows x 8 chunks(16 B) -> XPT chunks per thread (rows +64 apart)
+    const int xrow0 = tid >> 3, xq = tid & 7;
     const int wrow0 = tid >> 2, wch = tid & 3; // W chunk i: row + 128 i
     const int x_st0 = XIMG + (xrow0 >> 5) * (2 * GIMG) + g_off(xrow0 & 31, xq >> 1) + ((xq & 1) << 3);
-    const int x_st1 = x_st0 + 2 * (2 * GIMG);  // row + 64 -> two row blocks further, same (row & 31)
     int w_st[WPT];
 #pragma unroll
     for (int i = 0; i < WPT; ++i)
         w_st[i] = WIMG + ((wrow0 + 128 * i) >> 5) * (2 * GIMG) + g_off(wrow0 & 31, wch);
 
-    f32x16 acc[2][WCB];
+    f32x16 acc[RB][WCB];
     float bv[WCB];  // bias of this lane's output columns: loaded (and waited for) once, up front
 #pragma unroll
     for (int j = 0; j < WCB; ++j) bv[j] = bias ? bias[col0 + 32 * (WCB * wn + j) + l31] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < WCB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = bv[j];  // accumulate on top of the bias
 
     // fetch streams (x three items ahead, W two items ahead), each with its own (tile, kt) cursor
-    f32x4 xs0[2], xs1[2], xs2[2];
+    f32x4 xs0[XPT], xs1[XPT], xs2[XPT];
     u32x4 ws0[2 * WPT], ws1[2 * WPT];
     // Every workgroup walks K in a rotated order (start at k-tile blockIdx % nkt): with all CUs on the
     // same k-tile at the same time, every access hits bytes [128 kt, 128 kt + 128) of a 1 KB row,
@@ -129,13 +129,15 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     const int krot = blockIdx.x % nkt;
     int fx_tile = blockIdx.x, fx_kt = 0, fx_it = 0;
     int fw_kt = 0, fw_it = 0;
-    auto fetch_x = [&](f32x4 (&d)[2]) {
+    auto fetch_x = [&](f32x4 (&d)[XPT]) {
         if (fx_it < total) {
-            const int r0 = min(fx_tile * GBM + xrow0, Nrows - 1), r1 = min(fx_tile * GBM + xrow0 + 64, Nrows - 1);
             int kk = fx_kt + krot;
             kk = (kk >= nkt ? kk - nkt : kk) * GBK;
-            d[0] = *reinterpret_cast<const f32x4*>(x + (size_t)r0 * K + kk + 4 * xq);
-            d[1] = *reinterpret_cast<const f32x4*>(x + (size_t)r1 * K + kk + 4 * xq);
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int r = min(fx_tile * BM + xrow0 + 64 * i, Nrows - 1);
+                d[i] = *reinterpret_cast<const f32x4*>(x + (size_t)r * K + kk + 4 * xq);
+            }
         }
         ++fx_it;
         if (++fx_kt == nkt) {
@@ -157,15 +159,15 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
         ++fw_it;
         if (++fw_kt == nkt) fw_kt = 0;
     };
-    auto stage = [&](int buf, const f32x4 (&xv)[2], const u32x4 (&wv)[2 * WPT]) {
+    auto stage = [&](int buf, const f32x4 (&xv)[XPT], const u32x4 (&wv)[2 * WPT]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < XPT; ++i) {
             const f32x4 v = xv[i];
             const unsigned h01 = g_pack(v[0], v[1]), h23 = g_pack(v[2], v[3]);
             const u32x2 hi = {h01, h23};
             const u32x2 lo = {g_pack(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u)),
                               g_pack(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u))};
-            const int off = buf + (i ? x_st1 : x_st0);
+            const int off = buf + x_st0 + i * 2 * (2 * GIMG);  // row + 64 i: two row blocks further
             *reinterpret_cast<u32x2*>(gsm + off) = hi;
             *reinterpret_cast<u32x2*>(gsm + off + GIMG) = lo;
         }
@@ -179,25 +181,25 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     auto compute = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            GFrag a[2], b[WCB];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = g_read(buf + XIMG + (2 * wm + i) * (2 * GIMG), l31, hf + 2 * ks);
+            GFrag b[WCB];
 #pragma unroll
             for (int j = 0; j < WCB; ++j) b[j] = g_read(buf + WIMG + (WCB * wn + j) * (2 * GIMG), l31, hf + 2 * ks);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < RB; ++i) {  // one A fragment at a time: RB = 4 leaves no room for four
+                const GFrag a = g_read(buf + XIMG + (RB * wm + i) * (2 * GIMG), l31, hf + 2 * ks);
 #pragma unroll
-                for (int j = 0; j < WCB; ++j) acc[i][j] = g_mfma3(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < WCB; ++j) acc[i][j] = g_mfma3(a, b[j], acc[i][j]);
+            }
         }
         if (++c_kt == nkt) {  // row tile finished: lane = output column, registers = rows
-            const int row0 = c_tile * GBM;
-            const bool full = row0 + GBM <= Nrows;  // wave-uniform: no per-store branch (a branch per
+            const int row0 = c_tile * BM;
+            const bool full = row0 + BM <= Nrows;  // wave-uniform: no per-store branch (a branch per
             // store made hipcc wait vmcnt(0) -- prefetch stream included -- before every store)
 #pragma unroll
             for (int j = 0; j < WCB; ++j) {
-                float* oc = out + (size_t)(row0 + 64 * wm + 4 * hf) * O + col0 + 32 * (WCB * wn + j) + l31;
+                float* oc = out + (size_t)(row0 + 32 * RB * wm + 4 * hf) * O + col0 + 32 * (WCB * wn + j) + l31;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < RB; ++i) {
                     if (full) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int rr = 32 * i + (r & 3) + 8 * (r >> 2);
-                            if (row0 + 64 * wm + 4 * hf + rr < Nrows) oc[(size_t)rr * O] = acc[i][j][r];
+                            if (row0 + 32 * RB * wm + 4 * hf + rr < Nrows) oc[(size_t)rr * O] = acc[i][j][r];
                         }
                     }
 #pragma unroll
@@ -219,11 +221,21 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     };
 
     // prologue: x items 0,1,2 and W items 0,1 in flight; item 0 staged; then x item 3 / W item 2
+    // (the 256-row variant has 128 accumulator registers: it keeps ONE W set, i.e. W runs one item
+    // ahead instead of two -- W comes from L2, and an item is 2x longer there)
+    constexpr bool kTwoW = RB < 4, kThreeX = RB < 4;  // 256-row variant: x two items ahead, W one
+    u32x4 (&wsB)[2 * WPT] = kTwoW ? ws1 : ws0;
+    f32x4 (&x_s0)[XPT] = xs1;
+    f32x4 (&x_s1)[XPT] = kThreeX ? xs2 : xs0;
+    f32x4 (&x_s2)[XPT] = kThreeX ? xs0 : xs1;
+    f32x4 (&x_s3)[XPT] = kThreeX ? xs1 : xs0;
+    f32x4 (&x_s4)[XPT] = kThreeX ? xs2 : xs1;
+    f32x4 (&x_s5)[XPT] = xs0;
     fetch_x(xs0);
     fetch_x(xs1);
-    fetch_x(xs2);
+    if (kThreeX) fetch_x(xs2);
     fetch_w(ws0);
-    fetch_w(ws1);
+    if (kTwoW) fetch_w(ws1);
     stage(0, xs0, ws0);
     fetch_x(xs0);
     fetch_w(ws0);
@@ -244,12 +256,12 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
         ++it;                                            \
     }
     for (int it = 0; it < total;) {
-        GEMM_STEP(xs1, ws1)
-        GEMM_STEP(xs2, ws0)
-        GEMM_STEP(xs0, ws1)
-        GEMM_STEP(xs1, ws0)
-        GEMM_STEP(xs2, ws1)
-        GEMM_STEP(xs0, ws0)
+        GEMM_STEP(x_s0, wsB)
+        GEMM_STEP(x_s1, ws0)
+        GEMM_STEP(x_s2, wsB)
+        GEMM_STEP(x_s3, ws0)
+        GEMM_STEP(x_s4, wsB)
+        GEMM_STEP(x_s5, ws0)
     }
 #undef GEMM_STEP
 }
@@ -277,26 +289,29 @@ extern "C" int haet_linear_fwd(const float* x, const uint16_t* W_hi, const uint1
     if (!x || !W_hi || !W_lo || !out || Nrows < 1) return fail(HAET_E_ARG, "linear_fwd: bad arguments");
     if (!haet_linear_supported(K, O))
         return fail(HAET_E_ARG, "linear_fwd: K=%d (multiple of 32) / O=%d (multiple of 128) unsupported", K, O);
-    const int tiles = (Nrows + GBM - 1) / GBM;
-    if (O % 256 == 0) {
-        const int ny = O / 256;
-        const int gx = tiles < 256 / ny ? tiles : (256 / ny > 0 ? 256 / ny : 1);  // one workgroup per CU
-        const size_t lds = 2 * (GBM / 32 + 8) * 2 * GIMG;
-        static thread_local bool attr = false;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<8>),
+    // 256-row workgroup tiles (W staged once per 256 rows) when there are enough rows to fill the
+    // chip, 128-row tiles otherwise; 128-column variant for O % 256 != 0
+    const bool big = Nrows >= 256 * 256 && O % 256 == 0;
+    const int BM = big ? 256 : 128;
+    const int tiles = (Nrows + BM - 1) / BM;
+    const int NCBv = (O % 256 == 0) ? 8 : 4;
+    const int ny = O / (32 * NCBv);
+    const int gx = tiles < 256 / ny ? tiles : (256 / ny > 0 ? 256 / ny : 1);  // one workgroup per CU
+    const size_t lds = (size_t)2 * (BM / 32 + NCBv) * 2 * GIMG;
+    auto launch = [&](auto kern) -> int {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return fail(HAET_E_LAUNCH, "linear_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            attr = true;
         }
-        hipLaunchKernelGGL(gemm_x3_kernel<8>, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi,
-                           W_lo, bias, Nrows, K, O, tiles, out);
-    } else {
-        const int ny = O / 128;
-        const int gx = tiles < 256 / ny ? tiles : (256 / ny > 0 ? 256 / ny : 1);
-        const size_t lds = 2 * (GBM / 32 + 4) * 2 * GIMG;
-        hipLaunchKernelGGL(gemm_x3_kernel<4>, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi,
-                           W_lo, bias, Nrows, K, O, tiles, out);
-    }
+        hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi, W_lo, bias, Nrows,
+                           K, O, tiles, out);
+        return HAET_OK;
+    };
+    int rc;
+    if (big) rc = launch(gemm_x3_kernel<8, 4>);
+    else if (NCBv == 8) rc = launch(gemm_x3_kernel<8, 2>);
+    else rc = launch(gemm_x3_kernel<4, 2>);
+    if (rc != HAET_OK) return rc;
     return check_launch("gemm_x3_kernel");
 }
