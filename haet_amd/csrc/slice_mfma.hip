@@ -28,6 +28,8 @@
 // Ada-Temp tau per (point, head) is reduced in the loader (8 lanes per head, DPP).  Loads
 // for tile t+1 are issued before computing tile t and written to the other LDS buffer
 // after it (one barrier per tile).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace haet {
@@ -502,7 +504,9 @@ bool mfma_plan(int B, int N, int H, int C, int M, MfmaPlan* p) {
         p->mb = mb;
         p->hpw = hpw;
         const int n_tiles = (N + TN - 1) / TN;
-        int target = 512 / (B < 1 ? 1 : B);
+        int chunks = 512;  // point chunks (= workgroups) per launch; HAET_SLICE_CHUNKS overrides (tuning)
+        if (const char* e = getenv("HAET_SLICE_CHUNKS")) chunks = atoi(e) > 0 ? atoi(e) : chunks;
+        int target = chunks / (B < 1 ? 1 : B);
         if (target < 1) target = 1;
         p->tiles_per_chunk = (n_tiles + target - 1) / target;
         p->parts = (n_tiles + p->tiles_per_chunk - 1) / p->tiles_per_chunk;
