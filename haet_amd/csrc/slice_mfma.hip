@@ -571,6 +571,13 @@ int deslice_mfma_fwd(const float* x, const float* Ws, const float* bs, const flo
                      int B, int N, int H, int C, int M, float* out, hipStream_t st) {
     MfmaPlan p;
     if (!mfma_plan(B, N, H, C, M, &p)) return fail(HAET_E_ARG, "deslice_mfma: unsupported shape");
+    {   // no partial records here, so more (shorter) chunks only help the tail: ~1024 per launch
+        const int n_tiles = (N + TN - 1) / TN;
+        int target = 1024 / B;
+        if (target < 1) target = 1;
+        p.tiles_per_chunk = (n_tiles + target - 1) / target;
+        p.parts = (n_tiles + p.tiles_per_chunk - 1) / p.tiles_per_chunk;
+    }
     dim3 grid(p.parts, B);
     DESLICE_CASE(4, 1, 2)
     DESLICE_CASE(4, 1, 1)
