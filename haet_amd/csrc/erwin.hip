@@ -127,14 +127,33 @@ __device__ __attribute__((noinline)) void linear_core(
 #endif
     LSTAMP(40);
 
+    // Item cursors advance incrementally (no integer divisions: each costs ~40 VALU instructions and
+    // there were six per item).  An item = (tile, k-step); tile = (tt, ot), tiles are dealt to the
+    // waves round-robin.
+    struct Cur {
+        int tt, ot, ks;
+    };
+    const auto first = [&]() {
+        Cur c;
+        c.tt = wave / nto;
+        c.ot = wave - c.tt * nto;
+        c.ks = 0;
+        return c;
+    };
+    const auto advance = [&](Cur& c) {
+        if (++c.ks == nks) {
+            c.ks = 0;
+            c.ot += nwaves;
+            while (c.ot >= nto) {
+                c.ot -= nto;
+                ++c.tt;
+            }
+        }
+    };
     u32x4 w0[4], w1[4];
-    auto fetch = [&](int it, u32x4 (&wv)[4]) {
-        const int tile = wave + nwaves * (it / nks), ks = it % nks;
-        const int ot = tile % nto;
-        const size_t off = (size_t)min(ot * 16 + l15, O - 1) * Kp + 32 * ks + 8 * kq;
-        // explicit global address space: a generic pointer argument would become flat_load,
-        // which waits for LDS and global traffic alike and kills the prefetch
-        typedef const __attribute__((address_space(1))) u32x4* gv4;
+    typedef const __attribute__((address_space(1))) u32x4* gv4;  // explicit global loads (not flat)
+    auto fetch = [&](const Cur& c, u32x4 (&wv)[4]) {
+        const size_t off = (size_t)min(c.ot * 16 + l15, O - 1) * Kp + 32 * c.ks + 8 * kq;
         wv[0] = *(gv4)(Wa + off);
         wv[1] = *(gv4)(Wa + plane + off);
         if (dual) {
@@ -143,10 +162,8 @@ __device__ __attribute__((noinline)) void linear_core(
         }
     };
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    auto step = [&](int it, const u32x4 (&wv)[4]) {
-        const int tile = wave + nwaves * (it / nks), ks = it % nks;
-        const int tt = tile / nto, ot = tile - tt * nto;
-        const int xo = x.base + min(tt * 16 + l15, n - 1) * x.S + (32 * ks + 8 * kq) * 2;
+    auto step = [&](const Cur& c, const u32x4 (&wv)[4]) {
+        const int xo = x.base + min(c.tt * 16 + l15, n - 1) * x.S + (32 * c.ks + 8 * kq) * 2;
         const u32x4 xh = *reinterpret_cast<const u32x4*>(smem + xo);
         const u32x4 xl = *reinterpret_cast<const u32x4*>(smem + xo + x.plane);
         LSTAMP(42);
@@ -156,26 +173,44 @@ __device__ __attribute__((noinline)) void linear_core(
         if (mode == EP_RESID && K <= 64) { asm volatile("" :: "v"(acc0)); }
 #endif
         LSTAMP(43);
-        if (ks == nks - 1) {
-            const int o = ot * 16 + l15;
+        if (c.ks == nks - 1) {
+            const int o = c.ot * 16 + l15, t0 = c.tt * 16 + 4 * kq;
             if (o < O) {
                 const float bo = F(b0 + 4 * o);
-                for (int r = 0; r < 4; ++r) {
-                    const int t = tt * 16 + 4 * kq + r;
-                    if (t < n) {
-                        const float v = acc0[r] + bo;
-                        if (mode == EP_QKV) {
-                            F(dst + 4 * (t * ldd + o)) = v;
-                        } else if (mode == EP_RESID) {
-                            F(dst + 4 * (t * ldd + o)) += v;
-                        } else if (mode == EP_SWIGLU) {
-                            di.put(t, o, (acc1[r] + F(b1 + 4 * o)) * (v / (1.0f + __expf(-v))));
-                        } else if (mode == EP_BN) {
-                            F(dst + 4 * (t * ldd + o)) = v * F(sc + 4 * o) + F(sh + 4 * o);
-                        } else {
-                            const int q = o / aux, ch = o - q * aux;  // 'n (m d) -> (n m) d'
-                            float& y = F(dst + 4 * ((t * st + q) * ldd + ch));
-                            y = (y + v) * F(sc + 4 * ch) + F(sh + 4 * ch);
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc0[r] + bo;
+                if (mode == EP_QKV) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t0 + r < n) F(dst + 4 * ((t0 + r) * ldd + o)) = v[r];
+                } else if (mode == EP_RESID) {
+                    float old[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) old[r] = F(dst + 4 * (min(t0 + r, n - 1) * ldd + o));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t0 + r < n) F(dst + 4 * ((t0 + r) * ldd + o)) = old[r] + v[r];
+                } else if (mode == EP_SWIGLU) {
+                    const float b1o = F(b1 + 4 * o);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[r]));
+                        if (t0 + r < n) di.put(t0 + r, o, (acc1[r] + b1o) * (v[r] * sig));
+                    }
+                } else if (mode == EP_BN) {
+                    const float so = F(sc + 4 * o), ho = F(sh + 4 * o);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t0 + r < n) F(dst + 4 * ((t0 + r) * ldd + o)) = v[r] * so + ho;
+                } else {
+                    const int q = o / aux, ch = o - q * aux;  // 'n (m d) -> (n m) d'
+                    const float so = F(sc + 4 * ch), ho = F(sh + 4 * ch);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (t0 + r < n) {
+                            float& y = F(dst + 4 * (((t0 + r) * st + q) * ldd + ch));
+                            y = (y + v[r]) * so + ho;
                         }
                     }
                 }
@@ -184,17 +219,30 @@ __device__ __attribute__((noinline)) void linear_core(
             acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    fetch(0, w0);
-    if (items > 1) fetch(1, w1);
+    Cur cf = first(), cc = first();  // fetch cursor runs two items ahead of the compute cursor
+    fetch(cf, w0);
+    advance(cf);
+    if (items > 1) {
+        fetch(cf, w1);
+        advance(cf);
+    }
     LSTAMP(41);
     for (int it = 0; it < items; it += 2) {  // two named register sets, statically indexed
         u32x4 c0[4] = {w0[0], w0[1], w0[2], w0[3]};
-        if (it + 2 < items) fetch(it + 2, w0);
-        step(it, c0);
+        if (it + 2 < items) {
+            fetch(cf, w0);
+            advance(cf);
+        }
+        step(cc, c0);
+        advance(cc);
         if (it + 1 < items) {
             u32x4 c1[4] = {w1[0], w1[1], w1[2], w1[3]};
-            if (it + 3 < items) fetch(it + 3, w1);
-            step(it + 1, c1);
+            if (it + 3 < items) {
+                fetch(cf, w1);
+                advance(cf);
+            }
+            step(cc, c1);
+            advance(cc);
         }
     }
     LSTAMP(44);
@@ -278,9 +326,16 @@ __device__ __attribute__((noinline)) void ball_attention(int qkv, int ldq, int n
                                                          int ball, int perm, const Img out) {
     constexpr int KC = 8;  // keys per step: 8 independent score chains, one rescale per step
     const float scale = 1.0f / sqrtf((float)HD);
-    for (int i = threadIdx.x; i < n * heads; i += blockDim.x) {
-        const int place = i / heads, h = i % heads;
+    // Two adjacent lanes share one (place, head): each takes half of the ball's keys and the two
+    // partial (m, l, acc) are merged with the log-sum-exp rule through xor-1 shuffles, so a cloud of
+    // n*heads = 256 queries keeps all 512 threads busy and the key loop is half as long.
+    const bool split = ball >= 2 * KC;
+    const int per = split ? 2 : 1;
+    for (int i = threadIdx.x; i < n * heads * per; i += blockDim.x) {
+        const int half = split ? (i & 1) : 0, ih = split ? (i >> 1) : i;
+        const int place = ih / heads, h = ih - place * heads;
         const int tq = I(perm + 4 * place), b0 = (place / ball) * ball;
+        const int kbeg = split ? half * (ball >> 1) : 0, kend = split ? kbeg + (ball >> 1) : ball;
         float q[HD], acc[HD];
 #pragma unroll
         for (int e = 0; e < HD; ++e) {
@@ -288,13 +343,13 @@ __device__ __attribute__((noinline)) void ball_attention(int qkv, int ldq, int n
             acc[e] = 0.f;
         }
         float m = -INFINITY, l = 0.f;
-        for (int p0 = 0; p0 < ball; p0 += KC) {
+        for (int p0 = kbeg; p0 < kend; p0 += KC) {
             int kr[KC];
             float sc[KC];
             float mx = m;
 #pragma unroll
             for (int u = 0; u < KC; ++u) {
-                const int p = min(p0 + u, ball - 1);
+                const int p = min(p0 + u, kend - 1);
                 kr[u] = qkv + 4 * (I(perm + 4 * (b0 + p)) * ldq + c + h * HD);
             }
 #pragma unroll
@@ -302,7 +357,7 @@ __device__ __attribute__((noinline)) void ball_attention(int qkv, int ldq, int n
                 float sv = 0.f;
 #pragma unroll
                 for (int e = 0; e < HD; ++e) sv = fmaf(q[e], F(kr[u] + 4 * e), sv);
-                sc[u] = (p0 + u < ball) ? sv : -INFINITY;
+                sc[u] = (p0 + u < kend) ? sv : -INFINITY;
                 mx = fmaxf(mx, sc[u]);
             }
             const float a = __expf(m - mx);  // m = -inf on the first step -> 0
@@ -318,9 +373,23 @@ __device__ __attribute__((noinline)) void ball_attention(int qkv, int ldq, int n
             }
             m = mx;
         }
-        const float inv = 1.0f / l;
+        if (split) {  // merge with the partner lane (both end up with the full result)
+            const float mo = __shfl_xor(m, 1), lo = __shfl_xor(l, 1);
+            const float mx = fmaxf(m, mo);
+            const float a = __expf(m - mx), bq = __expf(mo - mx);
+            l = l * a + lo * bq;
 #pragma unroll
-        for (int e = 0; e < HD; ++e) out.put(tq, h * HD + e, acc[e] * inv);
+            for (int e = 0; e < HD; ++e) acc[e] = acc[e] * a + __shfl_xor(acc[e], 1) * bq;
+        }
+        const float inv = 1.0f / l;
+        if (split && HD >= 2) {  // each lane of the pair writes half of the head's channels
+#pragma unroll
+            for (int e = 0; e < HD / 2; ++e)
+                out.put(tq, h * HD + half * (HD / 2) + e, (half ? acc[e + HD / 2] : acc[e]) * inv);
+        } else if (half == 0) {
+#pragma unroll
+            for (int e = 0; e < HD; ++e) out.put(tq, h * HD + e, acc[e] * inv);
+        }
     }
 }
 
