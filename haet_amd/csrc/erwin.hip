@@ -326,16 +326,9 @@ __device__ __attribute__((noinline)) void ball_attention(int qkv, int ldq, int n
                                                          int ball, int perm, const Img out) {
     constexpr int KC = 8;  // keys per step: 8 independent score chains, one rescale per step
     const float scale = 1.0f / sqrtf((float)HD);
-    // Two adjacent lanes share one (place, head): each takes half of the ball's keys and the two
-    // partial (m, l, acc) are merged with the log-sum-exp rule through xor-1 shuffles, so a cloud of
-    // n*heads = 256 queries keeps all 512 threads busy and the key loop is half as long.
-    const bool split = ball >= 2 * KC;
-    const int per = split ? 2 : 1;
-    for (int i = threadIdx.x; i < n * heads * per; i += blockDim.x) {
-        const int half = split ? (i & 1) : 0, ih = split ? (i >> 1) : i;
-        const int place = ih / heads, h = ih - place * heads;
+    for (int i = threadIdx.x; i < n * heads; i += blockDim.x) {
+        const int place = i / heads, h = i % heads;
         const int tq = I(perm + 4 * place), b0 = (place / ball) * ball;
-        const int kbeg = split ? half * (ball >> 1) : 0, kend = split ? kbeg + (ball >> 1) : ball;
         float q[HD], acc[HD];
 #pragma unroll
         for (int e = 0; e < HD; ++e) {
@@ -343,13 +336,13 @@ __device__ __attribute__((noinline)) void ball_attention(int qkv, int ldq, int n
             acc[e] = 0.f;
         }
         float m = -INFINITY, l = 0.f;
-        for (int p0 = kbeg; p0 < kend; p0 += KC) {
+        for (int p0 = 0; p0 < ball; p0 += KC) {
             int kr[KC];
             float sc[KC];
             float mx = m;
 #pragma unroll
             for (int u = 0; u < KC; ++u) {
-                const int p = min(p0 + u, kend - 1);
+                const int p = min(p0 + u, ball - 1);
                 kr[u] = qkv + 4 * (I(perm + 4 * (b0 + p)) * ldq + c + h * HD);
             }
 #pragma unroll
@@ -357,7 +350,7 @@ __device__ __attribute__((noinline)) void ball_attention(int qkv, int ldq, int n
                 float sv = 0.f;
 #pragma unroll
                 for (int e = 0; e < HD; ++e) sv = fmaf(q[e], F(kr[u] + 4 * e), sv);
-                sc[u] = (p0 + u < kend) ? sv : -INFINITY;
+                sc[u] = (p0 + u < ball) ? sv : -INFINITY;
                 mx = fmaxf(mx, sc[u]);
             }
             const float a = __expf(m - mx);  // m = -inf on the first step -> 0
@@ -373,23 +366,9 @@ __device__ __attribute__((noinline)) void ball_attention(int qkv, int ldq, int n
             }
             m = mx;
         }
-        if (split) {  // merge with the partner lane (both end up with the full result)
-            const float mo = __shfl_xor(m, 1), lo = __shfl_xor(l, 1);
-            const float mx = fmaxf(m, mo);
-            const float a = __expf(m - mx), bq = __expf(mo - mx);
-            l = l * a + lo * bq;
-#pragma unroll
-            for (int e = 0; e < HD; ++e) acc[e] = acc[e] * a + __shfl_xor(acc[e], 1) * bq;
-        }
         const float inv = 1.0f / l;
-        if (split && HD >= 2) {  // each lane of the pair writes half of the head's channels
 #pragma unroll
-            for (int e = 0; e < HD / 2; ++e)
-                out.put(tq, h * HD + half * (HD / 2) + e, (half ? acc[e + HD / 2] : acc[e]) * inv);
-        } else if (half == 0) {
-#pragma unroll
-            for (int e = 0; e < HD; ++e) out.put(tq, h * HD + e, acc[e] * inv);
-        }
+        for (int e = 0; e < HD; ++e) out.put(tq, h * HD + e, acc[e] * inv);
     }
 }
 
