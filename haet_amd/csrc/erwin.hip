@@ -55,6 +55,17 @@ __device__ __forceinline__ unsigned short bf16_rne(float a) {
 // flat access must wait vmcnt(0) AND lgkmcnt(0): the first version of this kernel had 1038 flat
 // and 4 ds instructions and every phase ran at one memory latency per access.
 extern __shared__ __attribute__((aligned(16))) char smem[];
+// Arguments of a non-inlined routine arrive in VGPRs, i.e. "divergent" to the compiler: every
+// `if (mode == ...)` becomes an exec-mask dance and every address a vector computation.  The
+// wave-uniform ones are re-declared uniform with v_readfirstlane at routine entry.
+__device__ __forceinline__ int U(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename P>
+__device__ __forceinline__ P* UP(P* p) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return reinterpret_cast<P*>(((unsigned long long)hi << 32) | lo);
+}
+struct Img;
 __device__ __forceinline__ float& F(int off) { return *reinterpret_cast<float*>(smem + off); }
 __device__ __forceinline__ int& I(int off) { return *reinterpret_cast<int*>(smem + off); }
 
@@ -70,6 +81,7 @@ struct Img {
     }
 };
 
+__device__ __forceinline__ Img UI(const Img& i) { return Img{U(i.base), U(i.S), U(i.plane)}; }
 __host__ __device__ inline int round32(int k) { return (k + 31) & ~31; }
 __host__ __device__ inline int img_stride(int K) { return round32(K) * 2 + kImgPad; }
 
@@ -79,7 +91,7 @@ constexpr int T_X = 0, T_P = 4, T_ROT = 8, T_N = 12, T_LD = 16;  // + level
 constexpr int T_IA = 20, T_WIDE = 21, T_REL = 22, T_PAR = 23, T_IDENT = 24, T_HID = 25, T_ALIAS = 26;
 constexpr int T_RELV = 28;  // + 2*level + rotated: ball-centre offsets per (level, perm)
 constexpr int T_WORDS = 40;
-__device__ __forceinline__ int T(int i) { return I(4 * i); }
+__device__ __forceinline__ int T(int i) { return __builtin_amdgcn_readfirstlane(I(4 * i)); }
 
 // copy `len` floats (16-B aligned, multiple of 4) of small parameters into LDS
 __device__ __forceinline__ void stage_params(int dst, const float* __restrict__ src, int len) {
@@ -110,10 +122,13 @@ enum EpiMode {
 // are in flight behind the one being multiplied.  dst / b0 / b1 / sc / sh are LDS byte offsets.
 // One shared routine (runtime epilogue mode) keeps the kernel's instruction footprint small.
 __device__ __attribute__((noinline)) void linear_core(
-    const Img x, int n, int K, const unsigned short* __restrict__ Wa,
+    const Img x_, int n, int K, const unsigned short* __restrict__ Wa,
     const unsigned short* __restrict__ Wb, int O, int mode, int dst, int ldd, int b0, int b1, int sc,
-    int sh, const Img di, int aux, int st) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    int sh, const Img di_, int aux, int st) {
+    const Img x = UI(x_), di = UI(di_);
+    n = U(n), K = U(K), O = U(O), mode = U(mode), dst = U(dst), ldd = U(ldd), b0 = U(b0), b1 = U(b1);
+    sc = U(sc), sh = U(sh), aux = U(aux), st = U(st), Wa = UP(Wa), Wb = UP(Wb);
+    const int lane = threadIdx.x & 63, wave = U(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const int Kp = round32(K), nks = Kp >> 5;
     const int nto = (O + 15) >> 4, ntiles = ((n + 15) >> 4) * nto;
@@ -407,9 +422,12 @@ enum GEpi { G_QKV = 0, G_RESID = 1, G_SWIGLU = 2 };
 // group); the 16 x 16-output tiles are walked o-tile by o-tile, k-step fastest; four (o-tile,
 // k-step) weight items are in flight.  Output rows map to tokens tok[r] (rows 4*kq + r of this lane).
 __device__ __attribute__((noinline)) void group_linear(
-    const Img x, int row0, int K, const unsigned short* __restrict__ Wa,
+    const Img x_, int row0, int K, const unsigned short* __restrict__ Wa,
     const unsigned short* __restrict__ Wb, int O, int mode, int dst, int ldd, int b0, int b1,
-    const Img di, int tok0, int tok1, int tok2, int tok3, int nrows /* valid rows in the group */) {
+    const Img di_, int tok0, int tok1, int tok2, int tok3, int nrows /* valid rows in the group */) {
+    const Img x = UI(x_), di = UI(di_);
+    row0 = U(row0), K = U(K), O = U(O), mode = U(mode), dst = U(dst), ldd = U(ldd), b0 = U(b0), b1 = U(b1);
+    nrows = U(nrows), Wa = UP(Wa), Wb = UP(Wb);
     const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
     const int Kp = round32(K), nks = Kp >> 5, nto = (O + 15) >> 4, items = nto * nks;
     const size_t plane = (size_t)O * Kp;
@@ -495,7 +513,10 @@ __device__ __attribute__((noinline)) void group_linear(
 // out[place rows of the group] = split( RMSNorm(X[tok]) * w [+ pe_b + rel[tok] . pe_w] ); one wave,
 // 4 lanes per row, float4 channel chunks (c <= 128).
 __device__ __attribute__((noinline)) void group_norm(int X, int ldx, int c, int w, int rel, int d, int pe_w,
-                                                     int pe_b, int perm, int row0, int nrows, const Img out) {
+                                                     int pe_b, int perm, int row0, int nrows, const Img out_) {
+    const Img out = UI(out_);
+    X = U(X), ldx = U(ldx), c = U(c), w = U(w), rel = U(rel), d = U(d), pe_w = U(pe_w), pe_b = U(pe_b);
+    perm = U(perm), row0 = U(row0), nrows = U(nrows);
     const int lane = threadIdx.x & 63, r = lane >> 2, sub = lane & 3;
     const int cp = round32(c), iters = cp >> 4;  // float4 chunks per lane: channels 4*sub + 16*i
     const bool live = r < nrows;
@@ -543,8 +564,11 @@ __device__ __attribute__((noinline)) void group_norm(int X, int ldx, int c, int 
 // the reference calls flash_attn_qkvpacked_func here); keys = the ball of each place.
 template <int HD>
 __device__ __attribute__((noinline)) void group_attention(int qkv, int ldq, int c, int heads, int ball,
-                                                          int perm, int row0, int nrows, const Img out) {
+                                                          int perm, int row0, int nrows, const Img out_) {
     constexpr int KC = 8;
+    const Img out = UI(out_);
+    qkv = U(qkv), ldq = U(ldq), c = U(c), heads = U(heads), ball = U(ball), perm = U(perm), row0 = U(row0);
+    nrows = U(nrows);
     const float scale = 1.0f / sqrtf((float)HD);
     const int lane = threadIdx.x & 63;
     for (int j = lane; j < nrows * heads; j += 64) {
@@ -608,13 +632,14 @@ __device__ __attribute__((noinline)) void group_attention_dispatch(int hd, int q
 __device__ __attribute__((noinline)) void erwin_block(int lvl, const haet_erwin_layer& L,
                                                       const haet_erwin_block_w& w,
                                                       const float* __restrict__ W, int d, int perm, int rotated) {
+    lvl = U(lvl), d = U(d), perm = U(perm), rotated = U(rotated), W = UP(W);
     const int X = T(T_X + lvl), n = T(T_N + lvl), ld = T(T_LD + lvl), c = L.c, hid = L.hidden;
     const int ldq = 3 * c + kPad, qbuf = T(T_WIDE), rel = T(T_RELV + 2 * lvl + rotated);
     const int npad = (n + TG - 1) / TG * TG;
     const Img ia = {T(T_IA), img_stride(c), npad * img_stride(c)};
     const Img ih = {T(T_HID), img_stride(hid), npad * img_stride(hid)};
     const Img none = {0, 0, 0};
-    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, kq = (threadIdx.x & 63) >> 4;
+    const int wave = U(threadIdx.x >> 6), nwaves = blockDim.x >> 6, kq = (threadIdx.x & 63) >> 4;
     const int ngroups = npad / TG;
     // norm weights, positional projection and every bias of this block: one coalesced copy to LDS
     const int par = T(T_PAR) - 4 * w.small_off;  // par + 4 * <blob offset> addresses the LDS copy
