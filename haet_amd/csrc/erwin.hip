@@ -192,7 +192,7 @@ __device__ __attribute__((noinline)) void linear_core(
         LSTAMP(43);
         if (c.ks == nks - 1) {
             const int o = c.ot * 16 + l15, t0 = c.tt * 16 + 4 * kq;
-            if (o < O) {
+            if (o < O && t0 < n) {
                 const float bo = F(b0 + 4 * o);
                 float v[4];
 #pragma unroll
@@ -236,28 +236,26 @@ __device__ __attribute__((noinline)) void linear_core(
             acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    Cur cf = first(), cc = first();  // fetch cursor runs two items ahead of the compute cursor
+    // fetch cursor runs two items ahead of the compute cursor; fetches are unconditional (clamped)
+    // and the loop runs whole 2-step rounds, so that the compiler can count the loads in flight
+    Cur cf = first(), cc = first();
     fetch(cf, w0);
     advance(cf);
-    if (items > 1) {
-        fetch(cf, w1);
-        advance(cf);
-    }
+    fetch(cf, w1);
+    advance(cf);
     LSTAMP(41);
     for (int it = 0; it < items; it += 2) {  // two named register sets, statically indexed
-        u32x4 c0[4] = {w0[0], w0[1], w0[2], w0[3]};
-        if (it + 2 < items) {
+        {
+            u32x4 c0[4] = {w0[0], w0[1], w0[2], w0[3]};
             fetch(cf, w0);
             advance(cf);
+            step(cc, c0);
+            advance(cc);
         }
-        step(cc, c0);
-        advance(cc);
-        if (it + 1 < items) {
+        {
             u32x4 c1[4] = {w1[0], w1[1], w1[2], w1[3]};
-            if (it + 3 < items) {
-                fetch(cf, w1);
-                advance(cf);
-            }
+            fetch(cf, w1);
+            advance(cf);
             step(cc, c1);
             advance(cc);
         }
@@ -436,10 +434,16 @@ __device__ __attribute__((noinline)) void group_linear(
     typedef const __attribute__((address_space(1))) u32x4* gv4;
     const int xrow = x.base + min(row0 + l15, row0 + nrows - 1) * x.S + 16 * kq;
 
+    // Weight prefetch ring of four named register sets.  Every fetch is UNCONDITIONAL (the cursor
+    // is clamped to the last item) and the loop runs a whole number of 4-step rounds (ghost steps
+    // past the end multiply garbage into an accumulator that is never written): with a conditional
+    // load anywhere between a fetch and its use, hipcc's waitcnt pass can no longer count the
+    // younger loads in flight and falls back to vmcnt(0) -- which silently serialises the ring
+    // (measured: ~1.5k cycles per item instead of ~300).
     u32x4 w0[4], w1[4], w2[4], w3[4];
     int f_ot = 0, f_ks = 0;
     auto fetch = [&](u32x4 (&wv)[4]) {
-        const size_t off = (size_t)min(f_ot * 16 + l15, O - 1) * Kp + 32 * f_ks + 8 * kq;
+        const size_t off = (size_t)min(min(f_ot, nto - 1) * 16 + l15, O - 1) * Kp + 32 * f_ks + 8 * kq;
         wv[0] = *(gv4)(Wa + off);
         wv[1] = *(gv4)(Wa + plane + off);
         if (dual) {
@@ -460,7 +464,7 @@ __device__ __attribute__((noinline)) void group_linear(
         if (dual) acc1 = mfma3(xh, xl, wv[2], wv[3], acc1);
         if (++c_ks == nks) {
             const int o = c_ot * 16 + l15;
-            if (o < O) {
+            if (c_ot < nto && o < O) {
                 const float bo = F(b0 + 4 * o);
                 if (mode == G_QKV) {
 #pragma unroll
@@ -489,19 +493,17 @@ __device__ __attribute__((noinline)) void group_linear(
             ++c_ot;
         }
     };
-    // ring of four named register sets: item i+4 is fetched when item i has been consumed
-    if (items > 0) fetch(w0);
-    if (items > 1) fetch(w1);
-    if (items > 2) fetch(w2);
-    if (items > 3) fetch(w3);
+    fetch(w0);
+    fetch(w1);
+    fetch(w2);
+    fetch(w3);
 #define GL_STEP(WS)                                  \
-    if (it < items) {                                \
+    {                                                \
         u32x4 cw[4] = {WS[0], WS[1], WS[2], WS[3]};  \
-        if (it + 4 < items) fetch(WS);               \
+        fetch(WS);                                   \
         step(cw);                                    \
-        ++it;                                        \
     }
-    for (int it = 0; it < items;) {
+    for (int it = 0; it < items; it += 4) {
         GL_STEP(w0)
         GL_STEP(w1)
         GL_STEP(w2)
