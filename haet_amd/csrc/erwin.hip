@@ -65,7 +65,6 @@ __device__ __forceinline__ P* UP(P* p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
     return reinterpret_cast<P*>(((unsigned long long)hi << 32) | lo);
 }
-struct Img;
 __device__ __forceinline__ float& F(int off) { return *reinterpret_cast<float*>(smem + off); }
 __device__ __forceinline__ int& I(int off) { return *reinterpret_cast<int*>(smem + off); }
 
@@ -88,9 +87,7 @@ __host__ __device__ inline int img_stride(int K) { return round32(K) * 2 + kImgP
 // LDS directory, itself in LDS (ints at smem[0..]): per level l the BYTE offsets of X_l, P_l,
 // rot_l and n_l, ld_l (floats); then the shared regions.
 constexpr int T_X = 0, T_P = 4, T_ROT = 8, T_N = 12, T_LD = 16;  // + level
-constexpr int T_IA = 20, T_WIDE = 21, T_REL = 22, T_PAR = 23, T_IDENT = 24, T_HID = 25, T_ALIAS = 26;
-constexpr int T_RELV = 28;  // + 2*level + rotated: ball-centre offsets per (level, perm)
-constexpr int T_WORDS = 40;
+constexpr int T_IA = 20, T_WIDE = 21, T_REL = 22, T_PAR = 23, T_IDENT = 24, T_WORDS = 32;
 __device__ __forceinline__ int T(int i) { return __builtin_amdgcn_readfirstlane(I(4 * i)); }
 
 // copy `len` floats (16-B aligned, multiple of 4) of small parameters into LDS
@@ -236,8 +233,11 @@ __device__ __attribute__((noinline)) void linear_core(
             acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    // fetch cursor runs two items ahead of the compute cursor; fetches are unconditional (clamped)
-    // and the loop runs whole 2-step rounds, so that the compiler can count the loads in flight
+    // The fetch cursor runs two items ahead of the compute cursor.  Fetches are UNCONDITIONAL
+    // (addresses clamped) and the loop runs whole 2-step rounds (a ghost step past the end multiplies
+    // garbage into an accumulator that is never written): with a conditional load between a fetch and
+    // its use, hipcc's waitcnt pass cannot count the younger loads in flight and waits vmcnt(0),
+    // which silently serialises the prefetch.
     Cur cf = first(), cc = first();
     fetch(cf, w0);
     advance(cf);
@@ -269,7 +269,9 @@ __device__ __attribute__((noinline)) void linear_core(
 // channel).  nn.RMSNorm(eps=None): eps = finfo(float32).eps (layers.py:25-26); PE:
 // attention.py:59-61.  X, w, rel, pe_w, pe_b: LDS byte offsets (pe_w < 0: no positional term).
 __device__ __attribute__((noinline)) void norm_rows(int X, int ldx, int n, int c, int w, int rel,
-                                                    int d, int pe_w, int pe_b, const Img out) {
+                                                    int d, int pe_w, int pe_b, const Img out_) {
+    const Img out = UI(out_);
+    X = U(X), ldx = U(ldx), n = U(n), c = U(c), w = U(w), rel = U(rel), d = U(d), pe_w = U(pe_w), pe_b = U(pe_b);
     const int cp = round32(c), tpr = cp >> 2;  // threads per row: 8, 16 or 32 (power of two)
     const int sub = threadIdx.x & (tpr - 1), ch = 4 * sub;
     const int rows_per_pass = blockDim.x / tpr;
@@ -306,6 +308,7 @@ __device__ __attribute__((noinline)) void norm_rows(int X, int ldx, int n, int c
 // One thread per (dimension, place): a ball's places are `ball` consecutive lanes, so for the
 // power-of-two ball sizes (<= 64) the ball sum is a segmented xor-butterfly.
 __device__ __attribute__((noinline)) void ball_rel_pos(int P, int n, int d, int ball, int perm, int rel) {
+    P = U(P), n = U(n), d = U(d), ball = U(ball), perm = U(perm), rel = U(rel);
     if (ball <= 64 && (ball & (ball - 1)) == 0) {
         const int total = (n * d + 63) & ~63;  // whole waves: every lane takes part in the shuffles
         for (int i = threadIdx.x; i < total; i += blockDim.x) {
@@ -338,8 +341,10 @@ __device__ __attribute__((noinline)) void ball_rel_pos(int P, int n, int d, int 
 // that feeds the proj Linear.
 template <int HD>
 __device__ __attribute__((noinline)) void ball_attention(int qkv, int ldq, int n, int c, int heads,
-                                                         int ball, int perm, const Img out) {
+                                                         int ball, int perm, const Img out_) {
     constexpr int KC = 8;  // keys per step: 8 independent score chains, one rescale per step
+    const Img out = UI(out_);
+    qkv = U(qkv), ldq = U(ldq), n = U(n), c = U(c), heads = U(heads), ball = U(ball), perm = U(perm);
     const float scale = 1.0f / sqrtf((float)HD);
     for (int i = threadIdx.x; i < n * heads; i += blockDim.x) {
         const int place = i / heads, h = i % heads;
@@ -404,288 +409,53 @@ __device__ __forceinline__ const unsigned short* wptr(const float* W, int off) {
     return reinterpret_cast<const unsigned short*>(W + off);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Token-group execution of a block.  A wave owns a GROUP of 16 consecutive places of the block's
-// ball sequence and runs  norm1+PE -> qkv | barrier | attention -> proj -> +res -> norm2 ->
-// w1,w2 -> SwiGLU -> w3 -> +res  for those 16 tokens entirely by itself: every Linear of the chain is
-// row-local, only the attention needs other tokens (the k/v of its ball).  A block is therefore
-// TWO workgroup barriers and two long wave-local chains with deep weight prefetch, instead of
-// eight barrier-separated phases whose latency chains dominated the first version of this kernel
-// (stamped build: ~55k cycles per block at 2.4 GHz for ~3k cycles of MFMA work).
-constexpr int TG = 16;
-
-enum GEpi { G_QKV = 0, G_RESID = 1, G_SWIGLU = 2 };
-
-// Linear on one token group.  x: split image whose rows are PLACES (row0 = first place of the
-// group); the 16 x 16-output tiles are walked o-tile by o-tile, k-step fastest; four (o-tile,
-// k-step) weight items are in flight.  Output rows map to tokens tok[r] (rows 4*kq + r of this lane).
-__device__ __attribute__((noinline)) void group_linear(
-    const Img x_, int row0, int K, const unsigned short* __restrict__ Wa,
-    const unsigned short* __restrict__ Wb, int O, int mode, int dst, int ldd, int b0, int b1,
-    const Img di_, int tok0, int tok1, int tok2, int tok3, int nrows /* valid rows in the group */) {
-    const Img x = UI(x_), di = UI(di_);
-    row0 = U(row0), K = U(K), O = U(O), mode = U(mode), dst = U(dst), ldd = U(ldd), b0 = U(b0), b1 = U(b1);
-    nrows = U(nrows), Wa = UP(Wa), Wb = UP(Wb);
-    const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
-    const int Kp = round32(K), nks = Kp >> 5, nto = (O + 15) >> 4, items = nto * nks;
-    const size_t plane = (size_t)O * Kp;
-    const bool dual = mode == G_SWIGLU;
-    const int tok[4] = {tok0, tok1, tok2, tok3};
-    typedef const __attribute__((address_space(1))) u32x4* gv4;
-    const int xrow = x.base + min(row0 + l15, row0 + nrows - 1) * x.S + 16 * kq;
-
-    // Weight prefetch ring of four named register sets.  Every fetch is UNCONDITIONAL (the cursor
-    // is clamped to the last item) and the loop runs a whole number of 4-step rounds (ghost steps
-    // past the end multiply garbage into an accumulator that is never written): with a conditional
-    // load anywhere between a fetch and its use, hipcc's waitcnt pass can no longer count the
-    // younger loads in flight and falls back to vmcnt(0) -- which silently serialises the ring
-    // (measured: ~1.5k cycles per item instead of ~300).
-    u32x4 w0[4], w1[4], w2[4], w3[4];
-    int f_ot = 0, f_ks = 0;
-    auto fetch = [&](u32x4 (&wv)[4]) {
-        const size_t off = (size_t)min(min(f_ot, nto - 1) * 16 + l15, O - 1) * Kp + 32 * f_ks + 8 * kq;
-        wv[0] = *(gv4)(Wa + off);
-        wv[1] = *(gv4)(Wa + plane + off);
-        if (dual) {
-            wv[2] = *(gv4)(Wb + off);
-            wv[3] = *(gv4)(Wb + plane + off);
-        }
-        if (++f_ks == nks) {
-            f_ks = 0;
-            ++f_ot;
-        }
-    };
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    int c_ot = 0, c_ks = 0;
-    auto step = [&](const u32x4 (&wv)[4]) {
-        const u32x4 xh = *reinterpret_cast<const u32x4*>(smem + xrow + 64 * c_ks);
-        const u32x4 xl = *reinterpret_cast<const u32x4*>(smem + xrow + 64 * c_ks + x.plane);
-        acc0 = mfma3(xh, xl, wv[0], wv[1], acc0);
-        if (dual) acc1 = mfma3(xh, xl, wv[2], wv[3], acc1);
-        if (++c_ks == nks) {
-            const int o = c_ot * 16 + l15;
-            if (c_ot < nto && o < O) {
-                const float bo = F(b0 + 4 * o);
-                if (mode == G_QKV) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (4 * kq + r < nrows) F(dst + 4 * (tok[r] * ldd + o)) = acc0[r] + bo;
-                } else if (mode == G_RESID) {
-                    float old[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) old[r] = F(dst + 4 * (tok[r] * ldd + o));
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (4 * kq + r < nrows) F(dst + 4 * (tok[r] * ldd + o)) = old[r] + acc0[r] + bo;
-                } else {
-                    const float b1o = F(b1 + 4 * o);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = acc0[r] + bo;
-                        const float sig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
-                        di.put(row0 + 4 * kq + r, o, (acc1[r] + b1o) * (v * sig));
-                    }
-                }
-            }
-            acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-            c_ks = 0;
-            ++c_ot;
-        }
-    };
-    fetch(w0);
-    fetch(w1);
-    fetch(w2);
-    fetch(w3);
-#define GL_STEP(WS)                                  \
-    {                                                \
-        u32x4 cw[4] = {WS[0], WS[1], WS[2], WS[3]};  \
-        fetch(WS);                                   \
-        step(cw);                                    \
-    }
-    for (int it = 0; it < items; it += 4) {
-        GL_STEP(w0)
-        GL_STEP(w1)
-        GL_STEP(w2)
-        GL_STEP(w3)
-    }
-#undef GL_STEP
-}
-
-// out[place rows of the group] = split( RMSNorm(X[tok]) * w [+ pe_b + rel[tok] . pe_w] ); one wave,
-// 4 lanes per row, float4 channel chunks (c <= 128).
-__device__ __attribute__((noinline)) void group_norm(int X, int ldx, int c, int w, int rel, int d, int pe_w,
-                                                     int pe_b, int perm, int row0, int nrows, const Img out_) {
-    const Img out = UI(out_);
-    X = U(X), ldx = U(ldx), c = U(c), w = U(w), rel = U(rel), d = U(d), pe_w = U(pe_w), pe_b = U(pe_b);
-    perm = U(perm), row0 = U(row0), nrows = U(nrows);
-    const int lane = threadIdx.x & 63, r = lane >> 2, sub = lane & 3;
-    const int cp = round32(c), iters = cp >> 4;  // float4 chunks per lane: channels 4*sub + 16*i
-    const bool live = r < nrows;
-    const int tok = I(perm + 4 * (row0 + min(r, nrows - 1)));
-    f32x4 xv[8];
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int ch = 4 * sub + 16 * i;
-        if (i < iters && ch < c) {
-            xv[i] = *reinterpret_cast<const f32x4*>(smem + X + 4 * (tok * ldx + ch));
-            ss = fmaf(xv[i][0], xv[i][0], fmaf(xv[i][1], xv[i][1], fmaf(xv[i][2], xv[i][2], fmaf(xv[i][3], xv[i][3], ss))));
-        }
-    }
-    ss += __shfl_xor(ss, 1);
-    ss += __shfl_xor(ss, 2);
-    const float rn = rsqrtf(ss / (float)c + 1.1920928955078125e-07f);
-    float rl[3] = {0.f, 0.f, 0.f};
-    if (pe_w >= 0)
-        for (int j = 0; j < d; ++j) rl[j] = F(rel + 4 * (tok * d + j));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int ch = 4 * sub + 16 * i;
-        if (i < iters) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ch < c) {
-                v = xv[i] * rn * *reinterpret_cast<const f32x4*>(smem + w + 4 * ch);
-                if (pe_w >= 0) {
-                    f32x4 pe = *reinterpret_cast<const f32x4*>(smem + pe_b + 4 * ch);
-                    for (int j = 0; j < d; ++j)
-                        pe += rl[j] * *reinterpret_cast<const f32x4*>(smem + pe_w + 4 * (j * c + ch));
-                    v += pe;
-                }
-            }
-            if (live) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) out.put(row0 + r, ch + e, v[e]);
-            }
-        }
-    }
-}
-
-// exact softmax(q k^T / sqrt(hd)) v for the 16 places x heads of one group (attention.py:68-84;
-// the reference calls flash_attn_qkvpacked_func here); keys = the ball of each place.
-template <int HD>
-__device__ __attribute__((noinline)) void group_attention(int qkv, int ldq, int c, int heads, int ball,
-                                                          int perm, int row0, int nrows, const Img out_) {
-    constexpr int KC = 8;
-    const Img out = UI(out_);
-    qkv = U(qkv), ldq = U(ldq), c = U(c), heads = U(heads), ball = U(ball), perm = U(perm), row0 = U(row0);
-    nrows = U(nrows);
-    const float scale = 1.0f / sqrtf((float)HD);
-    const int lane = threadIdx.x & 63;
-    for (int j = lane; j < nrows * heads; j += 64) {
-        const int r = j / heads, h = j - r * heads;
-        const int place = row0 + r, tq = I(perm + 4 * place), b0 = (place / ball) * ball;
-        float q[HD], acc[HD];
-#pragma unroll
-        for (int e = 0; e < HD; ++e) {
-            q[e] = F(qkv + 4 * (tq * ldq + h * HD + e)) * scale;
-            acc[e] = 0.f;
-        }
-        float m = -INFINITY, l = 0.f;
-        for (int p0 = 0; p0 < ball; p0 += KC) {
-            int kr[KC];
-            float sc[KC];
-            float mx = m;
-#pragma unroll
-            for (int u = 0; u < KC; ++u) kr[u] = qkv + 4 * (I(perm + 4 * (b0 + min(p0 + u, ball - 1))) * ldq + c + h * HD);
-#pragma unroll
-            for (int u = 0; u < KC; ++u) {
-                float sv = 0.f;
-#pragma unroll
-                for (int e = 0; e < HD; ++e) sv = fmaf(q[e], F(kr[u] + 4 * e), sv);
-                sc[u] = (p0 + u < ball) ? sv : -INFINITY;
-                mx = fmaxf(mx, sc[u]);
-            }
-            const float a = __expf(m - mx);
-            l *= a;
-#pragma unroll
-            for (int e = 0; e < HD; ++e) acc[e] *= a;
-#pragma unroll
-            for (int u = 0; u < KC; ++u) {
-                const float pr = __expf(sc[u] - mx);
-                l += pr;
-#pragma unroll
-                for (int e = 0; e < HD; ++e) acc[e] = fmaf(pr, F(kr[u] + 4 * (c + e)), acc[e]);
-            }
-            m = mx;
-        }
-        const float inv = 1.0f / l;
-#pragma unroll
-        for (int e = 0; e < HD; ++e) out.put(place, h * HD + e, acc[e] * inv);
-    }
-}
-
-__device__ __attribute__((noinline)) void group_attention_dispatch(int hd, int qkv, int ldq, int c, int heads,
-                                                                   int ball, int perm, int row0, int nrows,
-                                                                   const Img out) {
-    switch (hd) {
-        case 1: group_attention<1>(qkv, ldq, c, heads, ball, perm, row0, nrows, out); break;
-        case 2: group_attention<2>(qkv, ldq, c, heads, ball, perm, row0, nrows, out); break;
-        case 4: group_attention<4>(qkv, ldq, c, heads, ball, perm, row0, nrows, out); break;
-        case 8: group_attention<8>(qkv, ldq, c, heads, ball, perm, row0, nrows, out); break;
-        case 16: group_attention<16>(qkv, ldq, c, heads, ball, perm, row0, nrows, out); break;
-        case 32: group_attention<32>(qkv, ldq, c, heads, ball, perm, row0, nrows, out); break;
-        default: group_attention<64>(qkv, ldq, c, heads, ball, perm, row0, nrows, out); break;
-    }
-}
-
 // ErwinTransformerBlock (layers.py:30-32) on the tokens of one level, in place
 __device__ __attribute__((noinline)) void erwin_block(int lvl, const haet_erwin_layer& L,
                                                       const haet_erwin_block_w& w,
-                                                      const float* __restrict__ W, int d, int perm, int rotated) {
-    lvl = U(lvl), d = U(d), perm = U(perm), rotated = U(rotated), W = UP(W);
+                                                      const float* __restrict__ W, int d, int perm) {
+    lvl = U(lvl), d = U(d), perm = U(perm), W = UP(W);
     const int X = T(T_X + lvl), n = T(T_N + lvl), ld = T(T_LD + lvl), c = L.c, hid = L.hidden;
-    const int ldq = 3 * c + kPad, qbuf = T(T_WIDE), rel = T(T_RELV + 2 * lvl + rotated);
-    const int npad = (n + TG - 1) / TG * TG;
-    const Img ia = {T(T_IA), img_stride(c), npad * img_stride(c)};
-    const Img ih = {T(T_HID), img_stride(hid), npad * img_stride(hid)};
+    const int ldq = 3 * c + kPad, wide = T(T_WIDE);
+    const Img ia = {T(T_IA), img_stride(c), n * img_stride(c)};
+    const Img ih = {wide, img_stride(hid), n * img_stride(hid)};
     const Img none = {0, 0, 0};
-    const int wave = U(threadIdx.x >> 6), nwaves = blockDim.x >> 6, kq = (threadIdx.x & 63) >> 4;
-    const int ngroups = npad / TG;
     // norm weights, positional projection and every bias of this block: one coalesced copy to LDS
+    // (they are re-read per token / per tile; from global each use is a dependent L2/HBM trip)
     const int par = T(T_PAR) - 4 * w.small_off;  // par + 4 * <blob offset> addresses the LDS copy
     STAMP(16);
     stage_params(T(T_PAR), W + w.small_off, w.small_len);
+    // x~ = RMSNorm(x) + pe_proj(pos - ball centre)            (attention.py:59-61)
+    ball_rel_pos(T(T_P + lvl), n, d, L.ball, perm, T(T_REL));
     __syncthreads();
     STAMP(17);
-    // --- chain A: x~ = RMSNorm(x) + pe_proj(pos - ball centre) -> qkv          (attention.py:59-64)
-    for (int g = wave; g < ngroups; g += nwaves) {
-        const int row0 = TG * g, nrows = min(TG, n - row0);
-        int tok[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tok[r] = I(perm + 4 * (row0 + min(4 * kq + r, nrows - 1)));
-        group_norm(X, ld, c, par + 4 * w.norm1, rel, d, par + 4 * w.pe_w, par + 4 * w.pe_b, perm, row0, nrows, ia);
-        group_linear(ia, row0, c, wptr(W, w.qkv_w), nullptr, 3 * c, G_QKV, qbuf, ldq, par + 4 * w.qkv_b, 0, none,
-                     tok[0], tok[1], tok[2], tok[3], nrows);
-    }
-    __syncthreads();  // every token's k / v is in place
+    norm_rows(X, ld, n, c, par + 4 * w.norm1, T(T_REL), d, par + 4 * w.pe_w, par + 4 * w.pe_b, ia);
+    __syncthreads();
+    STAMP(18);
+    linear_core(ia, n, c, wptr(W, w.qkv_w), nullptr, 3 * c, EP_QKV, wide, ldq, par + 4 * w.qkv_b, 0, 0, 0,
+                none, 0, 0);
+    __syncthreads();
     STAMP(19);
-    // --- chain B: attention -> proj -> +res -> RMSNorm -> SwiGLU -> +res        (layers.py:30-32)
-    for (int g = wave; g < ngroups; g += nwaves) {
-        const int row0 = TG * g, nrows = min(TG, n - row0);
-        int tok[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tok[r] = I(perm + 4 * (row0 + min(4 * kq + r, nrows - 1)));
-        group_attention_dispatch(c / L.heads, qbuf, ldq, c, L.heads, L.ball, perm, row0, nrows, ia);
-        group_linear(ia, row0, c, wptr(W, w.proj_w), nullptr, c, G_RESID, X, ld, par + 4 * w.proj_b, 0, none,
-                     tok[0], tok[1], tok[2], tok[3], nrows);
-        group_norm(X, ld, c, par + 4 * w.norm2, 0, 0, -1, 0, perm, row0, nrows, ia);
-        if (T(T_ALIAS)) __syncthreads();  // hidden image shares LDS with the qkv rows (tight LDS only)
-        {
-            const int padk = round32(hid) - hid, lane = threadIdx.x & 63;  // zero the k padding
-            for (int i = lane; i < nrows * padk; i += 64) ih.put(row0 + i / padk, hid + i % padk, 0.f);
-        }
-        group_linear(ia, row0, c, wptr(W, w.w1_w), wptr(W, w.w2_w), hid, G_SWIGLU, 0, 0, par + 4 * w.w1_b,
-                     par + 4 * w.w2_b, ih, tok[0], tok[1], tok[2], tok[3], nrows);
-        group_linear(ih, row0, hid, wptr(W, w.w3_w), nullptr, c, G_RESID, X, ld, par + 4 * w.w3_b, 0, none,
-                     tok[0], tok[1], tok[2], tok[3], nrows);
+    attention_dispatch(c / L.heads, wide, ldq, n, c, L.heads, L.ball, perm, ia);
+    __syncthreads();
+    STAMP(20);
+    linear_core(ia, n, c, wptr(W, w.proj_w), nullptr, c, EP_RESID, X, ld, par + 4 * w.proj_b, 0, 0, 0, none,
+                0, 0);
+    __syncthreads();
+    STAMP(21);
+    // x += W3( W2 x^ * silu(W1 x^) ),  x^ = RMSNorm(x)          (mlp.py:17-18)
+    norm_rows(X, ld, n, c, par + 4 * w.norm2, 0, 0, -1, 0, ia);
+    {
+        const int padk = round32(hid) - hid;  // zero the k padding of the hidden image
+        for (int i = threadIdx.x; i < n * padk; i += blockDim.x) ih.put(i / padk, hid + i % padk, 0.f);
     }
-    if (T(T_ALIAS)) {  // waves without a group still have to meet the in-chain barrier
-        const int mine = wave < ngroups ? (ngroups - wave + nwaves - 1) / nwaves : 0;
-        const int most = (ngroups + nwaves - 1) / nwaves;
-        for (int i = mine; i < most; ++i) __syncthreads();
-    }
+    __syncthreads();
+    STAMP(22);
+    linear_core(ia, n, c, wptr(W, w.w1_w), wptr(W, w.w2_w), hid, EP_SWIGLU, 0, 0, par + 4 * w.w1_b,
+                par + 4 * w.w2_b, 0, 0, ih, 0, 0);
+    __syncthreads();
+    STAMP(23);
+    linear_core(ih, n, hid, wptr(W, w.w3_w), nullptr, c, EP_RESID, X, ld, par + 4 * w.w3_b, 0, 0, 0, none, 0,
+                0);
     __syncthreads();
     STAMP(24);
 }
@@ -767,26 +537,22 @@ __host__ __device__ inline int erwin_max_small(const haet_erwin_desc& D) {
     return (m + 3) & ~3;
 }
 
-// LDS carve-up shared by host (sizing) and device; returns the total in floats.  `wide` holds the
-// qkv rows (fp32) and the pooling rows; `hid` the SwiGLU hidden image.  When everything does not
-// fit 160 KiB (M = 128), `hid` aliases `wide` and the block pays one extra barrier (*alias = 1).
+// LDS carve-up shared by host (sizing) and device; returns the total in floats
 __host__ __device__ inline int erwin_layout(const haet_erwin_desc& D, int Mp, int* ia_bytes,
-                                            int* wide_bytes, int* hid_bytes, int* alias) {
-    int n = Mp, ia = 0, wide = 0, hidb = 0, tot = T_WORDS, idx = 0, relv = 0;
+                                            int* wide_bytes) {
+    int n = Mp, ia = 0, wide = 0, tot = T_WORDS, idx = 0;
     const int d = D.d;
     for (int l = 0; l < D.n_levels; ++l) {
         const haet_erwin_layer& L = D.enc[l];
-        const int npad = (n + 15) / 16 * 16;
         tot += n * (L.c + kPad) + ((n * d + 3) & ~3);
         idx += n;
-        relv += 2 * ((n * d + 3) & ~3);
-        const int a = 2 * npad * img_stride(L.c);
+        const int a = 2 * n * img_stride(L.c);
         ia = ia > a ? ia : a;
         int hid = L.hidden;
         if (l < D.n_levels - 1 && D.dec[l].hidden > hid) hid = D.dec[l].hidden;
         int w = n * (3 * L.c + kPad) * 4;
-        const int wh = 2 * npad * img_stride(hid);
-        hidb = hidb > wh ? hidb : wh;
+        const int wh = 2 * n * img_stride(hid);
+        w = w > wh ? w : wh;
         if (l < D.n_levels - 1) {
             const int st = D.pool[l].stride, n2 = n / st;
             const int wp = 2 * n2 * img_stride(st * L.c + st * d);
@@ -798,17 +564,9 @@ __host__ __device__ inline int erwin_layout(const haet_erwin_desc& D, int Mp, in
         wide = wide > w ? wide : w;
     }
     *ia_bytes = (ia + 15) & ~15;
-    wide = (wide + 15) & ~15;
-    hidb = (hidb + 15) & ~15;
-    tot += *ia_bytes / 4 + relv + erwin_max_small(D) + idx + Mp;
-    *alias = (tot * 4 + wide + hidb) > 160 * 1024;
-    if (*alias) {
-        wide = wide > hidb ? wide : hidb;
-        hidb = 0;
-    }
-    *wide_bytes = wide;
-    *hid_bytes = hidb;
-    return tot + (wide + hidb) / 4;
+    *wide_bytes = (wide + 15) & ~15;
+    tot += (*ia_bytes + *wide_bytes) / 4 + ((Mp * d + 3) & ~3) + erwin_max_small(D) + idx + Mp;
+    return tot;
 }
 
 // The weight blob starts with a copy of the descriptor (read with scalar loads).
@@ -821,8 +579,8 @@ __global__ __launch_bounds__(512) void erwin_kernel(
     const haet_erwin_desc& D = *reinterpret_cast<const haet_erwin_desc*>(W);
     const int cloud = blockIdx.x, n_clouds = gridDim.x, d = D.d, nl = D.n_levels;
     if (threadIdx.x == 0) {  // LDS directory
-        int ia_bytes, wide_bytes, hid_bytes, alias;
-        erwin_layout(D, Mp, &ia_bytes, &wide_bytes, &hid_bytes, &alias);
+        int ia_bytes, wide_bytes;
+        erwin_layout(D, Mp, &ia_bytes, &wide_bytes);
         int p = 4 * T_WORDS, n = Mp;
         for (int l = 0; l < nl; ++l) {
             I(4 * (T_N + l)) = n;
@@ -838,19 +596,9 @@ __global__ __launch_bounds__(512) void erwin_kernel(
         I(4 * T_IA) = p;
         p += ia_bytes;
         I(4 * T_WIDE) = p;
-        I(4 * T_HID) = p;  // aliases `wide` unless there is room for both
-        I(4 * T_ALIAS) = alias;
         p += wide_bytes;
-        if (!alias) {
-            I(4 * T_HID) = p;
-            p += hid_bytes;
-        }
-        I(4 * T_REL) = p;  // (kept for the layout; ball centres now live in T_RELV)
-        for (int l = 0; l < nl; ++l)
-            for (int v = 0; v < 2; ++v) {
-                I(4 * (T_RELV + 2 * l + v)) = p;
-                p += 4 * ((I(4 * (T_N + l)) * d + 3) & ~3);
-            }
+        I(4 * T_REL) = p;
+        p += 4 * ((Mp * d + 3) & ~3);
         I(4 * T_PAR) = p;
         p += 4 * erwin_max_small(D);
         for (int l = 0; l < nl; ++l) {
@@ -881,9 +629,6 @@ __global__ __launch_bounds__(512) void erwin_kernel(
             off += (size_t)n_clouds * nlv;
         }
     }
-    __syncthreads();
-    ball_rel_pos(P0, T(T_N), d, D.enc[0].ball, ident, T(T_RELV));  // ball centres of level 0, both sequences
-    if (D.rotate) ball_rel_pos(P0, T(T_N), d, D.enc[0].ball, T(T_ROT), T(T_RELV + 1));
     __syncthreads();
     STAMP(2);
 
@@ -916,15 +661,9 @@ __global__ __launch_bounds__(512) void erwin_kernel(
             const haet_erwin_layer& L = (b & 256) ? D.dec[a] : D.enc[a];
             const int j = b & 255;
             const bool rt = D.rotate && L.depth > 1 && (j & 1);  // layers.py:66,75-89
-            erwin_block(a, L, L.blocks[j], W, d, rt ? T(T_ROT + a) : ident, rt ? 1 : 0);
+            erwin_block(a, L, L.blocks[j], W, d, rt ? T(T_ROT + a) : ident);
         } else if (kind == 1) {
             erwin_pool(a, D, W);
-            // ball centres of the new level (its positions were just pooled)
-            ball_rel_pos(T(T_P + a + 1), T(T_N + a + 1), d, D.enc[a + 1].ball, ident, T(T_RELV + 2 * (a + 1)));
-            if (D.rotate)
-                ball_rel_pos(T(T_P + a + 1), T(T_N + a + 1), d, D.enc[a + 1].ball, T(T_ROT + a + 1),
-                             T(T_RELV + 2 * (a + 1) + 1));
-            __syncthreads();
         } else {
             erwin_unpool(a, D, W);
         }
@@ -987,8 +726,8 @@ extern "C" int haet_debug_read_stamps(unsigned long long* host_out) {
 
 extern "C" size_t haet_erwin_lds_bytes(const haet_erwin_desc* desc, int Mp) {
     if (erwin_validate(desc, Mp) != HAET_OK) return 0;
-    int a, w, h, al;
-    return (size_t)erwin_layout(*desc, Mp, &a, &w, &h, &al) * sizeof(float);
+    int a, w;
+    return (size_t)erwin_layout(*desc, Mp, &a, &w) * sizeof(float);
 }
 
 extern "C" int haet_erwin_fwd(const float* tokens, const float* pos, const int32_t* tree_idx,
@@ -1005,8 +744,8 @@ extern "C" int haet_erwin_fwd(const float* tokens, const float* pos, const int32
     int rc = erwin_validate(desc, Mp);
     if (rc != HAET_OK) return rc;
     if (desc->rotate && !rot) return fail(HAET_E_ARG, "erwin: rotate set but rot is NULL");
-    int a, w, h, al;
-    const size_t bytes = (size_t)erwin_layout(*desc, Mp, &a, &w, &h, &al) * sizeof(float);
+    int a, w;
+    const size_t bytes = (size_t)erwin_layout(*desc, Mp, &a, &w) * sizeof(float);
     if (bytes > 160 * 1024)
         return fail(HAET_E_RESOURCE, "erwin: one cloud needs %zu B of LDS (> 160 KiB)", bytes);
     static thread_local size_t attr_set = 0;

@@ -36,5 +36,9 @@ prev = 0
 for i in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12):
     print(f"  {names[i]:22s} +{t[i]-t[prev]:8d} cycles")
     prev = i
-print("last block (dec0 block 1): params", t[17] - t[16], "| chain A (norm1+PE, qkv)", t[19] - t[17],
-      "| chain B (attention, proj, norm2, SwiGLU)", t[24] - t[19])
+print("last block (dec0 block 1) phases:")
+bn = {17: "params+rel_pos", 18: "norm1+pe", 19: "qkv", 20: "attention", 21: "proj", 22: "norm2", 23: "w1w2", 24: "w3"}
+for i in range(17, 25):
+    print(f"  {bn[i]:14s} {t[i]-t[i-1]:8d} cycles")
+print("inside the last proj/w3-type Linear call (wave 0): entry -> fetch issued -> operands read -> MFMAs done -> exit")
+print("  ", [t[i] - t[40] for i in range(40, 45)], " (phase entry stamp to linear entry:", t[40] - t[23], ")")
