@@ -34,7 +34,7 @@ STAGES = ("project", "slice", "merge", "token", "erwin", "deslice", "to_out")
 # de-slice pass reads and writes D.
 BYTES_PER_POINT = {"project": lambda D: 8 * D, "slice": lambda D: 4 * D, "deslice": lambda D: 8 * D,
                    "to_out": lambda D: 8 * D}
-KERNEL_OF_STAGE = {"project": "gemm_x3", "slice": "slice", "deslice": "deslice", "to_out": "gemm_x3"}
+KERNEL_OF_STAGE = {"project": "gemm_ws", "slice": "slice", "deslice": "deslice", "to_out": "gemm_ws"}
 
 
 def build_module(dev):

@@ -13,6 +13,8 @@
 // HBM stream full across row tiles (see the kernel).
 #include "common.h"
 
+#include <type_traits>
+
 namespace haet {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -266,6 +268,225 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
 #undef GEMM_STEP
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// W-stationary variant (K = 128 / 256, O % 256 == 0): the whole split weight lives in REGISTERS.
+// Each of the 8 waves of a (persistent, one per CU) workgroup owns 32 output columns and keeps
+// their W rows -- K x 32 x {hi, lo} bf16 = K/2 VGPRs per lane, 128 at K = 256 -- as ready-made
+// MFMA B fragments for the lifetime of the kernel (gfx950: 512 registers per SIMD lane, 2 waves
+// per SIMD -> 256 each).  What streams is x only, in 64-row tiles:
+//   * x is read in whole rows -- one wave instruction = 1 KB contiguous -- converted fp32 ->
+//     {hi, lo} bf16 by the loader and parked in LDS as the [32 rows][32 k] images of ALL k-items of
+//     the tile (64 KB; two tiles resident), one barrier per TILE,
+//   * no W traffic at all (the streaming kernel above re-stages 32 KB of W per 32 KB of x and is
+//     ~15 % slower; it stays for the other shapes),
+//   * stores and loads share ONE in-order counter on gfx9 (vmcnt): a wait for a prefetched load
+//     that is older than a burst of stores asks for the stores to drain.  So the epilogue is spread
+//     out (see run_tile), the loop is fully unrolled with all fetches unconditional, and the
+//     prologue imitates the steady-state operation pattern: every wait in the loop is vmcnt(8).
+// Budget at 1M x 256 x 256 (measured on this part): HBM at copy rate 0.40 ms; the 3 x 12M MFMAs
+// 0.23 ms (random operands clock the matrix cores at ~1.65 GHz; 0.157 ms is the 2.4 GHz figure);
+// this kernel 0.52-0.55 ms stand-alone.  Prefetch depth (S = 2/4/8), LDS fragment look-ahead and
+// store width were each varied without effect; what is left is the overlap of a single
+// barrier-coupled workgroup per CU, the price of 128 registers of W per wave.
+#ifdef HAET_STAMPS
+// Diagnostic build only (make EXTRA=-DHAET_STAMPS; tools/gemm_stamps.py): s_memtime along one tile
+// of one workgroup, waves 0 and 4 (same SIMD).  Never quote this build's run time.
+__device__ unsigned long long haet_gemm_stamps[64];
+#define GSTAMP(i) gst[i] = __builtin_amdgcn_s_memtime()
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
+constexpr int WS_IMGP = 2 * GIMG + 32;  // {hi, lo} image pair + 8 banks of skew between k-items
+template <int NKT, int S>
+__global__ __launch_bounds__(512) void gemm_ws_kernel(
+    const float* __restrict__ x, const unsigned short* __restrict__ Whi,
+    const unsigned short* __restrict__ Wlo, const float* __restrict__ bias, int Nrows, int O,
+    int n_row_tiles, float* __restrict__ out) {
+    constexpr int K = NKT * GBK, BM = 64;
+    constexpr int RBSZ = NKT * WS_IMGP, TBUF = 2 * RBSZ;  // one 32-row block, one tile
+    constexpr int LPR = K / 4, RPI = 64 / LPR;            // lanes per x row, rows per wave load
+    static_assert(NKT % S == 0 && S >= 2 && (NKT == 4 || NKT == 8), "prefetch ring must divide the tile");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+    const int col = blockIdx.y * 256 + 32 * wave + l31;  // this lane's output column
+    const int my_tiles = n_row_tiles > (int)blockIdx.x ? (n_row_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    if (my_tiles == 0) return;
+
+    // stationary B fragments: k-step s (16 wide) -> k = 16 s + 8 hf .. + 8 of row `col` of W
+    u32x4 wh[2 * NKT], wl[2 * NKT];
+#pragma unroll
+    for (int s = 0; s < 2 * NKT; ++s) {
+        const size_t o = (size_t)col * K + 16 * s + 8 * hf;
+        wh[s] = *reinterpret_cast<const u32x4*>(Whi + o);
+        wl[s] = *reinterpret_cast<const u32x4*>(Wlo + o);
+    }
+    const float bv = bias ? bias[col] : 0.f;
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = bv;
+
+    // loader: fetch j of a tile = rows 8 wave + RPI j (+ lane / LPR), 16 B per lane, whole rows.
+    // The last (and every ghost) tile is SHIFTED to end at row Nrows instead of being clamped row by
+    // row: it recomputes a few rows of its neighbour (same operands, same values) and nothing on
+    // the load or store path needs a per-row address.
+    const int lrow = lane / LPR, lcol = lane % LPR;  // row within the wave load, 16-B chunk of the row
+    const int lkt = lcol >> 3, lq = lcol & 7;        // k-item and 16-B chunk inside the 32-wide item
+    auto tile_row0 = [&](int t) {                    // first row of this workgroup's t-th tile
+        const long long r = ((long long)blockIdx.x + (long long)t * gridDim.x) * BM;
+        return r + BM <= Nrows ? r : (long long)Nrows - BM;
+    };
+    const unsigned x_voff = (unsigned)(((8 * wave + lrow) * K + 4 * lcol) * 4);  // bytes from the tile base
+    auto fetch = [&](const char* tile_base, int j) {  // RPI rows further = exactly 1 KB
+        return *reinterpret_cast<const f32x4*>(tile_base + x_voff + 1024 * j);
+    };
+    // LDS address of fetch j: row = 8 wave + RPI j + lrow; the swizzle term changes once, at j = NKT/2
+    int st_off[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 8 * wave + 4 * h + lrow;
+        st_off[h] = (row >> 5) * RBSZ + lkt * WS_IMGP + g_off(row & 31, lq >> 1) + ((lq & 1) << 3) - 4 * h * 64;
+    }
+    auto stage = [&](int tbuf, int j, const f32x4 v) {
+        const int off = tbuf + st_off[j >= NKT / 2] + RPI * j * 64;
+        const unsigned h01 = g_pack(v[0], v[1]), h23 = g_pack(v[2], v[3]);
+        const u32x2 hi = {h01, h23};
+        const u32x2 lo = {g_pack(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u)),
+                          g_pack(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u))};
+        *reinterpret_cast<u32x2*>(gsm + off) = hi;
+        *reinterpret_cast<u32x2*>(gsm + off + GIMG) = lo;
+    };
+    auto mfma3 = [&](f32x16& c, const GFrag& f, const u32x4 bhv, const u32x4 blv) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bhv), bl = __builtin_bit_cast(bf16x8, blv);
+        const bf16x8 fh = __builtin_bit_cast(bf16x8, f.hi), fl = __builtin_bit_cast(bf16x8, f.lo);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bh, c, 0, 0, 0);
+    };
+
+    // Epilogue stores.  An accumulator holds, per lane, ONE column and 4 x 4 consecutive rows; a
+    // 4 x 4 transpose across each quad of lanes (two DPP butterflies, 16 VALU per register group)
+    // turns that into one row and 4 consecutive columns, so a group goes out as one
+    // global_store_dwordx4 covering 8 rows x 128 B instead of four dword stores of 2 rows x 128 B
+    // each: the memory pipeline takes ~170 cycles per store INSTRUCTION when every CU is storing.
+    const int col4 = blockIdx.y * 256 + 32 * wave + (l31 & ~3);  // first of this lane's 4 output columns
+    const unsigned o_voff = (unsigned)(((4 * hf + (lane & 3)) * O + col4) * 4);  // bytes from the tile's first row
+    constexpr int GPS = NKT == 8 ? 2 : 1;  // sub-steps per stored register group (4 groups per phase)
+    auto store_group = [&](char* ob, const f32x16& c, int i, int g) {
+        int v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = __float_as_int(c[4 * g + q]);
+        const bool odd = lane & 1, up = lane & 2;
+#pragma unroll
+        for (int m = 0; m < 4; m += 2) {  // lanes ^ 1: (reg m+1, even lane) <-> (reg m, odd lane)
+            const int send = odd ? v[m] : v[m + 1];
+            const int recv = __builtin_amdgcn_update_dpp(0, send, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+            v[m] = odd ? recv : v[m];
+            v[m + 1] = odd ? v[m + 1] : recv;
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {  // lanes ^ 2: (reg m+2, lanes 0,1) <-> (reg m, lanes 2,3)
+            const int send = up ? v[m] : v[m + 2];
+            const int recv = __builtin_amdgcn_update_dpp(0, send, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+            v[m] = up ? recv : v[m];
+            v[m + 2] = up ? v[m + 2] : recv;
+        }
+        const f32x4 o4 = {__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])};
+        *reinterpret_cast<f32x4*>(ob + o_voff + (unsigned)((32 * i + 8 * g) * O * 4)) = o4;
+    };
+
+    // prologue: tile 0 staged, fetches 0 .. S-1 of tile 1 in flight.  Each fetch is followed by the
+    // stores that follow it in the steady state (here: the bias into rows of tile 0, which this very
+    // lane overwrites later): the waitcnt pass merges the pending-operation state of the loop entry
+    // with the back edge's conservatively, and without them every tile started by draining its
+    // predecessor's stores (vmcnt(3) where vmcnt(19) would do).
+    f32x4 xs[S];
+    const char* const xb = reinterpret_cast<const char*>(x);
+    {
+        const char* b0 = xb + tile_row0(0) * (K * 4);
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) stage(0, j, fetch(b0, j));
+        const char* b1 = xb + tile_row0(1) * (K * 4);
+        char* o0 = reinterpret_cast<char*>(out) + tile_row0(0) * ((long long)O * 4);
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            __builtin_amdgcn_sched_barrier(0);  // x is __restrict__: the loads would drift past the stores
+            xs[i] = fetch(b1, i);
+            __builtin_amdgcn_sched_barrier(0);
+            if (GPS == 1) store_group(o0, acc[0], 0, (2 * i) & 3);
+            store_group(o0, acc[0], 0, (GPS == 1 ? 2 * i + 1 : i) & 3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+
+    // A tile is walked as two 32-row phases (accumulator 0, then 1), NKT sub-steps of 6 MFMAs each.
+    // While one accumulator is on the matrix cores the OTHER, finished one is written out, one
+    // register group every GPS sub-steps: a wave issues in order, and a burst of stores at the tile
+    // end (the memory system takes a store instruction every ~170 cycles when every CU stores at
+    // once) keeps the wave, and the loads queued behind the burst, away from the MFMAs.  No extra
+    // registers: the idle accumulator is the store buffer.
+    auto run_tile = [&](int t) {
+#ifdef HAET_STAMPS
+        unsigned long long gst[NKT + 2];
+#endif
+        GSTAMP(0);
+        const int cur = (t & 1) * TBUF, nxt = TBUF - cur;
+        const char* b1 = xb + tile_row0(t + 1) * (K * 4);
+        const char* b2 = xb + tile_row0(t + 2) * (K * 4);
+        // (t = 0: nothing to store yet -- the bias goes to this tile's own rows and is overwritten later)
+        char* o_prev = reinterpret_cast<char*>(out) + tile_row0(t ? t - 1 : 0) * ((long long)O * 4);
+        char* o_cur = reinterpret_cast<char*>(out) + tile_row0(t) * ((long long)O * 4);
+        GFrag a = g_read(cur, l31, hf);
+#pragma unroll
+        for (int u = 0; u < 2 * NKT; ++u) {
+            const int rb = u / NKT, kt = u % NKT;
+            if (u % 2 == 0) {  // stage fetch u/2 of tile t + 1 from its set, refill the set S fetches on
+                const int j = u / 2;
+                stage(nxt, j, xs[j % S]);
+                xs[j % S] = j + S < NKT ? fetch(b1, j + S) : fetch(b2, j + S - NKT);
+            }
+            if (kt % GPS == GPS - 1) {
+                if (rb == 0) store_group(o_prev, acc[1], 1, kt / GPS);
+                else store_group(o_cur, acc[0], 0, kt / GPS);
+            }
+            const int img = cur + rb * RBSZ + kt * WS_IMGP;
+            const GFrag f = g_read(img, l31, hf + 2);
+            // sched_barrier: left alone, the scheduler sinks every fragment read to just before its
+            // first use (fewest live registers), which is exactly the LDS round trip to hide
+            __builtin_amdgcn_sched_barrier(0);
+            mfma3(acc[rb], a, wh[2 * kt], wl[2 * kt]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u + 1 < 2 * NKT) a = g_read(cur + ((u + 1) / NKT) * RBSZ + ((u + 1) % NKT) * WS_IMGP, l31, hf);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma3(acc[rb], f, wh[2 * kt + 1], wl[2 * kt + 1]);
+            if (kt == NKT - 1) {  // the other accumulator is stored by now: back to the bias
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[1 - rb][r] = bv;
+            }
+            if (u % 2 == 1) GSTAMP(1 + u / 2);
+        }
+        __syncthreads();
+        GSTAMP(NKT + 1);
+#ifdef HAET_STAMPS
+        if (blockIdx.x == 5 && t == 10 && (tid & 255) == 0) {
+#pragma unroll
+            for (int i = 0; i < NKT + 2; ++i) haet_gemm_stamps[(wave >> 2) * 32 + i] = gst[i];
+        }
+        if (blockIdx.x == 5 && t == 11 && (tid & 255) == 0) haet_gemm_stamps[(wave >> 2) * 32 + NKT + 2] = gst[0];
+#endif
+    };
+    {
+        int t = 0;  // do-while: a guarded loop gets a preheader, and the prologue's loads sink into it
+        do run_tile(t);
+        while (++t < my_tiles);
+    }
+    {
+        char* ob = reinterpret_cast<char*>(out) + tile_row0(my_tiles - 1) * ((long long)O * 4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) store_group(ob, acc[1], 1, g);
+    }
+}
+
 }  // namespace haet
 
 using namespace haet;
@@ -279,6 +500,12 @@ extern "C" int haet_split_bf16(const float* w, size_t n, uint16_t* hi, uint16_t*
     return check_launch("split_bf16_kernel");
 }
 
+#ifdef HAET_STAMPS
+extern "C" int haet_debug_read_gemm_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(haet_gemm_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int haet_linear_supported(int K, int O) {
     return (K >= 32 && K % 32 == 0 && O >= 128 && O % 128 == 0) ? 1 : 0;
 }
@@ -289,6 +516,23 @@ extern "C" int haet_linear_fwd(const float* x, const uint16_t* W_hi, const uint1
     if (!x || !W_hi || !W_lo || !out || Nrows < 1) return fail(HAET_E_ARG, "linear_fwd: bad arguments");
     if (!haet_linear_supported(K, O))
         return fail(HAET_E_ARG, "linear_fwd: K=%d (multiple of 32) / O=%d (multiple of 128) unsupported", K, O);
+    // W-stationary kernel wherever the weight fits the register file
+    static const bool force_stream = getenv("HAET_GEMM_STREAM") != nullptr;
+    if (!force_stream && O % 256 == 0 && (K == 128 || K == 256) && Nrows >= 64) {
+        const int tiles = (Nrows + 63) / 64;
+        const int ny = O / 256;
+        const int gx = tiles < 256 / ny ? tiles : (256 / ny > 0 ? 256 / ny : 1);
+        const size_t lds = (size_t)2 * 2 * (K / GBK) * WS_IMGP;  // two resident tiles: 129 KB at K = 256
+        auto go = [&](auto kern) {
+            if (lds > 64 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi, W_lo, bias, Nrows,
+                               O, tiles, out);
+        };
+        if (K == 256) go(gemm_ws_kernel<8, 4>);
+        else go(gemm_ws_kernel<4, 4>);
+        return check_launch("gemm_ws_kernel");
+    }
     // 256-row workgroup tiles (W staged once per 256 rows) when there are enough rows to fill the
     // chip, 128-row tiles otherwise; 128-column variant for O % 256 != 0
     const bool big = Nrows >= 256 * 256 && O % 256 == 0;

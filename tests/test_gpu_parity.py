@@ -324,7 +324,11 @@ def test_ragged_point_counts_mfma_shapes(N, H, M, hip_device):
 
 
 @pytest.mark.parametrize("rows,K,O", [(1, 32, 128), (127, 64, 256), (1000, 256, 256), (513, 256, 384),
-                                      (4096, 256, 512), (300, 128, 128)])
+                                      (4096, 256, 512), (300, 128, 128),
+                                      # W-stationary kernel: one tile, shifted last tile, several
+                                      # tiles per workgroup with a ragged end, K = 128, two column blocks
+                                      (64, 256, 256), (65, 128, 256), (70001, 256, 256), (20011, 128, 512),
+                                      (63, 256, 256)])
 def test_split_bf16_linear_vs_fp64(rows, K, O, hip_device):
     """haet_linear_fwd (in_project_x / to_out): split-bf16 MFMA GEMM against an fp64 reference
     (and, as the sanity anchor, against the fp32 library GEMM it replaces)."""
@@ -339,6 +343,12 @@ def test_split_bf16_linear_vs_fp64(rows, K, O, hip_device):
     err = O_rel(out, ref)
     err_fp32 = O_rel(torch.nn.functional.linear(x, W, b), ref)
     assert err < 2e-5, (err, err_fp32)
+    # row by row as well (a misplaced row hardly moves the global norm of a long matrix)
+    row_err = (out.double() - ref).norm(dim=1) / ref.norm(dim=1)
+    assert float(row_err.max()) < 1e-4, int(row_err.argmax())
+    # overlapping (shifted) tiles write identical values: the result does not depend on who wins
+    again = ops.linear(x.to(hip_device), w).cpu()
+    assert torch.equal(out, again)
 
 
 def O_rel(a, b):

@@ -11,7 +11,24 @@ from haet_amd import ops
 
 dev = torch.device("cuda:0")
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-for K, O in ((256, 256), (256, 128), (128, 256), (512, 256), (256, 512)):
+def _copy_rate():
+    a = torch.randn(rows, 256, device=dev)
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print(f"torch copy_ of the same traffic: {ms:.3f} ms  {rows*512*4/ms/1e9:.2f} TB/s")
+
+
+_copy_rate()
+shapes = ((256, 256),) if os.environ.get('PROBE_ONE') else ((256, 256), (256, 128), (128, 256), (512, 256), (256, 512))
+for K, O in shapes:
     x = torch.randn(rows, K, device=dev)
     w = ops.SplitLinear(torch.randn(O, K, device=dev) * 0.05, torch.randn(O, device=dev))
     for _ in range(3):
