@@ -100,10 +100,10 @@ __device__ __forceinline__ float dpp(float v) {
 }
 
 // ----------------------------------------------------------------------------- tile loader
-// LI = ceil(H/2): 16-B chunks per thread per tile (32 rows x H*8 chunks / 512 threads).
+// LI = 16-B chunks per thread per tile (32 rows x H*8 chunks / NT threads): ceil(H/2) at 512 threads.
 // Everything that does not change from tile to tile is computed once in init(): the row / head of
 // each chunk, its LDS offsets, its global pointer (advanced by one tile per fetch).
-template <int LI>
+template <int LI, int NT = NTHR>
 struct Loader {
     f32x4 xr[LI];
     float wt4[4];
@@ -122,7 +122,7 @@ struct Loader {
         for (int i = 0; i < 4; ++i) wt4[i] = wt[4 * q8 + i];
 #pragma unroll
         for (int i = 0; i < LI; ++i) {
-            const int e = threadIdx.x + NTHR * i;
+            const int e = threadIdx.x + NT * i;
             const int r = e / cpr, q = e - r * cpr, h = q >> 3;
             row[i] = r;
             src[i] = xb + ((size_t)(row0 + r) * cpr + q) * 4;
@@ -202,7 +202,7 @@ __device__ __forceinline__ Frag read_cols(int img, int s, int lane) {
 // Ws as MB swizzled [32][32] split-bf16 image pairs in LDS (same for every head): both passes
 // re-read their Ws fragments per tile instead of pinning 16 VGPRs per column block.
 __device__ __forceinline__ void stage_ws(int wimg, const float* __restrict__ Ws, int M) {
-    for (int e = threadIdx.x; e < M * 4; e += NTHR) {
+    for (int e = threadIdx.x; e < M * 4; e += blockDim.x) {
         const int g = e >> 2, chunk = e & 3;
         float v[8];
 #pragma unroll
@@ -215,9 +215,14 @@ __device__ __forceinline__ void stage_ws(int wimg, const float* __restrict__ Ws,
 }
 
 // ----------------------------------------------------------------------------- slice
-// IPW items (head, 32-column block) per wave; MB = M/32 column blocks per head.
-template <int LI, int IPW, int MB>
-__global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
+// IPW items (head, 32-column block) per wave; MB = M/32 column blocks per head; NWV waves.
+// Measured at C3 (ablation builds, 1M points): loader + staging + barriers alone 0.24 ms, the
+// logits MFMAs +0.10, the Z MFMAs with the hi/lo split of P +0.10, exp2 +0.03 -- the parts add up
+// instead of overlapping (two waves per SIMD at ~230 VGPRs).  Tried without gain: 16 waves with
+// one item each (128 VGPRs only with spills; 25 % slower), running the two waves of a SIMD in
+// opposite stage/compute order.
+template <int LI, int IPW, int MB, int NWV = NW>
+__global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ Ws, const float* __restrict__ bs,
     const float* __restrict__ wt, float bt, float base_temp, float c0, int N, int H,
     int tiles_per_chunk, float* __restrict__ parts) {
@@ -233,10 +238,10 @@ __global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
     const int buf_bytes = H * 2 * IMG;
     const int sarr0 = 2 * buf_bytes, sarr_bytes = H * TN * 4;
     const int scratch = sarr0 + 2 * sarr_bytes + wave * 32 * 4;
-    const int wimg = sarr0 + 2 * sarr_bytes + NW * 32 * 4;  // [MB][hi|lo] images of Ws
+    const int wimg = sarr0 + 2 * sarr_bytes + NWV * 32 * 4;  // [MB][hi|lo] images of Ws
     const float* xb = x + (size_t)b * N * H * kC;
 
-    Loader<LI> ld;
+    Loader<LI, NWV * 64> ld;
     ld.init(wt, xb, H, t_begin * TN);
     stage_ws(wimg, Ws, M);
 
@@ -271,36 +276,53 @@ __global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
                 const int img = cur * buf_bytes + h * (2 * IMG);
                 const int sp = sarr0 + cur * sarr_bytes + 4 * (h * TN);
                 // rows of this lane's accumulator registers: n = (r&3) + 8(r>>2) + 4hf
-                f32x4 s4[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    s4[i] = *reinterpret_cast<const f32x4*>(smem + sp + 4 * (8 * i + 4 * hf));
-                const Frag xa0 = read_rows(img, l31, hf), xa1 = read_rows(img, l31, 2 + hf);
-                const Frag xb0 = read_cols(img, 0, lane), xb1 = read_cols(img, 1, lane);
+                const int sq = sp + 16 * hf;  // s_n of those rows: four 16-B pieces, 32 B apart
 #pragma unroll
                 for (int kk = 0; kk < IPH; ++kk) {
                     const int k = hh * IPH + kk;
                     const int wi = wimg + ((item0 + k) % MB) * (2 * IMG);
-                    f32x16 Y;
+                    // Live ranges are kept short on purpose (fragments read where they are used, the
+                    // logits not kept for the rare rescale): the one-item-per-wave variant has to fit
+                    // 128 VGPRs to run four waves per SIMD.
+                    auto logits = [&]() {
+                        f32x16 Y;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Y[r] = bias[k];
-                    Y = mfma3(xa0, read_rows(wi, l31, hf), Y);
-                    Y = mfma3(xa1, read_rows(wi, l31, 2 + hf), Y);
+                        for (int r = 0; r < 16; ++r) Y[r] = bias[k];
+                        Y = mfma3(read_rows(img, l31, hf), read_rows(wi, l31, hf), Y);
+                        Y = mfma3(read_rows(img, l31, 2 + hf), read_rows(wi, l31, 2 + hf), Y);
+                        return Y;
+                    };
                     // p = exp2(Y s_n - m2): one fma + one v_exp per element.  The running maximum is a
                     // deferred REFERENCE: only when some exponent exceeds 2^20 (or on the first tile,
-                    // m2 = -inf) is it raised and Z, l rescaled (rare; recomputes the exponents).
+                    // m2 = -inf) is it raised and Z, l rescaled (rare; recomputes the logits).
                     float p[16];
                     float tmax = -INFINITY;
+                    {
+                        const f32x16 Y = logits();
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        p[r] = fmaf(Y[r], s4[r >> 2][r & 3], -m2[k]);
-                        tmax = fmaxf(tmax, p[r]);
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 s4 = *reinterpret_cast<const f32x4*>(smem + sq + 32 * i);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                p[4 * i + q] = fmaf(Y[4 * i + q], s4[q], -m2[k]);
+                                tmax = fmaxf(tmax, p[4 * i + q]);
+                            }
+                        }
                     }
                     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
                     if (__any(tmax > kThr2)) {
+                        const f32x16 Y = logits();
+                        float ys[16];
                         float zmax = -INFINITY;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) zmax = fmaxf(zmax, Y[r] * s4[r >> 2][r & 3]);
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 s4 = *reinterpret_cast<const f32x4*>(smem + sq + 32 * i);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                ys[4 * i + q] = Y[4 * i + q] * s4[q];
+                                zmax = fmaxf(zmax, ys[4 * i + q]);
+                            }
+                        }
                         zmax = fmaxf(zmax, __shfl_xor(zmax, 32));
                         const float mn = fmaxf(m2[k], zmax);
                         const float a = __builtin_amdgcn_exp2f(m2[k] - mn);  // m2 = -inf -> 0
@@ -316,7 +338,7 @@ __global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         m2[k] = mn;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) p[r] = fmaf(Y[r], s4[r >> 2][r & 3], -mn);
+                        for (int r = 0; r < 16; ++r) p[r] = ys[r] - mn;
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(p[r]);
@@ -330,15 +352,14 @@ __global__ __launch_bounds__(NTHR) void slice_mfma_kernel(
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ps += p[r];
                     lsum[k] += ps;
-                    float p0[8], p1[8];
+                    // Z[g,c] += P^T X : accumulator tile reused as the A operand, one half at a time
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        p0[j] = p[j];
-                        p1[j] = p[8 + j];
+                    for (int s = 0; s < 2; ++s) {
+                        float ph[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ph[j] = p[8 * s + j];
+                        Z[k] = mfma3(split8(ph), read_cols(img, s, lane), Z[k]);
                     }
-                    // Z[g,c] += P^T X : accumulator tile reused as the A operand
-                    Z[k] = mfma3(split8(p0), xb0, Z[k]);
-                    Z[k] = mfma3(split8(p1), xb1, Z[k]);
                 }
             }
         }
@@ -484,6 +505,7 @@ __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
 // ----------------------------------------------------------------------------- host side
 struct MfmaPlan {
     int li, ipw, mb, hpw, tiles_per_chunk, parts;
+    int s_nw, s_li;  // slice pass: waves per workgroup and loader chunks per thread
     size_t lds_slice, lds_deslice;
 };
 
@@ -512,7 +534,9 @@ bool mfma_plan(int B, int N, int H, int C, int M, MfmaPlan* p) {
         p->parts = (n_tiles + p->tiles_per_chunk - 1) / p->tiles_per_chunk;
         const size_t bufs = (size_t)2 * H * 2 * IMG + (size_t)2 * H * TN * 4;
         const size_t wimg = (size_t)mb * 2 * IMG;
-        p->lds_slice = bufs + NW * 32 * 4 + wimg;
+        p->s_nw = NW;  // (16 waves with one item each fit 128 VGPRs only with spills and ran 25 % slower)
+        p->s_li = p->li;
+        p->lds_slice = bufs + p->s_nw * 32 * 4 + wimg;
         p->lds_deslice = bufs + (size_t)2 * H * M * 4 + wimg;
     }
     return true;
@@ -528,13 +552,13 @@ static int set_lds(K kernel, size_t bytes) {
     return HAET_OK;
 }
 
-#define SLICE_CASE(LI_, IPW_, MB_)                                                              \
-    if (p.li == LI_ && p.ipw == IPW_ && p.mb == MB_) {                                           \
-        auto kern = slice_mfma_kernel<LI_, IPW_, MB_>;                                           \
-        if (int rc = set_lds(kern, p.lds_slice)) return rc;                                      \
-        hipLaunchKernelGGL(kern, grid, dim3(NTHR), p.lds_slice, st, x, Ws, bs, wt, bt, base_temp, \
-                           c0, N, H, p.tiles_per_chunk, parts);                                  \
-        return check_launch("slice_mfma_kernel");                                                \
+#define SLICE_CASE(LI_, IPW_, MB_, NW_)                                                            \
+    if (p.s_li == LI_ && p.ipw == IPW_ && p.mb == MB_ && p.s_nw == NW_) {                            \
+        auto kern = slice_mfma_kernel<LI_, IPW_, MB_, NW_>;                                          \
+        if (int rc = set_lds(kern, p.lds_slice)) return rc;                                          \
+        hipLaunchKernelGGL(kern, grid, dim3(NW_ * 64), p.lds_slice, st, x, Ws, bs, wt, bt, base_temp, \
+                           c0, N, H, p.tiles_per_chunk, parts);                                      \
+        return check_launch("slice_mfma_kernel");                                                    \
     }
 
 int slice_mfma_fwd(const float* x, const float* Ws, const float* bs, const float* wt, float bt,
@@ -543,17 +567,17 @@ int slice_mfma_fwd(const float* x, const float* Ws, const float* bs, const float
     MfmaPlan p;
     if (!mfma_plan(B, N, H, C, M, &p)) return fail(HAET_E_ARG, "slice_mfma: unsupported shape");
     dim3 grid(p.parts, B);
-    SLICE_CASE(4, 2, 2)  // H=8,  M=64  (C3/C4)
-    SLICE_CASE(4, 1, 1)  // H=8,  M=32
-    SLICE_CASE(4, 4, 4)  // H=8,  M=128 (C5)
-    SLICE_CASE(2, 1, 2)  // H=4,  M=64
-    SLICE_CASE(2, 1, 1)  // H=4,  M=32
-    SLICE_CASE(2, 2, 4)  // H=4,  M=128
-    SLICE_CASE(1, 1, 1)  // H=2
-    SLICE_CASE(1, 1, 2)
-    SLICE_CASE(1, 1, 4)
-    SLICE_CASE(8, 2, 1)  // H=16, M=32
-    SLICE_CASE(8, 4, 2)  // H=16, M=64
+    SLICE_CASE(4, 2, 2, 8)   // H=8,  M=64  (C3/C4)
+    SLICE_CASE(4, 1, 1, 8)   // H=8,  M=32
+    SLICE_CASE(4, 4, 4, 8)   // H=8,  M=128 (C5)
+    SLICE_CASE(2, 1, 2, 8)   // H=4,  M=64
+    SLICE_CASE(2, 1, 1, 8)   // H=4,  M=32
+    SLICE_CASE(2, 2, 4, 8)   // H=4,  M=128
+    SLICE_CASE(1, 1, 1, 8)   // H=2
+    SLICE_CASE(1, 1, 2, 8)
+    SLICE_CASE(1, 1, 4, 8)
+    SLICE_CASE(8, 2, 1, 8)   // H=16, M=32
+    SLICE_CASE(8, 4, 2, 8)   // H=16, M=64
     return fail(HAET_E_ARG, "slice_mfma: no instantiation for H=%d M=%d", H, M);
 }
 
