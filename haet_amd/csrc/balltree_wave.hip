@@ -1,5 +1,6 @@
-// Register-resident ball-tree builder (power-of-two clouds of <= 64 points): one wave per
-// cloud, the working arrays of std::nth_element live ACROSS THE LANES of two VGPRs
+// Register-resident ball-tree builder (power-of-two clouds of <= 64 points): eight waves per
+// cloud that each hold the whole cloud and share the independent nodes of a tree level between
+// them; the working arrays of std::nth_element live ACROSS THE LANES of two VGPRs
 // (lane p = array position p: an order-preserving integer key and the point index), and the
 // sequential introselect runs as scalar control flow that reads/writes single lanes with
 // v_readlane and single-lane selects.  The two Hoare scans ("while key[lo] < pivot", "while pivot <
@@ -141,9 +142,9 @@ __device__ __forceinline__ void w_select_nth(LaneArr& a, int first, int nth, int
     w_insertion_sort(a, first, last);
 }
 
-// one tree level: all nodes have `sz` points (power of two, lane-aligned segments).
-// cx,cy,cz: coordinates BY ELEMENT (lane e = element e).
-__device__ __forceinline__ void w_split_level(LaneArr& a, float cx, float cy, float cz, int nd, int n, int sz) {
+// Split dimension and sort keys of one tree level: all nodes have `sz` points (power of two,
+// lane-aligned segments).  cx,cy,cz: coordinates BY ELEMENT (lane e = element e).  Pure lane-parallel.
+__device__ __forceinline__ void w_level_keys(LaneArr& a, float cx, float cy, float cz, int nd, int sz) {
     // coordinates of the element sitting at my position
     float v[3] = {__shfl(cx, a.idx), __shfl(cy, a.idx), nd > 2 ? __shfl(cz, a.idx) : 0.f};
     int best = 0;
@@ -164,18 +165,39 @@ __device__ __forceinline__ void w_split_level(LaneArr& a, float cx, float cy, fl
         }
     }
     a.key = okey(best == 0 ? v[0] : (best == 1 ? v[1] : v[2]));
-    for (int s = 0; s < n; s += sz) w_select_nth(a, s, s + sz / 2, s + sz);
 }
 
 struct Rot3w {
     float r[9];
 };
 
-__global__ __launch_bounds__(64) void balltree_wave_kernel(
+constexpr int TW = 8;  // waves per cloud
+
+// One tree level shared by the `nw` waves w0 .. w0+nw-1, which all hold the same lane arrays: the
+// nodes of a level are independent, so wave i runs the (sequential) introselect of nodes i, i+nw, ...
+// and the waves swap their results through `ex` (double-buffered by `par`: one barrier per level).
+// EVERY wave of the workgroup calls this the same number of times (the barrier is the workgroup's);
+// `work` = false just keeps the barrier count.
+__device__ __forceinline__ void w_shared_level(LaneArr& a, float cx, float cy, float cz, int nd, int n, int sz,
+                                               bool work, int me, int nw, int* ex) {
+    const int lane = threadIdx.x & 63;
+    if (work) {
+        w_level_keys(a, cx, cy, cz, nd, sz);
+        const int nodes = n / sz;
+        for (int j = me; j < nodes; j += nw) w_select_nth(a, j * sz, j * sz + sz / 2, j * sz + sz);
+        if (lane < n && (lane / sz) % nw == me) ex[lane] = a.idx;
+    }
+    __syncthreads();
+    if (work && lane < n) a.idx = ex[lane];
+}
+
+__global__ __launch_bounds__(64 * TW) void balltree_wave_kernel(
     const float* __restrict__ pos, int M, int nd, int n_levels, int s0, int s1, int s2, int t0,
     int t1, int t2, int t3, int rotate, Rot3w R, int32_t* __restrict__ tree_idx,
     uint8_t* __restrict__ tree_mask, int32_t* __restrict__ rot) {
-    const int lane = threadIdx.x, cloud = blockIdx.x, n_clouds = gridDim.x;
+    __shared__ int ex[4][2][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cloud = blockIdx.x, n_clouds = gridDim.x;
     const int strides[3] = {s0, s1, s2};
     const int targets[4] = {t0, t1, t2, t3};
     float cx = 0.f, cy = 0.f, cz = 0.f;
@@ -188,9 +210,10 @@ __global__ __launch_bounds__(64) void balltree_wave_kernel(
     LaneArr a;
     a.idx = lane;
     a.key = 0;
-    // main tree (balltree.h:121-186): halve until the nodes hold 2 points
-    for (int sz = M; sz > 2; sz >>= 1) w_split_level(a, cx, cy, cz, nd, M, sz);
-    if (lane < M) {
+    // main tree (balltree.h:121-186): halve until the nodes hold 2 points; all TW waves share a level
+    int par = 0;
+    for (int sz = M; sz > 2; sz >>= 1, par ^= 1) w_shared_level(a, cx, cy, cz, nd, M, sz, true, wave, TW, ex[0][par]);
+    if (wave == 0 && lane < M) {
         tree_idx[(size_t)cloud * M + lane] = cloud * M + a.idx;
         tree_mask[(size_t)cloud * M + lane] = 1;
     }
@@ -206,30 +229,47 @@ __global__ __launch_bounds__(64) void balltree_wave_kernel(
         ry = fmaf(lz, R.r[7], fmaf(ly, R.r[4], lx * R.r[1]));
         rz = fmaf(lz, R.r[8], fmaf(ly, R.r[5], lx * R.r[2]));
     }
+    // The re-partitions of the hierarchy levels depend only on the (pooled) rotated leaves, not on
+    // each other: wave group g builds level g, all levels at once.
+    const int G = n_levels <= 1 ? 1 : (n_levels <= 2 ? 2 : 4), gsize = TW / G;
+    const int grp = wave / gsize, me = wave % gsize;
+    const bool mine = grp < n_levels;
     int n = M;
     size_t rot_off = 0;
-    for (int lev = 0; lev < n_levels; ++lev) {
-        a.idx = lane;
-        int sz = n;
-        for (int L = 0; L < targets[lev] && sz > 1; ++L, sz >>= 1) w_split_level(a, rx, ry, rz, nd, n, sz);
-        if (lane < n) rot[rot_off + (size_t)cloud * n + lane] = cloud * n + a.idx;
+    for (int lev = 0; lev < grp && lev < n_levels - 1; ++lev) {  // pool down to my level
+        const int st = strides[lev];
+        float sx = 0.f, sy = 0.f, sz2 = 0.f;
+        for (int q = 0; q < st; ++q) {  // sequential sum like .mean(axis=1)
+            const int src = (lane * st + q) & 63;
+            const float gx = __shfl(rx, src), gy = __shfl(ry, src), gz = __shfl(rz, src);
+            sx = q ? sx + gx : gx;
+            sy = q ? sy + gy : gy;
+            sz2 = q ? sz2 + gz : gz;
+        }
+        rx = sx / (float)st;
+        ry = sy / (float)st;
+        rz = sz2 / (float)st;
         rot_off += (size_t)n_clouds * n;
-        if (lev < n_levels - 1) {
-            const int st = strides[lev];
-            float sx = 0.f, sy = 0.f, sz2 = 0.f;
-            for (int q = 0; q < st; ++q) {  // sequential sum like .mean(axis=1)
-                const int src = (lane * st + q) & 63;
-                const float gx = __shfl(rx, src), gy = __shfl(ry, src), gz = __shfl(rz, src);
-                sx = q ? sx + gx : gx;
-                sy = q ? sy + gy : gy;
-                sz2 = q ? sz2 + gz : gz;
-            }
-            rx = sx / (float)st;
-            ry = sy / (float)st;
-            rz = sz2 / (float)st;
-            n /= st;
+        n /= st;
+    }
+    int max_splits = 0;  // same for every wave: the deepest level sets the number of barriers
+    {
+        int nn = M;
+        for (int lev = 0; lev < n_levels; ++lev) {
+            int c = 0;
+            for (int sz = nn; c < targets[lev] && sz > 1; sz >>= 1) ++c;
+            max_splits = max(max_splits, c);
+            if (lev < n_levels - 1) nn /= strides[lev];
         }
     }
+    a.idx = lane;
+    int sz = n;
+    for (int it = 0; it < max_splits; ++it, par ^= 1) {  // `par` carries on: never the buffer just read
+        const bool work = mine && it < targets[mine ? grp : 0] && sz > 1;
+        w_shared_level(a, rx, ry, rz, nd, n, sz, work, me, gsize, ex[grp & 3][par]);
+        if (work) sz >>= 1;
+    }
+    if (mine && me == 0 && lane < n) rot[rot_off + (size_t)cloud * n + lane] = cloud * n + a.idx;
 }
 
 bool balltree_wave_ok(int M, int n_levels, const int* st) {
@@ -244,7 +284,7 @@ int balltree_wave_launch(const float* pos, int n_clouds, int M, int d, int n_lev
                          uint8_t* tree_mask, int32_t* rot, hipStream_t stream) {
     Rot3w R;
     for (int i = 0; i < 9; ++i) R.r[i] = R9[i];
-    hipLaunchKernelGGL(balltree_wave_kernel, dim3(n_clouds), dim3(64), 0, stream, pos, M, d, n_levels,
+    hipLaunchKernelGGL(balltree_wave_kernel, dim3(n_clouds), dim3(64 * TW), 0, stream, pos, M, d, n_levels,
                        st[0], st[1], st[2], tg[0], tg[1], tg[2], tg[3], rotate, R, tree_idx, tree_mask,
                        rot);
     return check_launch("balltree_wave_kernel");
