@@ -28,19 +28,26 @@ from .._lib import HaetError
 
 
 class _StageTimer:
-    """Brackets a stage with HIP events on the current (= launch) stream when enabled."""
+    """Brackets a stage with HIP events on the current (= launch) stream when enabled.  Events come
+    from `pool` when the caller provides one (the first record() of a fresh timing event creates the
+    hipEvent: ~60 us of host time, fourteen per forward)."""
 
-    def __init__(self, sink, name):
-        self.sink, self.name = sink, name
+    def __init__(self, sink, name, pool=None):
+        self.sink, self.name, self.pool = sink, name, pool
+
+    def _event(self):
+        if self.pool:
+            return self.pool.pop()
+        return torch.cuda.Event(enable_timing=True)
 
     def __enter__(self):
         if self.sink is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0 = self._event()
             self.e0.record()
 
     def __exit__(self, *exc):
         if self.sink is not None:
-            e1 = torch.cuda.Event(enable_timing=True)
+            e1 = self._event()
             e1.record()
             self.sink.append((self.name, self.e0, e1))
         return False
@@ -81,6 +88,7 @@ class PhysicsAttentionBase(nn.Module):
         self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout))
         self.shard_group = None  # torch.distributed group over which the POINTS are sharded
         self.stage_events = None  # set to [] to collect (stage, start, end) HIP events (bench.py)
+        self.event_pool = None    # optional list of pre-recorded timing events the stage timer draws from
         self._slice_cache = None
 
     # -- per-variant projection to [B, N, H*C] -------------------------------------------
@@ -113,10 +121,26 @@ class PhysicsAttentionBase(nn.Module):
         return self._slice_cache[1]
 
     def _stage(self, name):
-        return _StageTimer(self.stage_events, name)
+        return _StageTimer(self.stage_events, name, self.event_pool)
+
+    def _any_requires_grad(self) -> bool:
+        d = self.__dict__
+        ps = d.get("_grad_check_params")
+        d["_grad_check_age"] = d.get("_grad_check_age", 0) + 1
+        if ps is None or d.get("_grad_check_stale", True) or d["_grad_check_age"] >= 256:
+            ps = list(self.parameters())  # ~50 us: cached, see ErwinTransformer._pack_key
+            d["_grad_check_params"], d["_grad_check_stale"], d["_grad_check_age"] = ps, False, 0
+        for p in ps:
+            if p.requires_grad:
+                return True
+        return False
+
+    def _apply(self, fn, *args, **kwargs):  # .to() / .cuda(): parameter objects may be replaced
+        self.__dict__["_grad_check_stale"] = True
+        return super()._apply(fn, *args, **kwargs)
 
     def forward(self, x: torch.Tensor, return_intermediates: bool = False):
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (x.requires_grad or self._any_requires_grad()):
             raise NotImplementedError(
                 "the HIP PhysicsAttention path is forward-only so far (backward is the next scope "
                 "row, SURVEY.md 8f-1): wrap the call in torch.no_grad()")

@@ -125,6 +125,7 @@ class ErwinTransformer(nn.Module):
         self.in_dim, self.out_dim = c_in, c_hidden[0]
         self.apply(self._init_weights)
         self._packed = None  # (key, weights blob, desc)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_stale())
 
     def _init_weights(self, m):
         # erwin_flash.py:127-136
@@ -140,7 +141,24 @@ class ErwinTransformer(nn.Module):
 
     # ------------------------------------------------------------------ packing
     def _pack_key(self):
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        # Walking nn.Module.parameters()/buffers() costs ~0.1 ms per forward, so the tensor list is
+        # cached.  The tensor OBJECTS only change through .to()/.cuda() (-> _apply), load_state_dict
+        # with assign=True (-> post hook, which also fires for an ancestor's load) or a parameter
+        # re-assigned by hand on a submodule (-> caught by the periodic re-walk).
+        d = self.__dict__
+        ts = d.get("_pack_tensors")
+        d["_pack_age"] = d.get("_pack_age", 0) + 1
+        if ts is None or d.get("_pack_stale", True) or d["_pack_age"] >= 256:
+            ts = list(self.parameters()) + list(self.buffers())
+            d["_pack_tensors"], d["_pack_stale"], d["_pack_age"] = ts, False, 0
+        return tuple([(t.data_ptr(), t._version) for t in ts])
+
+    def _mark_stale(self, *_):
+        self.__dict__["_pack_stale"] = True
+
+    def _apply(self, fn, *args, **kwargs):
+        self._mark_stale()
+        return super()._apply(fn, *args, **kwargs)
 
     def packed(self):
         """(weights blob, desc) for haet_erwin_fwd, rebuilt only when a parameter changed."""
