@@ -231,9 +231,11 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
     constexpr int HPW = IPW / IPH;              // heads per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y, BH = gridDim.y * H;
-    const int n_tiles = (N + TN - 1) / TN;
-    const int t_begin = blockIdx.x * tiles_per_chunk;
-    const int t_end = min(n_tiles, t_begin + tiles_per_chunk);
+    // Tiles are dealt round-robin: workgroup i takes tiles i, i + G, i + 2G, ... (G = gridDim.x), so
+    // all workgroups sweep the cloud together (neighbouring tiles = neighbouring DRAM pages), every
+    // workgroup gets the same number of tiles +-1, and there are only G partial records to merge.
+    const int n_tiles = (N + TN - 1) / TN, G = gridDim.x;
+    const int t_begin = blockIdx.x, t_end = n_tiles;
     // LDS (byte offsets): tile buffers [2][H][hi|lo] | s_n [2][H][32] | rescale scratch [NW][32] | Ws images
     const int buf_bytes = H * 2 * IMG;
     const int sarr0 = 2 * buf_bytes, sarr_bytes = H * TN * 4;
@@ -243,6 +245,7 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
 
     Loader<LI, NWV * 64> ld;
     ld.init(wt, xb, H, t_begin * TN);
+    ld.tile_stride *= G;
     stage_ws(wimg, Ws, M);
 
     // per-item state (the Ws fragments -- B operand: col g = lane&31, k = c -- come from LDS)
@@ -265,9 +268,9 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
     ld.stage(0, sarr0, bt, base_temp);
     __syncthreads();
     int cur = 0;
-    for (int t = t_begin; t < t_end; ++t) {
-        const bool more = t + 1 < t_end;
-        if (more) ld.fetch(N - (t + 1) * TN);
+    for (int t = t_begin; t < t_end; t += G) {
+        const bool more = t + G < t_end;
+        if (more) ld.fetch(N - (t + G) * TN);
         if (active) {
             const int nvalid = N - t * TN;  // >= 32 except on the last tile
 #pragma unroll
@@ -399,9 +402,8 @@ __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
     constexpr int M = 32 * MB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y;
-    const int n_tiles = (N + TN - 1) / TN;
-    const int t_begin = blockIdx.x * tiles_per_chunk;
-    const int t_end = min(n_tiles, t_begin + tiles_per_chunk);
+    const int n_tiles = (N + TN - 1) / TN, G = gridDim.x;  // tiles dealt round-robin, see the slice kernel
+    const int t_begin = blockIdx.x, t_end = n_tiles;
     // LDS (byte offsets): tile buffers | s_n [2][H][32] | bias [H][M] | m2 [H][M] | Ws images
     const int buf_bytes = H * 2 * IMG;
     const int sarr0 = 2 * buf_bytes, sarr_bytes = H * TN * 4;
@@ -417,6 +419,7 @@ __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
     }
     Loader<LI> ld;
     ld.init(wt, xb, H, t_begin * TN);
+    ld.tile_stride *= G;
     stage_ws(wimg, Ws, M);
 
     // per-head constants: the S'/l fragments (A operand: row c = lane&31, k = g in accumulator
@@ -447,9 +450,9 @@ __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
     ld.stage(0, sarr0, bt, base_temp);
     __syncthreads();
     int cur = 0;
-    for (int t = t_begin; t < t_end; ++t) {
-        const bool more = t + 1 < t_end;
-        if (more) ld.fetch(N - (t + 1) * TN);
+    for (int t = t_begin; t < t_end; t += G) {
+        const bool more = t + G < t_end;
+        if (more) ld.fetch(N - (t + G) * TN);
         const int nvalid = N - t * TN;
 #pragma unroll
         for (int hh = 0; hh < HPW; ++hh) {
@@ -526,12 +529,12 @@ bool mfma_plan(int B, int N, int H, int C, int M, MfmaPlan* p) {
         p->mb = mb;
         p->hpw = hpw;
         const int n_tiles = (N + TN - 1) / TN;
-        int chunks = 512;  // point chunks (= workgroups) per launch; HAET_SLICE_CHUNKS overrides (tuning)
-        if (const char* e = getenv("HAET_SLICE_CHUNKS")) chunks = atoi(e) > 0 ? atoi(e) : chunks;
-        int target = chunks / (B < 1 ? 1 : B);
+        int wgs = 256;  // workgroups per launch (one per CU: ~230 VGPRs); HAET_SLICE_CHUNKS overrides (tuning)
+        if (const char* e = getenv("HAET_SLICE_CHUNKS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
+        int target = wgs / (B < 1 ? 1 : B);
         if (target < 1) target = 1;
-        p->tiles_per_chunk = (n_tiles + target - 1) / target;
-        p->parts = (n_tiles + p->tiles_per_chunk - 1) / p->tiles_per_chunk;
+        p->parts = n_tiles < target ? n_tiles : target;
+        p->tiles_per_chunk = (n_tiles + p->parts - 1) / p->parts;  // (informational: tiles per workgroup)
         const size_t bufs = (size_t)2 * H * 2 * IMG + (size_t)2 * H * TN * 4;
         const size_t wimg = (size_t)mb * 2 * IMG;
         p->s_nw = NW;  // (16 waves with one item each fit 128 VGPRs only with spills and ran 25 % slower)
@@ -595,13 +598,6 @@ int deslice_mfma_fwd(const float* x, const float* Ws, const float* bs, const flo
                      int B, int N, int H, int C, int M, float* out, hipStream_t st) {
     MfmaPlan p;
     if (!mfma_plan(B, N, H, C, M, &p)) return fail(HAET_E_ARG, "deslice_mfma: unsupported shape");
-    {   // no partial records here, so more (shorter) chunks only help the tail: ~1024 per launch
-        const int n_tiles = (N + TN - 1) / TN;
-        int target = 1024 / B;
-        if (target < 1) target = 1;
-        p.tiles_per_chunk = (n_tiles + target - 1) / target;
-        p.parts = (n_tiles + p.tiles_per_chunk - 1) / p.tiles_per_chunk;
-    }
     dim3 grid(p.parts, B);
     DESLICE_CASE(4, 1, 2)
     DESLICE_CASE(4, 1, 1)

@@ -299,7 +299,7 @@ def test_full_size_properties_1m_points(hip_device, kernel_path):
 
 
 @pytest.mark.parametrize("N", [1, 31, 33, 1057])
-@pytest.mark.parametrize("H,M", [(4, 64), (8, 32), (2, 128), (8, 128)])
+@pytest.mark.parametrize("H,M", [(4, 64), (8, 32), (2, 128), (8, 128), (16, 32), (16, 64), (4, 128), (2, 32)])
 def test_ragged_point_counts_mfma_shapes(N, H, M, hip_device):
     """Shapes the MFMA kernels take (C = 32), partial last tile, B = 2, chunk boundaries."""
     from haet_amd import ops
@@ -353,3 +353,31 @@ def test_split_bf16_linear_vs_fp64(rows, K, O, hip_device):
 
 def O_rel(a, b):
     return O.rel_l2(a, b)
+
+
+def test_in_place_weight_update_is_picked_up(hip_device):
+    """Cached operands (split GEMM weights, slice parameters, packed Erwin blob) follow in-place
+    parameter updates -- what an optimizer step or load_state_dict does between forwards."""
+    from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh
+
+    torch.manual_seed(3)
+    mod = Physics_Attention_Irregular_Mesh(dim=256, heads=8, dim_head=32, slice_num=64, rotate=45).eval().to(hip_device)
+    x = torch.randn(1, 3000, 256, device=hip_device)
+    with torch.no_grad():
+        y0 = mod(x).clone()
+        assert torch.equal(mod(x), y0)  # deterministic, caches warm
+        outs = [y0]
+        for p in (mod.to_out[0].weight, mod.in_project_x.weight, mod.in_project_slice.weight,
+                  mod.erwin.encoder[0].blocks[0].swiglu.w3.weight):
+            p.mul_(1.25)
+            y = mod(x).clone()
+            assert not any(torch.equal(y, o) for o in outs), "a cached operand went stale"
+            outs.append(y)
+        # and a state_dict round trip restores the first answer bit for bit
+        sd = {k: v.clone() for k, v in mod.state_dict().items()}
+        for k, v in sd.items():
+            if v.is_floating_point() and ("to_out.0.weight" in k or "in_project_x.weight" in k or "in_project_slice.weight" in k
+                                          or "erwin.encoder.0.blocks.0.swiglu.w3.weight" in k):
+                v.div_(1.25)
+        mod.load_state_dict(sd)
+        assert (mod(x) - y0).abs().max() <= 1e-5 * y0.abs().max()

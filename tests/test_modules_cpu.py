@@ -89,3 +89,47 @@ def test_rot_targets_use_total_leaf_count():
 
     assert rot_targets(512, [32, 16]) == [4, 5]  # C3: 8 clouds x 64 slots (balltree.pyx:643 quirk)
     assert tree_slots(64) == 64 and tree_slots(12) == 16 and tree_slots(5) == 8 and tree_slots(2) == 2
+
+
+def test_weight_version_key_sees_every_kind_of_update():
+    """The packed Erwin weights are rebuilt when a parameter changes; the key walks a CACHED tensor
+    list, so every way a tensor can change or be replaced has to invalidate it."""
+    m = Physics_Attention_Irregular_Mesh(64, heads=4, dim_head=16, slice_num=8).eval()
+    er = m.erwin
+    k0 = er._pack_key()
+    assert er._pack_key() == k0
+    # in-place update (optimizer step, copy_): same tensor object, new version
+    with torch.no_grad():
+        er.encoder[0].blocks[0].norm1.weight.mul_(1.5)
+    k1 = er._pack_key()
+    assert k1 != k0
+    # load_state_dict on an ANCESTOR with assign=True replaces the tensor objects
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, assign=True)
+    k2 = er._pack_key()
+    assert k2 != k1 and {p for p, _ in k2} != {p for p, _ in k1}
+    # a dtype/device move goes through _apply
+    m.double()
+    k3 = er._pack_key()
+    assert k3 != k2
+    m.float()
+    # a parameter re-assigned by hand on a submodule is caught by the periodic re-walk at the latest
+    er._pack_key()
+    er.encoder[0].blocks[0].norm1.weight = torch.nn.Parameter(torch.ones(16))
+    new_ptr = er.encoder[0].blocks[0].norm1.weight.data_ptr()
+    seen = False
+    for _ in range(300):
+        if any(p == new_ptr for p, _ in er._pack_key()):
+            seen = True
+            break
+    assert seen
+
+
+def test_grad_check_cache_follows_requires_grad():
+    m = Physics_Attention_Irregular_Mesh(64, heads=4, dim_head=16, slice_num=8).eval()
+    assert m._any_requires_grad()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    assert not m._any_requires_grad()
+    m.to_out[0].weight.requires_grad_(True)
+    assert m._any_requires_grad()
