@@ -117,8 +117,12 @@ enum EpiMode {
 // columns, pad columns zero).  W: global bf16 planes [O][Kp] (hi at Wa, lo at Wa + O*Kp);
 // EP_SWIGLU adds a second matrix Wb on the same activations.  Two (tile, k-step) items of weights
 // are in flight behind the one being multiplied.  dst / b0 / b1 / sc / sh are LDS byte offsets.
-// One shared routine (runtime epilogue mode) keeps the kernel's instruction footprint small.
-__device__ __attribute__((noinline)) void linear_core(
+// One shared routine (runtime epilogue mode) keeps the kernel's instruction footprint small; only
+// DUAL (the SwiGLU pair) is a template parameter: as a runtime `if (dual)` around the second
+// matrix's loads it was a conditional VMEM operation inside the prefetch ring, and the waitcnt pass
+// then waits vmcnt(0) before every use -- one item in flight instead of two, for EVERY linear.
+template <bool DUAL>
+__device__ __attribute__((noinline)) void linear_core_t(
     const Img x_, int n, int K, const unsigned short* __restrict__ Wa,
     const unsigned short* __restrict__ Wb, int O, int mode, int dst, int ldd, int b0, int b1, int sc,
     int sh, const Img di_, int aux, int st) {
@@ -132,7 +136,7 @@ __device__ __attribute__((noinline)) void linear_core(
     const size_t plane = (size_t)O * Kp;
     const int my_tiles = ntiles > wave ? (ntiles - wave + nwaves - 1) / nwaves : 0;
     const int items = my_tiles * nks;
-    const bool dual = mode == EP_SWIGLU;
+    constexpr bool dual = DUAL;
     if (items == 0) return;
 #ifdef HAET_STAMPS
 #define LSTAMP(i) do { if (mode == EP_RESID && K <= 64) STAMP(i); } while (0)
@@ -261,6 +265,14 @@ __device__ __attribute__((noinline)) void linear_core(
         }
     }
     LSTAMP(44);
+}
+
+__device__ __forceinline__ void linear_core(
+    const Img x, int n, int K, const unsigned short* __restrict__ Wa,
+    const unsigned short* __restrict__ Wb, int O, int mode, int dst, int ldd, int b0, int b1, int sc,
+    int sh, const Img di, int aux, int st) {
+    if (mode == EP_SWIGLU) linear_core_t<true>(x, n, K, Wa, Wb, O, mode, dst, ldd, b0, b1, sc, sh, di, aux, st);
+    else linear_core_t<false>(x, n, K, Wa, Wb, O, mode, dst, ldd, b0, b1, sc, sh, di, aux, st);
 }
 
 // ia[t][:] = split( RMSNorm(X[t][:]) * w  [+ pe_b + rel[t] . pe_w] ).  A thread owns 4 consecutive
@@ -410,6 +422,11 @@ __device__ __forceinline__ const unsigned short* wptr(const float* W, int off) {
 }
 
 // ErwinTransformerBlock (layers.py:30-32) on the tokens of one level, in place
+#if defined(HAET_STAMPS) && defined(HAET_STAMP_LVL)
+#define BSTAMP(i) do { if (lvl == HAET_STAMP_LVL) STAMP(i); } while (0)  // phases of one hierarchy level only
+#else
+#define BSTAMP(i) STAMP(i)
+#endif
 __device__ __attribute__((noinline)) void erwin_block(int lvl, const haet_erwin_layer& L,
                                                       const haet_erwin_block_w& w,
                                                       const float* __restrict__ W, int d, int perm) {
@@ -422,26 +439,26 @@ __device__ __attribute__((noinline)) void erwin_block(int lvl, const haet_erwin_
     // norm weights, positional projection and every bias of this block: one coalesced copy to LDS
     // (they are re-read per token / per tile; from global each use is a dependent L2/HBM trip)
     const int par = T(T_PAR) - 4 * w.small_off;  // par + 4 * <blob offset> addresses the LDS copy
-    STAMP(16);
+    BSTAMP(16);
     stage_params(T(T_PAR), W + w.small_off, w.small_len);
     // x~ = RMSNorm(x) + pe_proj(pos - ball centre)            (attention.py:59-61)
     ball_rel_pos(T(T_P + lvl), n, d, L.ball, perm, T(T_REL));
     __syncthreads();
-    STAMP(17);
+    BSTAMP(17);
     norm_rows(X, ld, n, c, par + 4 * w.norm1, T(T_REL), d, par + 4 * w.pe_w, par + 4 * w.pe_b, ia);
     __syncthreads();
-    STAMP(18);
+    BSTAMP(18);
     linear_core(ia, n, c, wptr(W, w.qkv_w), nullptr, 3 * c, EP_QKV, wide, ldq, par + 4 * w.qkv_b, 0, 0, 0,
                 none, 0, 0);
     __syncthreads();
-    STAMP(19);
+    BSTAMP(19);
     attention_dispatch(c / L.heads, wide, ldq, n, c, L.heads, L.ball, perm, ia);
     __syncthreads();
-    STAMP(20);
+    BSTAMP(20);
     linear_core(ia, n, c, wptr(W, w.proj_w), nullptr, c, EP_RESID, X, ld, par + 4 * w.proj_b, 0, 0, 0, none,
                 0, 0);
     __syncthreads();
-    STAMP(21);
+    BSTAMP(21);
     // x += W3( W2 x^ * silu(W1 x^) ),  x^ = RMSNorm(x)          (mlp.py:17-18)
     norm_rows(X, ld, n, c, par + 4 * w.norm2, 0, 0, -1, 0, ia);
     {
@@ -449,15 +466,15 @@ __device__ __attribute__((noinline)) void erwin_block(int lvl, const haet_erwin_
         for (int i = threadIdx.x; i < n * padk; i += blockDim.x) ih.put(i / padk, hid + i % padk, 0.f);
     }
     __syncthreads();
-    STAMP(22);
+    BSTAMP(22);
     linear_core(ia, n, c, wptr(W, w.w1_w), wptr(W, w.w2_w), hid, EP_SWIGLU, 0, 0, par + 4 * w.w1_b,
                 par + 4 * w.w2_b, 0, 0, ih, 0, 0);
     __syncthreads();
-    STAMP(23);
+    BSTAMP(23);
     linear_core(ih, n, hid, wptr(W, w.w3_w), nullptr, c, EP_RESID, X, ld, par + 4 * w.w3_b, 0, 0, 0, none, 0,
                 0);
     __syncthreads();
-    STAMP(24);
+    BSTAMP(24);
 }
 
 // BallPooling (pooling.py:25-40): level l -> l+1

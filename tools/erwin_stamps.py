@@ -20,7 +20,8 @@ x = torch.randn(1, 200_000, 256, device=dev)
 big = torch.empty(256 * 1024 * 1024, device=dev)  # flush caches between forwards like the 1M-point run
 with torch.no_grad():
     for _ in range(3):
-        big.fill_(1.0)
+        if not os.environ.get("NO_FLUSH"):
+            big.fill_(1.0)
         mod(x)
 torch.cuda.synchronize()
 lib = _lib.load()
@@ -36,7 +37,7 @@ prev = 0
 for i in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12):
     print(f"  {names[i]:22s} +{t[i]-t[prev]:8d} cycles")
     prev = i
-print("last block (dec0 block 1) phases:")
+print("phases of the last block recorded (dec0 block 1; with EXTRA='-DHAET_STAMPS -DHAET_STAMP_LVL=1': bottleneck block 1):")
 bn = {17: "params+rel_pos", 18: "norm1+pe", 19: "qkv", 20: "attention", 21: "proj", 22: "norm2", 23: "w1w2", 24: "w3"}
 for i in range(17, 25):
     print(f"  {bn[i]:14s} {t[i]-t[i-1]:8d} cycles")
