@@ -69,6 +69,10 @@ __device__ __forceinline__ float& F(int off) { return *reinterpret_cast<float*>(
 __device__ __forceinline__ int& I(int off) { return *reinterpret_cast<int*>(smem + off); }
 
 // split-bf16 image: hi plane, then lo plane `plane` bytes later; rows `S` bytes apart
+// The launch's block size as a constant: `blockDim.x` is a load from the dispatch packet -- a
+// dependent memory round trip at the entry of every routine that uses it.
+constexpr int kErwinThreads = 512;
+
 struct Img {
     int base;  // byte offset in smem
     int S, plane;
@@ -92,7 +96,7 @@ __device__ __forceinline__ int T(int i) { return __builtin_amdgcn_readfirstlane(
 
 // copy `len` floats (16-B aligned, multiple of 4) of small parameters into LDS
 __device__ __forceinline__ void stage_params(int dst, const float* __restrict__ src, int len) {
-    for (int i = threadIdx.x * 4; i < len; i += blockDim.x * 4)
+    for (int i = threadIdx.x * 4; i < len; i += kErwinThreads * 4)
         *reinterpret_cast<f32x4*>(smem + dst + 4 * i) = *reinterpret_cast<const f32x4*>(src + i);
 }
 
@@ -121,15 +125,24 @@ enum EpiMode {
 // DUAL (the SwiGLU pair) is a template parameter: as a runtime `if (dual)` around the second
 // matrix's loads it was a conditional VMEM operation inside the prefetch ring, and the waitcnt pass
 // then waits vmcnt(0) before every use -- one item in flight instead of two, for EVERY linear.
-template <bool DUAL>
+// The epilogue mode is a template parameter too (five instantiations, ~3 KB each): with one
+// shared routine the 20+ arguments no longer fit the argument registers, the rest came through
+// scratch memory (a load and a wait at every entry), and the epilogue was a chain of mode branches.
+// ex0..ex3 are mode-specific: SWIGLU {b1, image base, image row stride, image plane}; BN {sc, sh};
+// UNPOOL {sc, sh, aux, st}.
+template <int MODE>
 __device__ __attribute__((noinline)) void linear_core_t(
     const Img x_, int n, int K, const unsigned short* __restrict__ Wa,
-    const unsigned short* __restrict__ Wb, int O, int mode, int dst, int ldd, int b0, int b1, int sc,
-    int sh, const Img di_, int aux, int st) {
-    const Img x = UI(x_), di = UI(di_);
-    n = U(n), K = U(K), O = U(O), mode = U(mode), dst = U(dst), ldd = U(ldd), b0 = U(b0), b1 = U(b1);
-    sc = U(sc), sh = U(sh), aux = U(aux), st = U(st), Wa = UP(Wa), Wb = UP(Wb);
-    const int lane = threadIdx.x & 63, wave = U(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+    const unsigned short* __restrict__ Wb, int O, int dst, int ldd, int b0, int ex0, int ex1, int ex2,
+    int ex3) {
+    constexpr int mode = MODE;
+    constexpr bool DUAL = MODE == EP_SWIGLU;
+    const Img x = UI(x_);
+    n = U(n), K = U(K), O = U(O), dst = U(dst), ldd = U(ldd), b0 = U(b0);
+    ex0 = U(ex0), ex1 = U(ex1), ex2 = U(ex2), ex3 = U(ex3), Wa = UP(Wa), Wb = UP(Wb);
+    const int b1 = ex0, sc = ex0, sh = ex1, aux = ex2, st = ex3;
+    const Img di = {ex1, ex2, ex3};
+    const int lane = threadIdx.x & 63, wave = U(threadIdx.x >> 6), nwaves = kErwinThreads >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const int Kp = round32(K), nks = Kp >> 5;
     const int nto = (O + 15) >> 4, ntiles = ((n + 15) >> 4) * nto;
@@ -271,8 +284,13 @@ __device__ __forceinline__ void linear_core(
     const Img x, int n, int K, const unsigned short* __restrict__ Wa,
     const unsigned short* __restrict__ Wb, int O, int mode, int dst, int ldd, int b0, int b1, int sc,
     int sh, const Img di, int aux, int st) {
-    if (mode == EP_SWIGLU) linear_core_t<true>(x, n, K, Wa, Wb, O, mode, dst, ldd, b0, b1, sc, sh, di, aux, st);
-    else linear_core_t<false>(x, n, K, Wa, Wb, O, mode, dst, ldd, b0, b1, sc, sh, di, aux, st);
+    switch (mode) {  // `mode` is a literal at every call site: this folds to one call
+        case EP_QKV: linear_core_t<EP_QKV>(x, n, K, Wa, Wb, O, dst, ldd, b0, 0, 0, 0, 0); break;
+        case EP_RESID: linear_core_t<EP_RESID>(x, n, K, Wa, Wb, O, dst, ldd, b0, 0, 0, 0, 0); break;
+        case EP_SWIGLU: linear_core_t<EP_SWIGLU>(x, n, K, Wa, Wb, O, dst, ldd, b0, b1, di.base, di.S, di.plane); break;
+        case EP_BN: linear_core_t<EP_BN>(x, n, K, Wa, Wb, O, dst, ldd, b0, sc, sh, 0, 0); break;
+        default: linear_core_t<EP_UNPOOL>(x, n, K, Wa, Wb, O, dst, ldd, b0, sc, sh, aux, st); break;
+    }
 }
 
 // ia[t][:] = split( RMSNorm(X[t][:]) * w  [+ pe_b + rel[t] . pe_w] ).  A thread owns 4 consecutive
@@ -286,7 +304,7 @@ __device__ __attribute__((noinline)) void norm_rows(int X, int ldx, int n, int c
     X = U(X), ldx = U(ldx), n = U(n), c = U(c), w = U(w), rel = U(rel), d = U(d), pe_w = U(pe_w), pe_b = U(pe_b);
     const int cp = round32(c), tpr = cp >> 2;  // threads per row: 8, 16 or 32 (power of two)
     const int sub = threadIdx.x & (tpr - 1), ch = 4 * sub;
-    const int rows_per_pass = blockDim.x / tpr;
+    const int rows_per_pass = kErwinThreads / tpr;
     const int passes = (n + rows_per_pass - 1) / rows_per_pass;
     for (int ps = 0; ps < passes; ++ps) {
         const int t = ps * rows_per_pass + threadIdx.x / tpr;
@@ -323,7 +341,7 @@ __device__ __attribute__((noinline)) void ball_rel_pos(int P, int n, int d, int 
     P = U(P), n = U(n), d = U(d), ball = U(ball), perm = U(perm), rel = U(rel);
     if (ball <= 64 && (ball & (ball - 1)) == 0) {
         const int total = (n * d + 63) & ~63;  // whole waves: every lane takes part in the shuffles
-        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        for (int i = threadIdx.x; i < total; i += kErwinThreads) {
             const int j = i / n, p = i - j * n;
             const bool ok = j < d;
             const int tok = ok ? I(perm + 4 * p) : 0;
@@ -335,7 +353,7 @@ __device__ __attribute__((noinline)) void ball_rel_pos(int P, int n, int d, int 
         return;
     }
     const int nb = n / ball;
-    for (int i = threadIdx.x; i < nb * d; i += blockDim.x) {
+    for (int i = threadIdx.x; i < nb * d; i += kErwinThreads) {
         const int b = i / d, j = i % d;
         float sm = 0.f;
         for (int p = 0; p < ball; ++p) sm += F(P + 4 * (I(perm + 4 * (b * ball + p)) * d + j));
@@ -358,7 +376,7 @@ __device__ __attribute__((noinline)) void ball_attention(int qkv, int ldq, int n
     const Img out = UI(out_);
     qkv = U(qkv), ldq = U(ldq), n = U(n), c = U(c), heads = U(heads), ball = U(ball), perm = U(perm);
     const float scale = 1.0f / sqrtf((float)HD);
-    for (int i = threadIdx.x; i < n * heads; i += blockDim.x) {
+    for (int i = threadIdx.x; i < n * heads; i += kErwinThreads) {
         const int place = i / heads, h = i % heads;
         const int tq = I(perm + 4 * place), b0 = (place / ball) * ball;
         float q[HD], acc[HD];
@@ -463,7 +481,7 @@ __device__ __attribute__((noinline)) void erwin_block(int lvl, const haet_erwin_
     norm_rows(X, ld, n, c, par + 4 * w.norm2, 0, 0, -1, 0, ia);
     {
         const int padk = round32(hid) - hid;  // zero the k padding of the hidden image
-        for (int i = threadIdx.x; i < n * padk; i += blockDim.x) ih.put(i / padk, hid + i % padk, 0.f);
+        for (int i = threadIdx.x; i < n * padk; i += kErwinThreads) ih.put(i / padk, hid + i % padk, 0.f);
     }
     __syncthreads();
     BSTAMP(22);
@@ -486,7 +504,7 @@ __device__ __attribute__((noinline)) void erwin_pool(int l, const haet_erwin_des
     const Img rows = {T(T_WIDE), img_stride(K), n2 * img_stride(K)};
     const Img none = {0, 0, 0};
     stage_params(T(T_PAR), W + R.small_off, R.small_len);
-    for (int i = threadIdx.x; i < n2 * d; i += blockDim.x) {
+    for (int i = threadIdx.x; i < n2 * d; i += kErwinThreads) {
         const int p = i / d, j = i % d;
         float sum = 0.f;
         for (int q = 0; q < st; ++q) sum += F(P0 + 4 * ((p * st + q) * d + j));
@@ -494,7 +512,7 @@ __device__ __attribute__((noinline)) void erwin_pool(int l, const haet_erwin_des
     }
     __syncthreads();
     const int Kp = round32(K);
-    for (int i = threadIdx.x; i < n2 * Kp; i += blockDim.x) {
+    for (int i = threadIdx.x; i < n2 * Kp; i += kErwinThreads) {
         const int p = i / Kp, k = i % Kp;
         float v = 0.f;
         if (k < st * c) {
@@ -522,7 +540,7 @@ __device__ __attribute__((noinline)) void erwin_unpool(int l, const haet_erwin_d
     const Img rows = {T(T_WIDE), img_stride(K), n2 * img_stride(K)};
     const Img none = {0, 0, 0};
     stage_params(T(T_PAR), W + R.small_off, R.small_len);
-    for (int i = threadIdx.x; i < n2 * Kp; i += blockDim.x) {
+    for (int i = threadIdx.x; i < n2 * Kp; i += kErwinThreads) {
         const int p = i / Kp, k = i % Kp;
         float v = 0.f;
         if (k < c2) {
@@ -628,20 +646,20 @@ __global__ __launch_bounds__(512) void erwin_kernel(
     STAMP(1);
     // gather the cloud into tree order (erwin_flash.py:176-181)
     const int c0 = D.enc[0].c, X0 = T(T_X), ld0 = T(T_LD), P0 = T(T_P), ident = T(T_IDENT);
-    for (int i = threadIdx.x; i < Mp * c0; i += blockDim.x) {
+    for (int i = threadIdx.x; i < Mp * c0; i += kErwinThreads) {
         const int slot = i / c0, ch = i % c0;
         F(X0 + 4 * (slot * ld0 + ch)) = tokens[(size_t)tree_idx[(size_t)cloud * Mp + slot] * c0 + ch];
     }
-    for (int i = threadIdx.x; i < Mp * d; i += blockDim.x) {
+    for (int i = threadIdx.x; i < Mp * d; i += kErwinThreads) {
         const int slot = i / d, j = i % d;
         F(P0 + 4 * i) = pos[(size_t)tree_idx[(size_t)cloud * Mp + slot] * d + j];
     }
-    for (int i = threadIdx.x; i < Mp; i += blockDim.x) I(ident + 4 * i) = i;
+    for (int i = threadIdx.x; i < Mp; i += kErwinThreads) I(ident + 4 * i) = i;
     if (D.rotate) {
         size_t off = 0;
         for (int l = 0; l < nl; ++l) {
             const int nlv = T(T_N + l), ro = T(T_ROT + l);
-            for (int i = threadIdx.x; i < nlv; i += blockDim.x)
+            for (int i = threadIdx.x; i < nlv; i += kErwinThreads)
                 I(ro + 4 * i) = rot[off + (size_t)cloud * nlv + i] - cloud * nlv;
             off += (size_t)n_clouds * nlv;
         }
@@ -687,7 +705,7 @@ __global__ __launch_bounds__(512) void erwin_kernel(
         STAMP(3 + (op < 8 ? op : 8));
     }
     // node.x[tree_mask][argsort(tree_idx[tree_mask])]  (erwin_flash.py:193)
-    for (int i = threadIdx.x; i < Mp * c0; i += blockDim.x) {
+    for (int i = threadIdx.x; i < Mp * c0; i += kErwinThreads) {
         const int slot = i / c0, ch = i % c0;
         const size_t g = (size_t)cloud * Mp + slot;
         if (tree_mask[g]) out[(size_t)tree_idx[g] * c0 + ch] = F(X0 + 4 * (slot * ld0 + ch));
@@ -772,7 +790,7 @@ extern "C" int haet_erwin_fwd(const float* tokens, const float* pos, const int32
         if (e != hipSuccess) return fail(HAET_E_LAUNCH, "erwin: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = bytes;
     }
-    hipLaunchKernelGGL(erwin_kernel, dim3(n_clouds), dim3(512), bytes, as_stream(stream), tokens,
+    hipLaunchKernelGGL(erwin_kernel, dim3(n_clouds), dim3(kErwinThreads), bytes, as_stream(stream), tokens,
                        pos, tree_idx, tree_mask, rot, weights, M, Mp, out);
     return check_launch("erwin_kernel");
 }
