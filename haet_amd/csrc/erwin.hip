@@ -422,8 +422,116 @@ __device__ __attribute__((noinline)) void ball_attention(int qkv, int ldq, int n
     }
 }
 
+// Ball attention on the matrix cores for head dim 8 (both hierarchy levels of the C3 shape) and
+// balls of <= 32 tokens: one wave per (32-token tile, head).
+//   St[k][q] = sum_d K[k][d] Q[q][d]        v_mfma_f32_32x32x16_bf16 x 3 (split bf16; d padded 8 -> 16
+//                                           with zeros: the hf = 1 halves of both operands are zero)
+//   lane = query column, registers = the 16 keys (r&3) + 8(r>>2) + 4hf: the softmax over the keys of a
+//   query is over one lane's registers plus its partner lane (xor 32); keys of another ball in the
+//   same tile (ball < 32) are masked to -inf.
+//   Ot[d][q] = sum_k Vt[d][k] Pt[k][q]      A = V gathered in the accumulator's key order, B = P straight
+//                                           from the accumulator (no lane movement); rows d >= 8 are zero
+//   lane (q, hf) ends up with O[q][4hf .. 4hf+3] in registers 0..3 and the softmax sum of ITS query.
+// The scalar version above reads every K and V row once per (query, head) thread -- 0.5 MB of LDS
+// traffic per level-0 block, 10k cycles; this one reads them once per (tile, head).
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (RNE)
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void split8v(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned h = pack2_bf16(v[2 * i], v[2 * i + 1]);
+        hi[i] = h;
+        lo[i] = pack2_bf16(v[2 * i] - __uint_as_float(h << 16), v[2 * i + 1] - __uint_as_float(h & 0xffff0000u));
+    }
+}
+__device__ __forceinline__ f32x16 mfma3_32(u32x4 ah, u32x4 al, u32x4 bh, u32x4 bl, f32x16 c) {
+    const bf16x8 a0 = __builtin_bit_cast(bf16x8, ah), a1 = __builtin_bit_cast(bf16x8, al);
+    const bf16x8 b0 = __builtin_bit_cast(bf16x8, bh), b1 = __builtin_bit_cast(bf16x8, bl);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
+    return c;
+}
+
+__device__ __attribute__((noinline)) void ball_attention_mfma8(int qkv, int ldq, int n, int c, int heads,
+                                                               int ball, int perm, const Img out_) {
+    constexpr int HD = 8;
+    const Img out = UI(out_);
+    qkv = U(qkv), ldq = U(ldq), n = U(n), c = U(c), heads = U(heads), ball = U(ball), perm = U(perm);
+    const int lane = threadIdx.x & 63, wave = U(threadIdx.x >> 6), hf = lane >> 5, l31 = lane & 31;
+    const float qscale = 1.4426950408889634f / sqrtf((float)HD);  // softmax in base 2
+    const int items = (n >> 5) * heads, bmask = 31 & ~(ball - 1);  // ball: a power of two <= 32
+    for (int item = wave; item < items; item += kErwinThreads / 64) {
+        const int tile = item / heads, h = item - tile * heads;
+        const int t = I(perm + 4 * (tile * 32 + l31));  // my token: key row of St, query column of St
+        const int row = qkv + 4 * (t * ldq + h * HD);
+        float kv[8], qv[8];
+#pragma unroll
+        for (int e4 = 0; e4 < 2; ++e4) {  // every lane reads (rows are 16-B aligned: kPad); hf = 1 is
+            const f32x4 k4 = *reinterpret_cast<const f32x4*>(smem + row + 4 * (c + 4 * e4));  // the zero padding
+            const f32x4 q4 = *reinterpret_cast<const f32x4*>(smem + row + 16 * e4);           // of d = 8..15
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                kv[4 * e4 + e] = hf ? 0.f : k4[e];
+                qv[4 * e4 + e] = hf ? 0.f : q4[e] * qscale;
+            }
+        }
+        u32x4 kh, kl, qh, ql;
+        split8v(kv, kh, kl);
+        split8v(qv, qh, ql);
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+        S = mfma3_32(kh, kl, qh, ql, S);
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * hf;
+            if ((key ^ l31) & bmask) S[r] = -INFINITY;  // another ball of the same tile
+            m = fmaxf(m, S[r]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            S[r] = __builtin_amdgcn_exp2f(S[r] - m);
+            l += S[r];
+        }
+        l += __shfl_xor(l, 32);
+        f32x16 O;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float vv[8], pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int key = 16 * s + 8 * (j >> 2) + 4 * hf + (j & 3);  // the accumulator's key order
+                const int tk = __shfl(t, key);
+                const float v1 = F(qkv + 4 * (tk * ldq + 2 * c + h * HD + (l31 & 7)));  // unconditional read
+                vv[j] = l31 < HD ? v1 : 0.f;
+                pv[j] = S[8 * s + j];
+            }
+            u32x4 vh, vl, ph, pl;
+            split8v(vv, vh, vl);
+            split8v(pv, ph, pl);
+            O = mfma3_32(vh, vl, ph, pl, O);
+        }
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out.put(t, h * HD + 4 * hf + r, O[r] * inv);
+    }
+}
+
 __device__ __attribute__((noinline)) void attention_dispatch(int hd, int qkv, int ldq, int n, int c,
                                                              int heads, int ball, int perm, const Img out) {
+    if (hd == 8 && n % 32 == 0 && ball <= 32 && (ball & (ball - 1)) == 0) {
+        ball_attention_mfma8(qkv, ldq, n, c, heads, ball, perm, out);
+        return;
+    }
     switch (hd) {
         case 1: ball_attention<1>(qkv, ldq, n, c, heads, ball, perm, out); break;
         case 2: ball_attention<2>(qkv, ldq, n, c, heads, ball, perm, out); break;
