@@ -306,12 +306,17 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
                         for (int i = 0; i < 4; ++i) {
                             const f32x4 s4 = *reinterpret_cast<const f32x4*>(smem + sq + 32 * i);
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                p[4 * i + q] = fmaf(Y[4 * i + q], s4[q], -m2[k]);
-                                tmax = fmaxf(tmax, p[4 * i + q]);
-                            }
+                            for (int q = 0; q < 4; ++q) p[4 * i + q] = fmaf(Y[4 * i + q], s4[q], -m2[k]);
                         }
                     }
+                    if (nvalid < TN) {  // last tile: rows past the end take no part in the maximum either
+                        asm volatile("" ::: "memory");  // (a cloud of one point must give weight 1, not 0/0)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if ((r & 3) + 8 * (r >> 2) + 4 * hf >= nvalid) p[r] = -INFINITY;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, p[r]);
                     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
                     if (__any(tmax > kThr2)) {
                         const f32x16 Y = logits();
@@ -321,11 +326,15 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
                         for (int i = 0; i < 4; ++i) {
                             const f32x4 s4 = *reinterpret_cast<const f32x4*>(smem + sq + 32 * i);
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                ys[4 * i + q] = Y[4 * i + q] * s4[q];
-                                zmax = fmaxf(zmax, ys[4 * i + q]);
-                            }
+                            for (int q = 0; q < 4; ++q) ys[4 * i + q] = Y[4 * i + q] * s4[q];
                         }
+                        if (nvalid < TN) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                if ((r & 3) + 8 * (r >> 2) + 4 * hf >= nvalid) ys[r] = -INFINITY;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) zmax = fmaxf(zmax, ys[r]);
                         zmax = fmaxf(zmax, __shfl_xor(zmax, 32));
                         const float mn = fmaxf(m2[k], zmax);
                         const float a = __builtin_amdgcn_exp2f(m2[k] - mn);  // m2 = -inf -> 0
