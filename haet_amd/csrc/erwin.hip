@@ -72,6 +72,15 @@ __device__ __forceinline__ int& I(int off) { return *reinterpret_cast<int*>(smem
 // The launch's block size as a constant: `blockDim.x` is a load from the dispatch packet -- a
 // dependent memory round trip at the entry of every routine that uses it.
 constexpr int kErwinThreads = 512;
+// The phase routines of a block are inlined into erwin_block (one copy: erwin_block itself is not
+// inlined): as calls each cost ~1.5k cycles -- the callee's entry waits for every outstanding memory
+// operation, the arguments are re-made uniform, and the caller reloads what it had to park in scratch
+// -- on phases of 3-8k cycles (kernel 392k -> 357k cycles).  -DHAET_ERWIN_NOINLINE restores the calls.
+#ifdef HAET_ERWIN_NOINLINE
+#define ERWIN_PHASE __attribute__((noinline))
+#else
+#define ERWIN_PHASE __forceinline__
+#endif
 
 struct Img {
     int base;  // byte offset in smem
@@ -131,7 +140,7 @@ enum EpiMode {
 // ex0..ex3 are mode-specific: SWIGLU {b1, image base, image row stride, image plane}; BN {sc, sh};
 // UNPOOL {sc, sh, aux, st}.
 template <int MODE>
-__device__ __attribute__((noinline)) void linear_core_t(
+__device__ ERWIN_PHASE void linear_core_t(
     const Img x_, int n, int K, const unsigned short* __restrict__ Wa,
     const unsigned short* __restrict__ Wb, int O, int dst, int ldd, int b0, int ex0, int ex1, int ex2,
     int ex3) {
@@ -298,7 +307,7 @@ __device__ __forceinline__ void linear_core(
 // with xor-shuffles: the dependent chain is ~5 LDS round trips whatever c is (it was one per
 // channel).  nn.RMSNorm(eps=None): eps = finfo(float32).eps (layers.py:25-26); PE:
 // attention.py:59-61.  X, w, rel, pe_w, pe_b: LDS byte offsets (pe_w < 0: no positional term).
-__device__ __attribute__((noinline)) void norm_rows(int X, int ldx, int n, int c, int w, int rel,
+__device__ ERWIN_PHASE void norm_rows(int X, int ldx, int n, int c, int w, int rel,
                                                     int d, int pe_w, int pe_b, const Img out_) {
     const Img out = UI(out_);
     X = U(X), ldx = U(ldx), n = U(n), c = U(c), w = U(w), rel = U(rel), d = U(d), pe_w = U(pe_w), pe_b = U(pe_b);
@@ -337,7 +346,7 @@ __device__ __attribute__((noinline)) void norm_rows(int X, int ldx, int n, int c
 // rel[tok] = P[tok] - mean over its ball (attention.py:35-40); ball b = places [b*ball, ..).
 // One thread per (dimension, place): a ball's places are `ball` consecutive lanes, so for the
 // power-of-two ball sizes (<= 64) the ball sum is a segmented xor-butterfly.
-__device__ __attribute__((noinline)) void ball_rel_pos(int P, int n, int d, int ball, int perm, int rel) {
+__device__ ERWIN_PHASE void ball_rel_pos(int P, int n, int d, int ball, int perm, int rel) {
     P = U(P), n = U(n), d = U(d), ball = U(ball), perm = U(perm), rel = U(rel);
     if (ball <= 64 && (ball & (ball - 1)) == 0) {
         const int total = (n * d + 63) & ~63;  // whole waves: every lane takes part in the shuffles
@@ -456,7 +465,7 @@ __device__ __forceinline__ f32x16 mfma3_32(u32x4 ah, u32x4 al, u32x4 bh, u32x4 b
     return c;
 }
 
-__device__ __attribute__((noinline)) void ball_attention_mfma8(int qkv, int ldq, int n, int c, int heads,
+__device__ ERWIN_PHASE void ball_attention_mfma8(int qkv, int ldq, int n, int c, int heads,
                                                                int ball, int perm, const Img out_) {
     constexpr int HD = 8;
     const Img out = UI(out_);
@@ -526,7 +535,7 @@ __device__ __attribute__((noinline)) void ball_attention_mfma8(int qkv, int ldq,
     }
 }
 
-__device__ __attribute__((noinline)) void attention_dispatch(int hd, int qkv, int ldq, int n, int c,
+__device__ ERWIN_PHASE void attention_dispatch(int hd, int qkv, int ldq, int n, int c,
                                                              int heads, int ball, int perm, const Img out) {
     if (hd == 8 && n % 32 == 0 && ball <= 32 && (ball & (ball - 1)) == 0) {
         ball_attention_mfma8(qkv, ldq, n, c, heads, ball, perm, out);
