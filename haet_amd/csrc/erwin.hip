@@ -562,7 +562,7 @@ __device__ __forceinline__ const unsigned short* wptr(const float* W, int off) {
 #else
 #define BSTAMP(i) STAMP(i)
 #endif
-__device__ __attribute__((noinline)) void erwin_block(int lvl, const haet_erwin_layer& L,
+__device__ ERWIN_PHASE void erwin_block(int lvl, const haet_erwin_layer& L,
                                                       const haet_erwin_block_w& w,
                                                       const float* __restrict__ W, int d, int perm) {
     lvl = U(lvl), d = U(d), perm = U(perm), W = UP(W);
@@ -613,7 +613,7 @@ __device__ __attribute__((noinline)) void erwin_block(int lvl, const haet_erwin_
 }
 
 // BallPooling (pooling.py:25-40): level l -> l+1
-__device__ __attribute__((noinline)) void erwin_pool(int l, const haet_erwin_desc& D,
+__device__ ERWIN_PHASE void erwin_pool(int l, const haet_erwin_desc& D,
                                                      const float* __restrict__ W) {
     const haet_erwin_resample& R = D.pool[l];
     const int d = D.d, st = R.stride, n2 = T(T_N + l + 1), c = D.enc[l].c, K = st * c + st * d;
@@ -648,7 +648,7 @@ __device__ __attribute__((noinline)) void erwin_pool(int l, const haet_erwin_des
 }
 
 // BallUnpooling (pooling.py:58-72): level l+1 -> l
-__device__ __attribute__((noinline)) void erwin_unpool(int l, const haet_erwin_desc& D,
+__device__ ERWIN_PHASE void erwin_unpool(int l, const haet_erwin_desc& D,
                                                        const float* __restrict__ W) {
     const haet_erwin_resample& R = D.unpool[l];
     const int d = D.d, st = R.stride, n2 = T(T_N + l + 1), c2 = D.enc[l + 1].c, c = D.enc[l].c;
@@ -722,43 +722,54 @@ __host__ __device__ inline int erwin_layout(const haet_erwin_desc& D, int Mp, in
 }
 
 // The weight blob starts with a copy of the descriptor (read with scalar loads).
+struct ErwinDir {
+    int t[T_WORDS];
+};
+
+// byte offsets of every LDS region (the T table the device routines read through T())
+inline void erwin_directory(const haet_erwin_desc& D, int Mp, ErwinDir* out) {
+    int ia_bytes, wide_bytes;
+    erwin_layout(D, Mp, &ia_bytes, &wide_bytes);
+    int* t = out->t;
+    for (int i = 0; i < T_WORDS; ++i) t[i] = 0;
+    const int nl = D.n_levels, d = D.d;
+    int p = 4 * T_WORDS, n = Mp;
+    for (int l = 0; l < nl; ++l) {
+        t[T_N + l] = n;
+        t[T_LD + l] = D.enc[l].c + kPad;
+        t[T_X + l] = p;
+        p += 4 * n * (D.enc[l].c + kPad);
+        if (l < nl - 1) n /= D.pool[l].stride;
+    }
+    for (int l = 0; l < nl; ++l) {
+        t[T_P + l] = p;
+        p += 4 * ((t[T_N + l] * d + 3) & ~3);
+    }
+    t[T_IA] = p;
+    p += ia_bytes;
+    t[T_WIDE] = p;
+    p += wide_bytes;
+    t[T_REL] = p;
+    p += 4 * ((Mp * d + 3) & ~3);
+    t[T_PAR] = p;
+    p += 4 * erwin_max_small(D);
+    for (int l = 0; l < nl; ++l) {
+        t[T_ROT + l] = p;
+        p += 4 * t[T_N + l];
+    }
+    t[T_IDENT] = p;
+}
+
 __global__ __launch_bounds__(512) void erwin_kernel(
     const float* __restrict__ tokens, const float* __restrict__ pos,
     const int32_t* __restrict__ tree_idx, const uint8_t* __restrict__ tree_mask,
     const int32_t* __restrict__ rot, const float* __restrict__ W, int M, int Mp,
-    float* __restrict__ out) {
+    float* __restrict__ out, ErwinDir dir) {
     STAMP(0);
     const haet_erwin_desc& D = *reinterpret_cast<const haet_erwin_desc*>(W);
     const int cloud = blockIdx.x, n_clouds = gridDim.x, d = D.d, nl = D.n_levels;
-    if (threadIdx.x == 0) {  // LDS directory
-        int ia_bytes, wide_bytes;
-        erwin_layout(D, Mp, &ia_bytes, &wide_bytes);
-        int p = 4 * T_WORDS, n = Mp;
-        for (int l = 0; l < nl; ++l) {
-            I(4 * (T_N + l)) = n;
-            I(4 * (T_LD + l)) = D.enc[l].c + kPad;
-            I(4 * (T_X + l)) = p;
-            p += 4 * n * (D.enc[l].c + kPad);
-            if (l < nl - 1) n /= D.pool[l].stride;
-        }
-        for (int l = 0; l < nl; ++l) {
-            I(4 * (T_P + l)) = p;
-            p += 4 * ((I(4 * (T_N + l)) * d + 3) & ~3);
-        }
-        I(4 * T_IA) = p;
-        p += ia_bytes;
-        I(4 * T_WIDE) = p;
-        p += wide_bytes;
-        I(4 * T_REL) = p;
-        p += 4 * ((Mp * d + 3) & ~3);
-        I(4 * T_PAR) = p;
-        p += 4 * erwin_max_small(D);
-        for (int l = 0; l < nl; ++l) {
-            I(4 * (T_ROT + l)) = p;
-            p += 4 * I(4 * (T_N + l));
-        }
-        I(4 * T_IDENT) = p;
-    }
+    // LDS directory: computed on the host (one thread walking the layout cost ~9k cycles per launch)
+    if (threadIdx.x < T_WORDS) I(4 * threadIdx.x) = dir.t[threadIdx.x];
     __syncthreads();
     STAMP(1);
     // gather the cloud into tree order (erwin_flash.py:176-181)
@@ -907,7 +918,9 @@ extern "C" int haet_erwin_fwd(const float* tokens, const float* pos, const int32
         if (e != hipSuccess) return fail(HAET_E_LAUNCH, "erwin: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = bytes;
     }
+    ErwinDir dir;
+    erwin_directory(*desc, Mp, &dir);
     hipLaunchKernelGGL(erwin_kernel, dim3(n_clouds), dim3(kErwinThreads), bytes, as_stream(stream), tokens,
-                       pos, tree_idx, tree_mask, rot, weights, M, Mp, out);
+                       pos, tree_idx, tree_mask, rot, weights, M, Mp, out, dir);
     return check_launch("erwin_kernel");
 }
