@@ -134,6 +134,41 @@ enum EpiMode {
 // DUAL (the SwiGLU pair) is a template parameter: as a runtime `if (dual)` around the second
 // matrix's loads it was a conditional VMEM operation inside the prefetch ring, and the waitcnt pass
 // then waits vmcnt(0) before every use -- one item in flight instead of two, for EVERY linear.
+// First two (tile, k-step) weight items of a Linear, fetched AHEAD of the phase that precedes it
+// (norm, attention, the previous Linear): with everything inlined in one routine the registers simply
+// stay live, and the Linear starts on operands that are already there instead of on an L2 round trip.
+struct WPre {
+    u32x4 a[4], b[4];
+};
+template <bool DUAL>
+__device__ __forceinline__ WPre linear_prefetch(int K, const unsigned short* __restrict__ Wa,
+                                               const unsigned short* __restrict__ Wb, int O) {
+    typedef const __attribute__((address_space(1))) u32x4* gv4;
+    const int lane = threadIdx.x & 63, wave = U(threadIdx.x >> 6), nwaves = kErwinThreads >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int Kp = round32(K), nks = Kp >> 5, nto = (O + 15) >> 4;
+    const size_t plane = (size_t)O * Kp;
+    int ot = wave % nto, ks = 0;  // item 0 of this wave (the token tile does not enter the address)
+    WPre p;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const size_t off = (size_t)min(ot * 16 + l15, O - 1) * Kp + 32 * ks + 8 * kq;
+        u32x4(&wv)[4] = i ? p.b : p.a;
+        wv[0] = *(gv4)(Wa + off);
+        wv[1] = *(gv4)(Wa + plane + off);
+        if (DUAL) {
+            wv[2] = *(gv4)(Wb + off);
+            wv[3] = *(gv4)(Wb + plane + off);
+        }
+        if (++ks == nks) {  // same walk as Cur::advance in linear_core_t
+            ks = 0;
+            ot += nwaves;
+            while (ot >= nto) ot -= nto;
+        }
+    }
+    return p;
+}
+
 // The epilogue mode is a template parameter too (five instantiations, ~3 KB each): with one
 // shared routine the 20+ arguments no longer fit the argument registers, the rest came through
 // scratch memory (a load and a wait at every entry), and the epilogue was a chain of mode branches.
@@ -143,7 +178,7 @@ template <int MODE>
 __device__ ERWIN_PHASE void linear_core_t(
     const Img x_, int n, int K, const unsigned short* __restrict__ Wa,
     const unsigned short* __restrict__ Wb, int O, int dst, int ldd, int b0, int ex0, int ex1, int ex2,
-    int ex3) {
+    int ex3, const WPre* pre = nullptr) {
     constexpr int mode = MODE;
     constexpr bool DUAL = MODE == EP_SWIGLU;
     const Img x = UI(x_);
@@ -265,9 +300,17 @@ __device__ ERWIN_PHASE void linear_core_t(
     // its use, hipcc's waitcnt pass cannot count the younger loads in flight and waits vmcnt(0),
     // which silently serialises the prefetch.
     Cur cf = first(), cc = first();
-    fetch(cf, w0);
+    if (pre) {  // (a compile-time fact after inlining)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            w0[i] = pre->a[i];
+            w1[i] = pre->b[i];
+        }
+    } else {
+        fetch(cf, w0);
+    }
     advance(cf);
-    fetch(cf, w1);
+    if (!pre) fetch(cf, w1);
     advance(cf);
     LSTAMP(41);
     for (int it = 0; it < items; it += 2) {  // two named register sets, statically indexed
@@ -292,11 +335,11 @@ __device__ ERWIN_PHASE void linear_core_t(
 __device__ __forceinline__ void linear_core(
     const Img x, int n, int K, const unsigned short* __restrict__ Wa,
     const unsigned short* __restrict__ Wb, int O, int mode, int dst, int ldd, int b0, int b1, int sc,
-    int sh, const Img di, int aux, int st) {
+    int sh, const Img di, int aux, int st, const WPre* pre = nullptr) {
     switch (mode) {  // `mode` is a literal at every call site: this folds to one call
-        case EP_QKV: linear_core_t<EP_QKV>(x, n, K, Wa, Wb, O, dst, ldd, b0, 0, 0, 0, 0); break;
-        case EP_RESID: linear_core_t<EP_RESID>(x, n, K, Wa, Wb, O, dst, ldd, b0, 0, 0, 0, 0); break;
-        case EP_SWIGLU: linear_core_t<EP_SWIGLU>(x, n, K, Wa, Wb, O, dst, ldd, b0, b1, di.base, di.S, di.plane); break;
+        case EP_QKV: linear_core_t<EP_QKV>(x, n, K, Wa, Wb, O, dst, ldd, b0, 0, 0, 0, 0, pre); break;
+        case EP_RESID: linear_core_t<EP_RESID>(x, n, K, Wa, Wb, O, dst, ldd, b0, 0, 0, 0, 0, pre); break;
+        case EP_SWIGLU: linear_core_t<EP_SWIGLU>(x, n, K, Wa, Wb, O, dst, ldd, b0, b1, di.base, di.S, di.plane, pre); break;
         case EP_BN: linear_core_t<EP_BN>(x, n, K, Wa, Wb, O, dst, ldd, b0, sc, sh, 0, 0); break;
         default: linear_core_t<EP_UNPOOL>(x, n, K, Wa, Wb, O, dst, ldd, b0, sc, sh, aux, st); break;
     }
@@ -575,6 +618,7 @@ __device__ ERWIN_PHASE void erwin_block(int lvl, const haet_erwin_layer& L,
     // (they are re-read per token / per tile; from global each use is a dependent L2/HBM trip)
     const int par = T(T_PAR) - 4 * w.small_off;  // par + 4 * <blob offset> addresses the LDS copy
     BSTAMP(16);
+    const WPre p_qkv = linear_prefetch<false>(c, wptr(W, w.qkv_w), nullptr, 3 * c);
     stage_params(T(T_PAR), W + w.small_off, w.small_len);
     // x~ = RMSNorm(x) + pe_proj(pos - ball centre)            (attention.py:59-61)
     ball_rel_pos(T(T_P + lvl), n, d, L.ball, perm, T(T_REL));
@@ -584,16 +628,18 @@ __device__ ERWIN_PHASE void erwin_block(int lvl, const haet_erwin_layer& L,
     __syncthreads();
     BSTAMP(18);
     linear_core(ia, n, c, wptr(W, w.qkv_w), nullptr, 3 * c, EP_QKV, wide, ldq, par + 4 * w.qkv_b, 0, 0, 0,
-                none, 0, 0);
+                none, 0, 0, &p_qkv);
     __syncthreads();
     BSTAMP(19);
+    const WPre p_proj = linear_prefetch<false>(c, wptr(W, w.proj_w), nullptr, c);
     attention_dispatch(c / L.heads, wide, ldq, n, c, L.heads, L.ball, perm, ia);
     __syncthreads();
     BSTAMP(20);
     linear_core(ia, n, c, wptr(W, w.proj_w), nullptr, c, EP_RESID, X, ld, par + 4 * w.proj_b, 0, 0, 0, none,
-                0, 0);
+                0, 0, &p_proj);
     __syncthreads();
     BSTAMP(21);
+    const WPre p_12 = linear_prefetch<true>(c, wptr(W, w.w1_w), wptr(W, w.w2_w), hid);
     // x += W3( W2 x^ * silu(W1 x^) ),  x^ = RMSNorm(x)          (mlp.py:17-18)
     norm_rows(X, ld, n, c, par + 4 * w.norm2, 0, 0, -1, 0, ia);
     {
@@ -602,12 +648,13 @@ __device__ ERWIN_PHASE void erwin_block(int lvl, const haet_erwin_layer& L,
     }
     __syncthreads();
     BSTAMP(22);
+    const WPre p_3 = linear_prefetch<false>(hid, wptr(W, w.w3_w), nullptr, c);
     linear_core(ia, n, c, wptr(W, w.w1_w), wptr(W, w.w2_w), hid, EP_SWIGLU, 0, 0, par + 4 * w.w1_b,
-                par + 4 * w.w2_b, 0, 0, ih, 0, 0);
+                par + 4 * w.w2_b, 0, 0, ih, 0, 0, &p_12);
     __syncthreads();
     BSTAMP(23);
     linear_core(ih, n, hid, wptr(W, w.w3_w), nullptr, c, EP_RESID, X, ld, par + 4 * w.w3_b, 0, 0, 0, none, 0,
-                0);
+                0, &p_3);
     __syncthreads();
     BSTAMP(24);
 }
