@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
-STAGES = ("project", "slice", "merge", "token", "erwin", "deslice", "to_out")
+STAGES = ("project", "slice", "merge", "erwin", "deslice", "to_out")  # erwin = positions + tree + Erwin kernel
 # algorithmic HBM bytes per point of the hand-written streaming kernels (DESIGN.md s.4 / SURVEY.md 8d),
 # fp32 I/O, D = dim = H*C: projection GEMMs read D and write D floats, the slice pass reads D, the
 # de-slice pass reads and writes D.
@@ -100,7 +100,7 @@ def main():
     def event_pool(n_forwards):
         # Created AND recorded once up front: torch creates the hipEvent lazily at the first record(),
         # ~60 us of host time each; 14 per forward would make a small forward launch-bound.
-        pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * len(STAGES) * n_forwards)]
+        pool = [torch.cuda.Event(enable_timing=True) for _ in range((len(STAGES) + 1) * n_forwards)]
         for e in pool:
             e.record()
         return pool

@@ -58,6 +58,8 @@ SIGNATURES = {
     "haet_token_pos": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "haet_balltree_build": (c_int, [_P, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int),
                                     c_float, _P, _P, _P, _P]),
+    "haet_tokens_tree_build": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int),
+                                       c_float, _P, _P, _P, _P]),
     "haet_erwin_lds_bytes": (c_size_t, [POINTER(ErwinDesc), c_int]),
     "haet_erwin_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, POINTER(ErwinDesc), c_int, c_int, _P, _P]),
     "haet_deslice_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P]

@@ -171,10 +171,12 @@ class ErwinTransformer(nn.Module):
         return self._packed[1], self._packed[2]
 
     # ------------------------------------------------------------------ forward
-    def forward(self, node_features: torch.Tensor, node_positions: torch.Tensor,
+    def forward(self, node_features: torch.Tensor, node_positions: Optional[torch.Tensor],
                 batch_idx: Optional[torch.Tensor] = None, n_clouds: Optional[int] = None, **kwargs):
         """tokens [T, c], positions [T, d]; the T tokens are n_clouds equally sized clouds in
-        order (what PhysicsAttention builds: batch_idx = arange(B*H).repeat_interleave(G))."""
+        order (what PhysicsAttention builds: batch_idx = arange(B*H).repeat_interleave(G)).
+        node_positions=None: positions = min-max normalised first `dimensionality` channels of the
+        tokens (IrregularMesh.py:204-209), computed inside the tree launch; kept in `last_positions`."""
         if not self.decode:
             raise NotImplementedError("decode=False is outside the PhysicsAttention hot path")
         if self.training:
@@ -190,6 +192,12 @@ class ErwinTransformer(nn.Module):
             raise HaetError("the HIP Erwin stage needs equally sized clouds")
         M = T // n_clouds
         blob, desc = self.packed()
-        tree_idx, tree_mask, rot, _ = ops.balltree_build(
-            node_positions, n_clouds, M, self.strides, self.ball_sizes, float(self.rotate))
+        if node_positions is None:
+            tree_idx, tree_mask, rot, _, node_positions = ops.balltree_build(
+                None, n_clouds, M, self.strides, self.ball_sizes, float(self.rotate),
+                tokens=node_features, d=self.dimensionality)
+        else:
+            tree_idx, tree_mask, rot, _ = ops.balltree_build(
+                node_positions, n_clouds, M, self.strides, self.ball_sizes, float(self.rotate))
+        self.__dict__["last_positions"] = node_positions
         return ops.erwin_fwd(node_features, node_positions, tree_idx, tree_mask, rot, blob, desc, n_clouds, M)

@@ -262,18 +262,21 @@ __global__ __launch_bounds__(64) void balltree_kernel(
 
 // balltree_wave.hip: register-resident variant for power-of-two clouds of <= 64 points
 bool balltree_wave_ok(int M, int n_levels, const int* st);
+int token_pos_launch(const float* S, int T, int C, int d, float* pos, hipStream_t stream);
 int balltree_wave_launch(const float* pos, int n_clouds, int M, int d, int n_levels, const int* st,
                          const int* tg, int rotate, const float* R9, int32_t* tree_idx,
-                         uint8_t* tree_mask, int32_t* rot, hipStream_t stream);
+                         uint8_t* tree_mask, int32_t* rot, hipStream_t stream, const float* S, int C,
+                         float* pos_out);
 
 }  // namespace haet
 
 using namespace haet;
 
-extern "C" int haet_balltree_build(const float* pos, int n_clouds, int M, int d, int n_levels,
-                                   const int* strides, const int* targets, float angle_deg,
-                                   int32_t* tree_idx, uint8_t* tree_mask, int32_t* rot,
-                                   haet_stream_t stream) {
+static int balltree_build_impl(const float* pos, int n_clouds, int M, int d, int n_levels,
+                               const int* strides, const int* targets, float angle_deg,
+                               int32_t* tree_idx, uint8_t* tree_mask, int32_t* rot,
+                               haet_stream_t stream, const float* S, int C) {
+    // S != nullptr: `pos` is an OUTPUT (token positions derived from the tokens' first d channels)
     if (!pos || !tree_idx || !tree_mask || n_clouds < 1)
         return fail(HAET_E_ARG, "balltree: null pointer or n_clouds < 1");
     if (M < 2 || M > kMaxPts) return fail(HAET_E_ARG, "balltree: M=%d unsupported (2..128)", M);
@@ -314,9 +317,30 @@ extern "C" int haet_balltree_build(const float* pos, int n_clouds, int M, int d,
     const char* force_lds = getenv("HAET_TREE_LDS");
     if (!(force_lds && force_lds[0] == '1') && balltree_wave_ok(M, n_levels, st))
         return balltree_wave_launch(pos, n_clouds, M, d, n_levels, st, tg, rotate, R.r, tree_idx,
-                                    tree_mask, rot, as_stream(stream));
+                                    tree_mask, rot, as_stream(stream), S, C, const_cast<float*>(pos));
+    if (S) {  // generic tree kernel: positions by the stand-alone kernel first
+        const int rc = token_pos_launch(S, n_clouds * M, C, d, const_cast<float*>(pos), as_stream(stream));
+        if (rc != HAET_OK) return rc;
+    }
     hipLaunchKernelGGL(balltree_kernel, dim3(n_clouds), dim3(64), 0, as_stream(stream), pos, M, d,
                        depth, n_levels, st[0], st[1], st[2], tg[0], tg[1], tg[2], tg[3], rotate, R,
                        tree_idx, tree_mask, rot);
     return check_launch("balltree_kernel");
+}
+
+extern "C" int haet_balltree_build(const float* pos, int n_clouds, int M, int d, int n_levels,
+                                   const int* strides, const int* targets, float angle_deg,
+                                   int32_t* tree_idx, uint8_t* tree_mask, int32_t* rot,
+                                   haet_stream_t stream) {
+    return balltree_build_impl(pos, n_clouds, M, d, n_levels, strides, targets, angle_deg, tree_idx,
+                               tree_mask, rot, stream, nullptr, 0);
+}
+
+extern "C" int haet_tokens_tree_build(const float* S, int C, float* pos, int n_clouds, int M, int d,
+                                      int n_levels, const int* strides, const int* targets,
+                                      float angle_deg, int32_t* tree_idx, uint8_t* tree_mask,
+                                      int32_t* rot, haet_stream_t stream) {
+    if (!S || C < d) return fail(HAET_E_ARG, "tokens_tree_build: S is NULL or C < d");
+    return balltree_build_impl(pos, n_clouds, M, d, n_levels, strides, targets, angle_deg, tree_idx,
+                               tree_mask, rot, stream, S, C);
 }

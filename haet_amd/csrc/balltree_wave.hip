@@ -194,14 +194,52 @@ __device__ __forceinline__ void w_shared_level(LaneArr& a, float cx, float cy, f
 __global__ __launch_bounds__(64 * TW) void balltree_wave_kernel(
     const float* __restrict__ pos, int M, int nd, int n_levels, int s0, int s1, int s2, int t0,
     int t1, int t2, int t3, int rotate, Rot3w R, int32_t* __restrict__ tree_idx,
-    uint8_t* __restrict__ tree_mask, int32_t* __restrict__ rot) {
+    uint8_t* __restrict__ tree_mask, int32_t* __restrict__ rot, const float* __restrict__ S, int C,
+    float* __restrict__ pos_out) {
     __shared__ int ex[4][2][64];
+    __shared__ float mm[TW][2][3];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cloud = blockIdx.x, n_clouds = gridDim.x;
     const int strides[3] = {s0, s1, s2};
     const int targets[4] = {t0, t1, t2, t3};
     float cx = 0.f, cy = 0.f, cz = 0.f;
-    if (lane < M) {
+    if (S) {
+        // Fused haet_token_pos (IrregularMesh.py:204-209): every cloud's workgroup reduces the global
+        // per-channel min / max over ALL tokens itself (T * d floats: a few KB), normalises its own
+        // tokens with the formula of token_pos_kernel (bit-identical) and writes them for the Erwin stage.
+        const int T = n_clouds * M;
+        for (int j = 0; j < nd; ++j) {
+            float lo = INFINITY, hi = -INFINITY;
+            for (int t = threadIdx.x; t < T; t += 64 * TW) {
+                const float v = S[(size_t)t * C + j];
+                lo = fminf(lo, v);
+                hi = fmaxf(hi, v);
+            }
+            lo = wave_min(lo);
+            hi = wave_max(hi);
+            if (lane == 0) {
+                mm[wave][0][j] = lo;
+                mm[wave][1][j] = hi;
+            }
+        }
+        __syncthreads();
+        float c3[3] = {0.f, 0.f, 0.f};
+        for (int j = 0; j < nd; ++j) {
+            float lo = mm[0][0][j], hi = mm[0][1][j];
+            for (int w = 1; w < TW; ++w) {
+                lo = fminf(lo, mm[w][0][j]);
+                hi = fmaxf(hi, mm[w][1][j]);
+            }
+            const float rng = hi - lo + 1e-8f;
+            if (lane < M) {
+                c3[j] = (S[((size_t)cloud * M + lane) * C + j] - lo) / rng;
+                if (wave == 0) pos_out[((size_t)cloud * M + lane) * nd + j] = c3[j];
+            }
+        }
+        cx = c3[0];
+        cy = c3[1];
+        cz = c3[2];
+    } else if (lane < M) {
         const float* p = pos + ((size_t)cloud * M + lane) * nd;
         cx = p[0];
         cy = p[1];
@@ -281,12 +319,13 @@ bool balltree_wave_ok(int M, int n_levels, const int* st) {
 
 int balltree_wave_launch(const float* pos, int n_clouds, int M, int d, int n_levels, const int* st,
                          const int* tg, int rotate, const float* R9, int32_t* tree_idx,
-                         uint8_t* tree_mask, int32_t* rot, hipStream_t stream) {
+                         uint8_t* tree_mask, int32_t* rot, hipStream_t stream, const float* S, int C,
+                         float* pos_out) {
     Rot3w R;
     for (int i = 0; i < 9; ++i) R.r[i] = R9[i];
     hipLaunchKernelGGL(balltree_wave_kernel, dim3(n_clouds), dim3(64 * TW), 0, stream, pos, M, d, n_levels,
                        st[0], st[1], st[2], tg[0], tg[1], tg[2], tg[3], rotate, R, tree_idx, tree_mask,
-                       rot);
+                       rot, S, C, pos_out);
     return check_launch("balltree_wave_kernel");
 }
 

@@ -98,6 +98,11 @@ __global__ __launch_bounds__(256) void token_pos_kernel(const float* __restrict_
     }
 }
 
+int token_pos_launch(const float* S, int T, int C, int d, float* pos, hipStream_t stream) {
+    hipLaunchKernelGGL(token_pos_kernel, dim3(1), dim3(256), 0, stream, S, T, C, d, pos);
+    return check_launch("token_pos_kernel");
+}
+
 }  // namespace haet
 
 using namespace haet;
@@ -121,6 +126,5 @@ extern "C" int haet_token_pos(const float* S, int T, int C, int d, float* pos,
                               haet_stream_t stream) {
     if (!S || !pos || T < 1 || d < 1 || d > 4 || d > C)
         return fail(HAET_E_ARG, "token_pos: bad arguments (T=%d C=%d d=%d)", T, C, d);
-    hipLaunchKernelGGL(token_pos_kernel, dim3(1), dim3(256), 0, as_stream(stream), S, T, C, d, pos);
-    return check_launch("token_pos_kernel");
+    return token_pos_launch(S, T, C, d, pos, as_stream(stream));
 }

@@ -105,13 +105,19 @@ def rot_targets(total_leaves: int, ball_sizes: Sequence[int]) -> List[int]:
     return [max(0, int(math.log2(total_leaves / bs))) for bs in ball_sizes]
 
 
-def balltree_build(pos: Tensor, n_clouds: int, M: int, strides: Sequence[int],
-                   ball_sizes: Sequence[int], angle: float):
+def balltree_build(pos: Optional[Tensor], n_clouds: int, M: int, strides: Sequence[int],
+                   ball_sizes: Sequence[int], angle: float, tokens: Optional[Tensor] = None, d: int = 3):
     """Device build_balltree_with_rotations for equally sized clouds.
-    Returns (tree_idx int32[n_clouds*Mp], tree_mask uint8[...], rot int32 flat | None, [level sizes])."""
+    Returns (tree_idx int32[n_clouds*Mp], tree_mask uint8[...], rot int32 flat | None, [level sizes]).
+    With `tokens` [n_clouds*M, C] instead of `pos`, the positions are derived from the tokens' first d
+    channels in the same launch (haet_tokens_tree_build) and returned as a fifth value."""
     lib = _lib.load()
-    pos = _f32(pos, "pos")
-    d = pos.shape[1]
+    if tokens is not None:
+        tokens = _f32(tokens, "tokens")
+        pos = torch.empty(tokens.shape[0], d, dtype=torch.float32, device=tokens.device)
+    else:
+        pos = _f32(pos, "pos")
+        d = pos.shape[1]
     if pos.shape[0] != n_clouds * M:
         raise HaetError("pos rows != n_clouds * M")
     if len(strides) != len(ball_sizes) - 1:
@@ -130,6 +136,11 @@ def balltree_build(pos: Tensor, n_clouds: int, M: int, strides: Sequence[int],
     tg = rot_targets(n_clouds * Mp, ball_sizes)
     c_str = (ctypes.c_int * max(1, nl - 1))(*list(strides)[: nl - 1]) if nl > 1 else (ctypes.c_int * 1)(1)
     c_tg = (ctypes.c_int * nl)(*tg)
+    if tokens is not None:
+        check(lib.haet_tokens_tree_build(_p(tokens), tokens.shape[1], _p(pos), n_clouds, M, d, nl, c_str, c_tg,
+                                         float(angle), _p(tree_idx), _p(tree_mask), _p(rot), _stream()),
+              "haet_tokens_tree_build")
+        return tree_idx, tree_mask, rot, sizes, pos
     check(lib.haet_balltree_build(_p(pos), n_clouds, M, d, nl, c_str, c_tg, float(angle),
                                   _p(tree_idx), _p(tree_mask), _p(rot), _stream()), "haet_balltree_build")
     return tree_idx, tree_mask, rot, sizes

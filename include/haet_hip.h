@@ -123,6 +123,15 @@ int haet_balltree_build(const float* pos /*[n_clouds*M, d]*/, int n_clouds, int 
                         int32_t* tree_idx, uint8_t* tree_mask, int32_t* rot,
                         haet_stream_t stream);
 
+/* haet_token_pos + haet_balltree_build in one launch (what the module calls: the two are
+ * back to back on the critical path of every forward, IrregularMesh.py:204-213 followed by
+ * erwin_flash.py:161-174).  S [n_clouds*M, C] are the slice tokens, pos [n_clouds*M, d] is
+ * WRITTEN (same values as haet_token_pos), the tree outputs are those of haet_balltree_build. */
+int haet_tokens_tree_build(const float* S, int C, float* pos, int n_clouds, int M, int d,
+                           int n_levels, const int* strides, const int* targets, float angle_deg,
+                           int32_t* tree_idx, uint8_t* tree_mask, int32_t* rot,
+                           haet_stream_t stream);
+
 /* ------------------------------------------------------------------ Erwin stage
  * Replaces ErwinTransformer.forward with embed=False, mp_steps=0
  * (models/components/erwinflash/erwin_flash.py:138-195; BasicLayer layers.py:72-92;

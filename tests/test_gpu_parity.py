@@ -427,3 +427,22 @@ def test_c3_module_small_and_scaled_clouds(N, scale, hip_device):
         with torch.no_grad():
             y = mod._linear("to_out", mod.to_out[0], out_x).cpu()
         assert O.rel_l2(y, ref) < NORTH_STAR_TOL
+
+
+@pytest.mark.parametrize("M,d,C", [(64, 3, 32), (32, 3, 64), (8, 2, 16), (48, 3, 32)])
+def test_fused_tokens_tree_matches_separate_calls(M, d, C, hip_device):
+    """haet_tokens_tree_build = haet_token_pos + haet_balltree_build in one launch: identical
+    positions (bit for bit) and identical trees, on the wave kernel (power-of-two clouds <= 64) and
+    on the generic fallback (M = 48)."""
+    from haet_amd import ops
+
+    torch.manual_seed(M + d)
+    n_clouds = 8
+    S = torch.randn(n_clouds * M, C, device=hip_device)
+    S[5] = S[4]  # a tie
+    ball_sizes, strides = [min(32, M), min(16, M // 2)], [2]
+    pos = ops.token_pos(S, d)
+    ti, tm, rot, _ = ops.balltree_build(pos, n_clouds, M, strides, ball_sizes, 45.0)
+    ti2, tm2, rot2, _, pos2 = ops.balltree_build(None, n_clouds, M, strides, ball_sizes, 45.0, tokens=S, d=d)
+    assert torch.equal(pos, pos2)
+    assert torch.equal(ti, ti2) and torch.equal(tm, tm2) and torch.equal(rot, rot2)
