@@ -105,6 +105,48 @@ __device__ __forceinline__ void w_insertion_sort(LaneArr& a, int first, int last
     }
 }
 
+// std::__unguarded_partition(first, last, pivot) of libstdc++ in ONE step instead of a swap loop.
+// The sequential scans stop at the "left stoppers" L1 < L2 < ... (positions with !(key < pivot)) and
+// the "right stoppers" R1 > R2 > ... (positions with !(pivot < key)); the swapped elements land behind
+// the cursors and are never looked at again, so the k-th swap exchanges Lk and Rk of the ORIGINAL
+// array for every k with Lk < Rk (k = 1..K), and the loop returns min(L(K+1), RK) -- the next left
+// stopper if one lies below RK, else RK itself (which now holds a stopper).  Every lane ranks itself
+// among the stoppers with two ballots and popcounts, the K pairs find each other through a small
+// per-wave LDS table, and all swaps are two cross-lane reads.
+__shared__ int haet_wtab[8 * 2 * 64];
+__shared__ int haet_wex[4 * 2 * 64];  // level exchange buffers [group][parity][lane] (by index: no generic pointers)
+__device__ __forceinline__ int w_partition(LaneArr& a, int lo, int hi, unsigned pivot) {
+    typedef unsigned long long u64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u64 range = (hi >= 64 ? ~0ull : ((1ull << hi) - 1)) & (~0ull << lo);
+    const u64 Lm = ~__ballot(a.key < pivot) & range, Rm = ~__ballot(pivot < a.key) & range;
+    const u64 below = (1ull << lane) - 1, above = lane == 63 ? 0ull : (~0ull << (lane + 1));
+    const int n_above = __popcll(Rm & above);
+    const int ra = __popcll(Lm & below) + 1;  // my rank among the left stoppers (if I am one)
+    const int rb = n_above + 1;               // my rank among the right stoppers, from the top
+    const bool swap_l = ((Lm >> lane) & 1) && n_above >= ra;  // L(ra) < R(ra)
+    const u64 SL = __ballot(swap_l);
+    const int K = __popcll(SL);
+    const bool swap_r = ((Rm >> lane) & 1) && rb <= K;
+    const u64 SR = __ballot(swap_r);
+    if (K) {
+        const int tl = wave * 128;  // [tl .. tl+63]: lane of L(k), [tl+64 .. tl+127]: lane of R(k)
+        if (swap_l) haet_wtab[tl + ra - 1] = lane;
+        if (swap_r) haet_wtab[tl + 64 + rb - 1] = lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        int partner = lane;
+        if (swap_l) partner = haet_wtab[tl + 64 + ra - 1];
+        if (swap_r) partner = haet_wtab[tl + rb - 1];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        a.key = (unsigned)__shfl((int)a.key, partner);
+        a.idx = __shfl(a.idx, partner);
+    }
+    const u64 rest = Lm & ~SL;  // left stoppers that did not swap: the lowest one is L(K+1)
+    const int next_l = rest ? __builtin_ctzll(rest) : 64;
+    const int r_k = K ? __builtin_ctzll(SR) : 64;
+    return next_l < r_k ? next_l : r_k;
+}
+
 // introselect on positions [first, last), all scalars wave-uniform
 __device__ __forceinline__ void w_select_nth(LaneArr& a, int first, int nth, int last) {
     if (first == last || nth == last) return;
@@ -123,19 +165,7 @@ __device__ __forceinline__ void w_select_nth(LaneArr& a, int first, int nth, int
         else med = (ka < kc) ? pa : ((kb < kc) ? pc : pb);
         a.swap(first, med);
         const unsigned pivot = a.k(first);
-        int lo = first + 1, hi = last;
-        for (;;) {
-            // while (key[lo] < pivot) ++lo;      (unguarded: a stopper always exists)
-            const unsigned long long lt = __ballot(a.key < pivot);
-            lo = __builtin_ctzll(~lt & (~0ull << lo));
-            --hi;
-            // while (pivot < key[hi]) --hi;
-            const unsigned long long gt = __ballot(pivot < a.key);
-            hi = 63 - __builtin_clzll(~gt & (~0ull >> (63 - hi)));
-            if (!(lo < hi)) break;
-            a.swap(lo, hi);
-            ++lo;
-        }
+        const int lo = w_partition(a, first + 1, last, pivot);
         if (lo <= nth) first = lo;
         else last = lo;
     }
@@ -179,16 +209,16 @@ constexpr int TW = 8;  // waves per cloud
 // EVERY wave of the workgroup calls this the same number of times (the barrier is the workgroup's);
 // `work` = false just keeps the barrier count.
 __device__ __forceinline__ void w_shared_level(LaneArr& a, float cx, float cy, float cz, int nd, int n, int sz,
-                                               bool work, int me, int nw, int* ex) {
+                                               bool work, int me, int nw, int ex) {  // ex: index into haet_wex
     const int lane = threadIdx.x & 63;
     if (work) {
         w_level_keys(a, cx, cy, cz, nd, sz);
         const int nodes = n / sz;
         for (int j = me; j < nodes; j += nw) w_select_nth(a, j * sz, j * sz + sz / 2, j * sz + sz);
-        if (lane < n && (lane / sz) % nw == me) ex[lane] = a.idx;
+        if (lane < n && (lane / sz) % nw == me) haet_wex[ex + lane] = a.idx;
     }
     __syncthreads();
-    if (work && lane < n) a.idx = ex[lane];
+    if (work && lane < n) a.idx = haet_wex[ex + lane];
 }
 
 __global__ __launch_bounds__(64 * TW) void balltree_wave_kernel(
@@ -196,7 +226,6 @@ __global__ __launch_bounds__(64 * TW) void balltree_wave_kernel(
     int t1, int t2, int t3, int rotate, Rot3w R, int32_t* __restrict__ tree_idx,
     uint8_t* __restrict__ tree_mask, int32_t* __restrict__ rot, const float* __restrict__ S, int C,
     float* __restrict__ pos_out) {
-    __shared__ int ex[4][2][64];
     __shared__ float mm[TW][2][3];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cloud = blockIdx.x, n_clouds = gridDim.x;
@@ -250,7 +279,7 @@ __global__ __launch_bounds__(64 * TW) void balltree_wave_kernel(
     a.key = 0;
     // main tree (balltree.h:121-186): halve until the nodes hold 2 points; all TW waves share a level
     int par = 0;
-    for (int sz = M; sz > 2; sz >>= 1, par ^= 1) w_shared_level(a, cx, cy, cz, nd, M, sz, true, wave, TW, ex[0][par]);
+    for (int sz = M; sz > 2; sz >>= 1, par ^= 1) w_shared_level(a, cx, cy, cz, nd, M, sz, true, wave, TW, par * 64);
     if (wave == 0 && lane < M) {
         tree_idx[(size_t)cloud * M + lane] = cloud * M + a.idx;
         tree_mask[(size_t)cloud * M + lane] = 1;
@@ -304,7 +333,7 @@ __global__ __launch_bounds__(64 * TW) void balltree_wave_kernel(
     int sz = n;
     for (int it = 0; it < max_splits; ++it, par ^= 1) {  // `par` carries on: never the buffer just read
         const bool work = mine && it < targets[mine ? grp : 0] && sz > 1;
-        w_shared_level(a, rx, ry, rz, nd, n, sz, work, me, gsize, ex[grp & 3][par]);
+        w_shared_level(a, rx, ry, rz, nd, n, sz, work, me, gsize, ((grp & 3) * 2 + par) * 64);
         if (work) sz >>= 1;
     }
     if (mine && me == 0 && lane < n) rot[rot_off + (size_t)cloud * n + lane] = cloud * n + a.idx;
