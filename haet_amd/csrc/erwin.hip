@@ -91,6 +91,23 @@ struct Img {
         *reinterpret_cast<unsigned short*>(smem + base + t * S + 2 * k) = h;
         *reinterpret_cast<unsigned short*>(smem + base + plane + t * S + 2 * k) = l;
     }
+    // four consecutive columns k0..k0+3 of row t (k0 % 4 == 0, 8-B aligned rows): 8 B per plane
+    __device__ __forceinline__ void put4(int t, int k0, const float (&v)[4]) const {
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+        typedef __attribute__((ext_vector_type(2))) float f2;
+        typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+        unsigned h[2], l[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f2 a = {v[2 * i], v[2 * i + 1]};
+            h[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(a, b2));
+            const f2 r = {v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u)};
+            l[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, b2));
+        }
+        const u32x2_t hv = {h[0], h[1]}, lv = {l[0], l[1]};
+        *reinterpret_cast<u32x2_t*>(smem + base + t * S + 2 * k0) = hv;
+        *reinterpret_cast<u32x2_t*>(smem + base + plane + t * S + 2 * k0) = lv;
+    }
 };
 
 __device__ __forceinline__ Img UI(const Img& i) { return Img{U(i.base), U(i.S), U(i.plane)}; }
@@ -190,6 +207,7 @@ __device__ ERWIN_PHASE void linear_core_t(
     const int l15 = lane & 15, kq = lane >> 4;
     const int Kp = round32(K), nks = Kp >> 5;
     const int nto = (O + 15) >> 4, ntiles = ((n + 15) >> 4) * nto;
+    const bool al16 = ((b0 | dst | (4 * ldd) | (mode == EP_SWIGLU ? (di.base | di.S | di.plane) : 0)) & 15) == 0;
     const size_t plane = (size_t)O * Kp;
     const int my_tiles = ntiles > wave ? (ntiles - wave + nwaves - 1) / nwaves : 0;
     const int items = my_tiles * nks;
@@ -242,50 +260,66 @@ __device__ ERWIN_PHASE void linear_core_t(
         const u32x4 xh = *reinterpret_cast<const u32x4*>(smem + xo);
         const u32x4 xl = *reinterpret_cast<const u32x4*>(smem + xo + x.plane);
         LSTAMP(42);
-        acc0 = mfma3(xh, xl, wv[0], wv[1], acc0);
-        if (dual) acc1 = mfma3(xh, xl, wv[2], wv[3], acc1);
+        // W is the A operand, X the B operand: the accumulator is Y^T -- lane = token column, registers =
+        // four CONSECUTIVE outputs -- so every epilogue moves 16 B (fp32 rows) or 8 B (bf16 image rows)
+        // per lane instead of four strided 4-B / 2-B pieces.
+        acc0 = mfma3(wv[0], wv[1], xh, xl, acc0);
+        if (dual) acc1 = mfma3(wv[2], wv[3], xh, xl, acc1);
 #ifdef HAET_STAMPS
         if (mode == EP_RESID && K <= 64) { asm volatile("" :: "v"(acc0)); }
 #endif
         LSTAMP(43);
         if (c.ks == nks - 1) {
-            const int o = c.ot * 16 + l15, t0 = c.tt * 16 + 4 * kq;
-            if (o < O && t0 < n) {
-                const float bo = F(b0 + 4 * o);
+            const int o0 = c.ot * 16 + 4 * kq, t = c.tt * 16 + l15;
+            if (t < n && o0 < O) {
+                const bool vec = al16 && o0 + 3 < O;  // (true in every shape the models produce)
                 float v[4];
+                if (vec) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(smem + b0 + 4 * o0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc0[r] + bo;
-                if (mode == EP_QKV) {
+                    for (int r = 0; r < 4; ++r) v[r] = acc0[r] + b4[r];
+                } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (t0 + r < n) F(dst + 4 * ((t0 + r) * ldd + o)) = v[r];
-                } else if (mode == EP_RESID) {
-                    float old[4];
+                    for (int r = 0; r < 4; ++r) v[r] = acc0[r] + F(b0 + 4 * min(o0 + r, O - 1));
+                }
+                if (mode == EP_QKV || mode == EP_RESID || mode == EP_BN) {
+                    const int row = dst + 4 * (t * ldd + o0);
+                    if (mode == EP_BN) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) old[r] = F(dst + 4 * (min(t0 + r, n - 1) * ldd + o));
+                        for (int r = 0; r < 4; ++r)
+                            v[r] = v[r] * F(sc + 4 * min(o0 + r, O - 1)) + F(sh + 4 * min(o0 + r, O - 1));
+                    }
+                    if (vec) {
+                        f32x4 y = {v[0], v[1], v[2], v[3]};
+                        if (mode == EP_RESID) y += *reinterpret_cast<const f32x4*>(smem + row);
+                        *reinterpret_cast<f32x4*>(smem + row) = y;
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (t0 + r < n) F(dst + 4 * ((t0 + r) * ldd + o)) = old[r] + v[r];
+                        for (int r = 0; r < 4; ++r)
+                            if (o0 + r < O) F(row + 4 * r) = (mode == EP_RESID ? F(row + 4 * r) : 0.f) + v[r];
+                    }
                 } else if (mode == EP_SWIGLU) {
-                    const float b1o = F(b1 + 4 * o);
+                    float g[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float sig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[r]));
-                        if (t0 + r < n) di.put(t0 + r, o, (acc1[r] + b1o) * (v[r] * sig));
+                        g[r] = (acc1[r] + F(b1 + 4 * min(o0 + r, O - 1))) * (v[r] * sig);
                     }
-                } else if (mode == EP_BN) {
-                    const float so = F(sc + 4 * o), ho = F(sh + 4 * o);
+                    if (vec) {
+                        di.put4(t, o0, g);
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (t0 + r < n) F(dst + 4 * ((t0 + r) * ldd + o)) = v[r] * so + ho;
+                        for (int r = 0; r < 4; ++r)
+                            if (o0 + r < O) di.put(t, o0 + r, g[r]);
+                    }
                 } else {
-                    const int q = o / aux, ch = o - q * aux;  // 'n (m d) -> (n m) d'
-                    const float so = F(sc + 4 * ch), ho = F(sh + 4 * ch);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (t0 + r < n) {
-                            float& y = F(dst + 4 * (((t0 + r) * st + q) * ldd + ch));
-                            y = (y + v[r]) * so + ho;
+                        const int o = o0 + r;
+                        if (o < O) {
+                            const int q = o / aux, ch = o - q * aux;  // 'n (m d) -> (n m) d'
+                            float& y = F(dst + 4 * ((t * st + q) * ldd + ch));
+                            y = (y + v[r]) * F(sc + 4 * ch) + F(sh + 4 * ch);
                         }
                     }
                 }
