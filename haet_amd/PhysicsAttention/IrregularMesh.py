@@ -21,3 +21,6 @@ class Physics_Attention_Irregular_Mesh(PhysicsAttentionBase):
     def project(self, x):
         # [B, N, H*C]; no [B,H,N,C] transpose is ever made
         return self._linear("in_project_x", self.in_project_x, x)
+
+    def project_split(self, x, sp):
+        return self._project_split_linear("in_project_x", self.in_project_x, x, sp)

@@ -17,6 +17,7 @@ merge is replicated.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -98,6 +99,22 @@ class PhysicsAttentionBase(nn.Module):
     def project(self, x: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
 
+    def project_split(self, x: torch.Tensor, sp):
+        """Projection straight into the streaming passes' operand format (ops.SplitPoints), or None
+        when this variant / shape has no such path (then `project` + the fp32 passes run)."""
+        return None
+
+    def _project_split_linear(self, name: str, lin: nn.Linear, x: torch.Tensor, sp):
+        B, N, _ = x.shape
+        H, C, G = self.heads, self.dim_head, self.slice_num
+        if os.environ.get("HAET_NO_SPLIT_FORMAT") or x.dtype != torch.float32:
+            return None
+        if not (ops.project_split_supported(lin.in_features, lin.out_features, B * N)
+                and ops.slice_split_supported(B, N, H, C, G)):
+            return None
+        w = self._split_linear(name, lin)
+        return None if w is None else ops.project_split(x, w, sp, H, C)
+
     def _split_linear(self, name: str, lin: nn.Linear):
         """haet_linear_fwd operand of a Linear (cached per weight version), or None when the shape
         is outside the MFMA GEMM's envelope (then the stock rocBLAS GEMM runs)."""
@@ -154,11 +171,14 @@ class PhysicsAttentionBase(nn.Module):
         H, C, G = self.heads, self.dim_head, self.slice_num
         self.__dict__["_event_chain"] = [None] if self.stage_events is not None else None
         ev = self._stage
-        with ev("project"):
-            x_lin = self.project(x).float().contiguous()                # [B, N, H*C]
         sp = self._slice_params()
+        xs = None
+        with ev("project"):
+            xs = self.project_split(x, sp)                               # fused operand format, or None
+            x_lin = None if xs is not None else self.project(x).float().contiguous()  # [B, N, H*C]
         with ev("slice"):
-            parts = ops.slice_partials(x_lin, sp, H, C, G)              # [P, record]
+            parts = (ops.slice_partials_split(xs, sp, G) if xs is not None
+                     else ops.slice_partials(x_lin, sp, H, C, G))       # [P, record]
         with ev("merge"):
             if self.shard_group is not None:
                 from ..sharding import allgather_records
@@ -170,10 +190,13 @@ class PhysicsAttentionBase(nn.Module):
             S2 = self.erwin(S, None, n_clouds=B * H)                     # [B*H*G, C]
             pos = self.erwin.last_positions                              # [B*H*G, d]
         with ev("deslice"):
-            out_x = ops.deslice(x_lin, sp, col_max, col_sum, S2, H, C, G)  # [B, N, H*C]
+            out_x = (ops.deslice_split(xs, sp, col_max, col_sum, S2, G) if xs is not None
+                     else ops.deslice(x_lin, sp, col_max, col_sum, S2, H, C, G))  # [B, N, H*C]
         with ev("to_out"):
             out = self.to_out[1](self._linear("to_out", self.to_out[0], out_x)).to(x.dtype)
         if return_intermediates:
+            if xs is not None:
+                x_lin = xs.to_float()
             return out, dict(x_lin=x_lin, col_max=col_max, col_sum=col_sum, eidetic=S, pos=pos,
                              processed=S2, out_x=out_x)
         return out

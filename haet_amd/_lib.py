@@ -60,6 +60,12 @@ SIGNATURES = {
                                     c_float, _P, _P, _P, _P]),
     "haet_tokens_tree_build": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int),
                                        c_float, _P, _P, _P, _P]),
+    "haet_project_split_supported": (c_int, [c_int, c_int, c_int]),
+    "haet_project_split_fwd": (c_int, [_P, _P, _P, _P, _P, c_float, c_float, c_int, c_int, c_int, _P, _P, _P]),
+    "haet_slice_split_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "haet_slice_fwd_split": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "haet_deslice_fwd_split": (c_int, [_P, _P, _P, _P, c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                                       _P, _P]),
     "haet_erwin_lds_bytes": (c_size_t, [POINTER(ErwinDesc), c_int]),
     "haet_erwin_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, POINTER(ErwinDesc), c_int, c_int, _P, _P]),
     "haet_deslice_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P]

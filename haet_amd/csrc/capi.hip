@@ -31,14 +31,15 @@ int deslice_valu_fwd(const float*, const float*, const float*, const float*, flo
 // slice_mfma.hip
 struct MfmaPlan {
     int li, ipw, mb, hpw, tiles_per_chunk, parts;
+    int s_nw, s_li;
     size_t lds_slice, lds_deslice;
 };
 bool mfma_plan(int B, int N, int H, int C, int M, MfmaPlan* p);
 int slice_mfma_fwd(const float*, const float*, const float*, const float*, float, float, float, int,
-                   int, int, int, int, float*, hipStream_t);
+                   int, int, int, int, float*, hipStream_t, const float* s_in);
 int deslice_mfma_fwd(const float*, const float*, const float*, const float*, float, float, float,
                      const float*, const float*, const float*, int, int, int, int, int, float*,
-                     hipStream_t);
+                     hipStream_t, const float* s_in);
 
 // HAET_FORCE_VALU=1 routes every shape through the generic fp32 VALU kernels (tests)
 static bool use_mfma(int B, int N, int H, int C, int M, MfmaPlan* p) {
@@ -72,7 +73,7 @@ extern "C" int haet_slice_fwd(const float* x_lin, const float* Ws, const float* 
     int rc = slice_shape_ok(B, N, H, C, M);
     if (rc != HAET_OK) return rc;
     if (use_mfma(B, N, H, C, M, nullptr))
-        return slice_mfma_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, B, N, H, C, M, parts, as_stream(stream));
+        return slice_mfma_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, B, N, H, C, M, parts, as_stream(stream), nullptr);
     return slice_valu_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, B, N, H, C, M, parts, as_stream(stream));
 }
 
@@ -86,7 +87,35 @@ extern "C" int haet_deslice_fwd(const float* x_lin, const float* Ws, const float
     if (rc != HAET_OK) return rc;
     if (use_mfma(B, N, H, C, M, nullptr))
         return deslice_mfma_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, S2, B, N, H, C,
-                                M, out_x, as_stream(stream));
+                                M, out_x, as_stream(stream), nullptr);
     return deslice_valu_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, S2, B, N, H, C, M,
                             out_x, as_stream(stream));
+}
+
+// ---- the same two passes on the split-format projection (haet_project_split_fwd) ----------------
+extern "C" int haet_slice_split_supported(int B, int N, int H, int C, int M) {
+    MfmaPlan p;
+    return (slice_shape_ok(B, N, H, C, M) == HAET_OK && (H == 8 || H == 16) && use_mfma(B, N, H, C, M, &p)) ? 1 : 0;
+}
+
+extern "C" int haet_slice_fwd_split(const void* x_split, const float* s, const float* Ws, const float* bs,
+                                    float c0, int B, int N, int H, int C, int M, float* parts,
+                                    haet_stream_t stream) {
+    if (!x_split || !s || !Ws || !bs || !parts) return fail(HAET_E_ARG, "slice_fwd_split: null pointer");
+    if (!haet_slice_split_supported(B, N, H, C, M))
+        return fail(HAET_E_ARG, "slice_fwd_split: shape B=%d N=%d H=%d C=%d M=%d is outside the MFMA path", B, N, H, C, M);
+    return slice_mfma_fwd(reinterpret_cast<const float*>(x_split), Ws, bs, nullptr, 0.f, 0.f, c0, B, N, H, C, M,
+                          parts, as_stream(stream), s);
+}
+
+extern "C" int haet_deslice_fwd_split(const void* x_split, const float* s, const float* Ws, const float* bs,
+                                      float c0, const float* col_max, const float* col_sum,
+                                      const float* S2, int B, int N, int H, int C, int M, float* out_x,
+                                      haet_stream_t stream) {
+    if (!x_split || !s || !Ws || !bs || !col_max || !col_sum || !S2 || !out_x)
+        return fail(HAET_E_ARG, "deslice_fwd_split: null pointer");
+    if (!haet_slice_split_supported(B, N, H, C, M))
+        return fail(HAET_E_ARG, "deslice_fwd_split: shape B=%d N=%d H=%d C=%d M=%d is outside the MFMA path", B, N, H, C, M);
+    return deslice_mfma_fwd(reinterpret_cast<const float*>(x_split), Ws, bs, nullptr, 0.f, 0.f, c0, col_max,
+                            col_sum, S2, B, N, H, C, M, out_x, as_stream(stream), s);
 }

@@ -298,11 +298,20 @@ __device__ unsigned long long haet_gemm_stamps[64];
 #define GSTAMP(i) do { } while (0)
 #endif
 constexpr int WS_IMGP = 2 * GIMG + 32;  // {hi, lo} image pair + 8 banks of skew between k-items
-template <int NKT, int S>
+// SPLIT (the in_project_x of the C = 32 fast path): the output goes out in the streaming passes' own
+// operand format instead of fp32 -- per 4 channels 16 B = {4 x bf16 hi, 4 x bf16 lo}, same row stride as
+// fp32 -- together with s[n][h] = log2(e) / tau(n, h) (Ada-Temp, IrregularMesh.py:168), so the slice
+// and de-slice loaders only copy.  They are bound by vector issue; the GEMM has the slack.
+struct SplitArgs {
+    const float* wt;  // ada_temp_linear.weight [32]
+    float bt, base_temp;
+    float* s_out;     // [Nrows][O / 32]
+};
+template <int NKT, int S, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ Whi,
     const unsigned short* __restrict__ Wlo, const float* __restrict__ bias, int Nrows, int O,
-    int n_row_tiles, float* __restrict__ out) {
+    int n_row_tiles, float* __restrict__ out, SplitArgs sa) {
     constexpr int K = NKT * GBK, BM = 64;
     constexpr int RBSZ = NKT * WS_IMGP, TBUF = 2 * RBSZ;  // one 32-row block, one tile
     constexpr int LPR = K / 4, RPI = 64 / LPR;            // lanes per x row, rows per wave load
@@ -371,7 +380,15 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(
     const int col4 = blockIdx.y * 256 + 32 * wave + (l31 & ~3);  // first of this lane's 4 output columns
     const unsigned o_voff = (unsigned)(((4 * hf + (lane & 3)) * O + col4) * 4);  // bytes from the tile's first row
     constexpr int GPS = NKT == 8 ? 2 : 1;  // sub-steps per stored register group (4 groups per phase)
-    auto store_group = [&](char* ob, const f32x16& c, int i, int g) {
+    float wt4[4] = {0.f, 0.f, 0.f, 0.f};
+    char* const sb = reinterpret_cast<char*>(sa.s_out);
+    const unsigned s_voff = (unsigned)(((4 * hf + (lane & 3)) * (O / 32) + blockIdx.y * 8 + wave) * 4);
+    if (SPLIT) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wt4[q] = sa.wt[(l31 & ~3) + q];
+    }
+    auto store_group = [&](long long row0, const f32x16& c, int i, int g) {  // row0: first row of the tile
+        char* const ob = reinterpret_cast<char*>(out) + row0 * ((long long)O * 4);
         int v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = __float_as_int(c[4 * g + q]);
@@ -390,8 +407,32 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(
             v[m] = up ? recv : v[m];
             v[m + 2] = up ? v[m + 2] : recv;
         }
-        const f32x4 o4 = {__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])};
-        *reinterpret_cast<f32x4*>(ob + o_voff + (unsigned)((32 * i + 8 * g) * O * 4)) = o4;
+        if (!SPLIT) {
+            const f32x4 o4 = {__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])};
+            *reinterpret_cast<f32x4*>(ob + o_voff + (unsigned)((32 * i + 8 * g) * O * 4)) = o4;
+        } else {
+            // this lane: ONE row, four consecutive channels of head `wave` (+ 8 blockIdx.y)
+            const float f0 = __int_as_float(v[0]), f1 = __int_as_float(v[1]), f2 = __int_as_float(v[2]), f3 = __int_as_float(v[3]);
+            const unsigned h01 = g_pack(f0, f1), h23 = g_pack(f2, f3);
+            const u32x4 o4 = {h01, h23,
+                              g_pack(f0 - __uint_as_float(h01 << 16), f1 - __uint_as_float(h01 & 0xffff0000u)),
+                              g_pack(f2 - __uint_as_float(h23 << 16), f3 - __uint_as_float(h23 & 0xffff0000u))};
+            *reinterpret_cast<u32x4*>(ob + o_voff + (unsigned)((32 * i + 8 * g) * O * 4)) = o4;
+            // Ada-Temp: dot over the head's 32 channels = my 4 + the other 7 quads of my row (lanes with
+            // the same lane & 3: rotations by 4 and 8 inside the 16-lane row, then the other row)
+            float t = f0 * wt4[0];
+            t = fmaf(f1, wt4[1], t);
+            t = fmaf(f2, wt4[2], t);
+            t = fmaf(f3, wt4[3], t);
+            t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x124, 0xF, 0xF, false));  // row_ror:4
+            t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, false));  // row_ror:8
+            t += __shfl_xor(t, 16);
+            const float tau = sa.base_temp + fminf(fmaxf(t + sa.bt, -0.4f), 0.4f);
+            // every lane stores (the 8 lanes of a row write the same value to the same word: a
+            // conditional store here would cost the prefetch ring its counted waits)
+            *reinterpret_cast<float*>(sb + row0 * ((long long)(O / 32) * 4) + s_voff + (unsigned)((32 * i + 8 * g) * (O / 32) * 4)) =
+                1.4426950408889634f * __builtin_amdgcn_rcpf(tau);
+        }
     };
 
     // prologue: tile 0 staged, fetches 0 .. S-1 of tile 1 in flight.  Each fetch is followed by the
@@ -406,7 +447,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(
 #pragma unroll
         for (int j = 0; j < NKT; ++j) stage(0, j, fetch(b0, j));
         const char* b1 = xb + tile_row0(1) * (K * 4);
-        char* o0 = reinterpret_cast<char*>(out) + tile_row0(0) * ((long long)O * 4);
+        const long long o0 = tile_row0(0);
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             __builtin_amdgcn_sched_barrier(0);  // x is __restrict__: the loads would drift past the stores
@@ -434,8 +475,8 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(
         const char* b1 = xb + tile_row0(t + 1) * (K * 4);
         const char* b2 = xb + tile_row0(t + 2) * (K * 4);
         // (t = 0: nothing to store yet -- the bias goes to this tile's own rows and is overwritten later)
-        char* o_prev = reinterpret_cast<char*>(out) + tile_row0(t ? t - 1 : 0) * ((long long)O * 4);
-        char* o_cur = reinterpret_cast<char*>(out) + tile_row0(t) * ((long long)O * 4);
+        const long long o_prev = tile_row0(t ? t - 1 : 0);
+        const long long o_cur = tile_row0(t);
         GFrag a = g_read(cur, l31, hf);
 #pragma unroll
         for (int u = 0; u < 2 * NKT; ++u) {
@@ -481,7 +522,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(
         while (++t < my_tiles);
     }
     {
-        char* ob = reinterpret_cast<char*>(out) + tile_row0(my_tiles - 1) * ((long long)O * 4);
+        const long long ob = tile_row0(my_tiles - 1);
 #pragma unroll
         for (int g = 0; g < 4; ++g) store_group(ob, acc[1], 1, g);
     }
@@ -527,7 +568,7 @@ extern "C" int haet_linear_fwd(const float* x, const uint16_t* W_hi, const uint1
             if (lds > 64 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi, W_lo, bias, Nrows,
-                               O, tiles, out);
+                               O, tiles, out, SplitArgs{nullptr, 0.f, 0.f, nullptr});
         };
         if (K == 256) go(gemm_ws_kernel<8, 4>);
         else go(gemm_ws_kernel<4, 4>);
@@ -558,4 +599,30 @@ extern "C" int haet_linear_fwd(const float* x, const uint16_t* W_hi, const uint1
     else rc = launch(gemm_x3_kernel<4, 2>);
     if (rc != HAET_OK) return rc;
     return check_launch("gemm_x3_kernel");
+}
+
+extern "C" int haet_project_split_supported(int K, int O, int Nrows) {
+    return (O % 256 == 0 && (K == 128 || K == 256) && Nrows >= 64) ? 1 : 0;
+}
+
+extern "C" int haet_project_split_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo,
+                                      const float* bias, const float* wt, float bt, float base_temp,
+                                      int Nrows, int K, int O, void* x_split, float* s_out,
+                                      haet_stream_t stream) {
+    if (!x || !W_hi || !W_lo || !wt || !x_split || !s_out)
+        return fail(HAET_E_ARG, "project_split_fwd: null pointer");
+    if (!haet_project_split_supported(K, O, Nrows))
+        return fail(HAET_E_ARG, "project_split_fwd: K=%d O=%d rows=%d outside the W-stationary kernel", K, O, Nrows);
+    const int tiles = (Nrows + 63) / 64, ny = O / 256;
+    const int gx = tiles < 256 / ny ? tiles : (256 / ny > 0 ? 256 / ny : 1);
+    const size_t lds = (size_t)2 * 2 * (K / GBK) * WS_IMGP;
+    auto go = [&](auto kern) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi, W_lo, bias, Nrows, O,
+                           tiles, reinterpret_cast<float*>(x_split), SplitArgs{wt, bt, base_temp, s_out});
+    };
+    if (K == 256) go(gemm_ws_kernel<8, 4, true>);
+    else go(gemm_ws_kernel<4, 4, true>);
+    return check_launch("gemm_ws_kernel<split>");
 }

@@ -103,7 +103,7 @@ __device__ __forceinline__ float dpp(float v) {
 // LI = 16-B chunks per thread per tile (32 rows x H*8 chunks / NT threads): ceil(H/2) at 512 threads.
 // Everything that does not change from tile to tile is computed once in init(): the row / head of
 // each chunk, its LDS offsets, its global pointer (advanced by one tile per fetch).
-template <int LI, int NT = NTHR>
+template <int LI, int NT = NTHR, bool SPLIT = false>
 struct Loader {
     f32x4 xr[LI];
     float wt4[4];
@@ -113,13 +113,27 @@ struct Loader {
     int soff[LI];          // byte offset of s_n inside an s array (q8 == 0 lanes)
     int q8;                // chunk index inside the head: c0 = 4*q8
     size_t tile_stride;    // floats per tile (32 rows)
+    // SPLIT input (haet_project_split_fwd): rows arrive as {4 x bf16 hi, 4 x bf16 lo} per 16 B and
+    // s_n = log2(e) / tau as an [N][H] array -- the loader only copies
+    const float* sptr;     // next tile's s value of this thread (threads < 32 * H)
+    size_t s_stride;
+    float sv;
+    int srow, soff2;
 
-    __device__ __forceinline__ void init(const float* __restrict__ wt, const float* xb, int H, int row0) {
+    __device__ __forceinline__ void init(const float* __restrict__ wt, const float* xb, int H, int row0,
+                                         const float* sb = nullptr) {
         q8 = threadIdx.x & 7;
+        if (SPLIT) {
+            srow = (int)threadIdx.x / H;  // >= TN: no s value on this thread
+            sptr = sb + (size_t)row0 * H + threadIdx.x;
+            s_stride = (size_t)TN * H;
+            soff2 = 4 * (((int)threadIdx.x % H) * TN + (srow & (TN - 1)));
+            sv = 1.f;
+        }
         const int cpr = H * 8;  // chunks per row
         tile_stride = (size_t)TN * cpr * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wt4[i] = wt[4 * q8 + i];
+        for (int i = 0; i < 4; ++i) wt4[i] = SPLIT ? 0.f : wt[4 * q8 + i];
 #pragma unroll
         for (int i = 0; i < LI; ++i) {
             const int e = threadIdx.x + NT * i;
@@ -139,9 +153,28 @@ struct Loader {
             xr[i] = v;
             src[i] += tile_stride;
         }
+        if (SPLIT) {
+            float v = 1.f;
+            if (srow < TN && srow < nvalid) v = *sptr;
+            sv = v;
+            sptr += s_stride;
+        }
     }
     // split to bf16 hi/lo, write the LDS images, reduce Ada-Temp and write s_n = log2e / tau
     __device__ __forceinline__ void stage(int buf, int sarr, float bt, float base_temp) {
+        if (SPLIT) {
+#pragma unroll
+            for (int i = 0; i < LI; ++i) {
+                if (row[i] < TN) {
+                    const u32x4 w = __builtin_bit_cast(u32x4, xr[i]);
+                    const u32x2 hi = {w[0], w[1]}, lo = {w[2], w[3]};
+                    *reinterpret_cast<u32x2*>(smem + buf + loff[i]) = hi;
+                    *reinterpret_cast<u32x2*>(smem + buf + loff[i] + IMG) = lo;
+                }
+            }
+            if (srow < TN) *reinterpret_cast<float*>(smem + sarr + soff2) = sv;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < LI; ++i) {
             if (row[i] < TN) {
@@ -221,11 +254,11 @@ __device__ __forceinline__ void stage_ws(int wimg, const float* __restrict__ Ws,
 // instead of overlapping (two waves per SIMD at ~230 VGPRs).  Tried without gain: 16 waves with
 // one item each (128 VGPRs only with spills; 25 % slower), running the two waves of a SIMD in
 // opposite stage/compute order.
-template <int LI, int IPW, int MB, int NWV = NW>
+template <int LI, int IPW, int MB, int NWV = NW, bool SPLIT = false>
 __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ Ws, const float* __restrict__ bs,
     const float* __restrict__ wt, float bt, float base_temp, float c0, int N, int H,
-    int tiles_per_chunk, float* __restrict__ parts) {
+    int tiles_per_chunk, float* __restrict__ parts, const float* __restrict__ s_in) {
     constexpr int M = 32 * MB;
     constexpr int IPH = (IPW < MB) ? IPW : MB;  // items of one head handled by this wave
     constexpr int HPW = IPW / IPH;              // heads per wave
@@ -243,9 +276,10 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
     const int wimg = sarr0 + 2 * sarr_bytes + NWV * 32 * 4;  // [MB][hi|lo] images of Ws
     const float* xb = x + (size_t)b * N * H * kC;
 
-    Loader<LI, NWV * 64> ld;
-    ld.init(wt, xb, H, t_begin * TN);
+    Loader<LI, NWV * 64, SPLIT> ld;
+    ld.init(wt, xb, H, t_begin * TN, SPLIT ? s_in + (size_t)b * N * H : nullptr);
     ld.tile_stride *= G;
+    if (SPLIT) ld.s_stride *= G;
     stage_ws(wimg, Ws, M);
 
     // per-item state (the Ws fragments -- B operand: col g = lane&31, k = c -- come from LDS)
@@ -402,12 +436,13 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
 
 // ----------------------------------------------------------------------------- de-slice
 // HPW heads per wave; all MB column blocks of a head are summed into one output tile.
-template <int LI, int HPW, int MB>
+template <int LI, int HPW, int MB, bool SPLIT = false>
 __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ Ws, const float* __restrict__ bs,
     const float* __restrict__ wt, float bt, float base_temp, float c0,
     const float* __restrict__ col_max, const float* __restrict__ col_sum,
-    const float* __restrict__ S2, int N, int H, int tiles_per_chunk, float* __restrict__ out) {
+    const float* __restrict__ S2, int N, int H, int tiles_per_chunk, float* __restrict__ out,
+    const float* __restrict__ s_in) {
     constexpr int M = 32 * MB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y;
@@ -426,9 +461,10 @@ __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
         *reinterpret_cast<float*>(smem + biasL + 4 * i) = bs[i % M] - c0;
         *reinterpret_cast<float*>(smem + m2L + 4 * i) = col_max[(size_t)b * H * M + i] * kLog2e;
     }
-    Loader<LI> ld;
-    ld.init(wt, xb, H, t_begin * TN);
+    Loader<LI, NTHR, SPLIT> ld;
+    ld.init(wt, xb, H, t_begin * TN, SPLIT ? s_in + (size_t)b * N * H : nullptr);
     ld.tile_stride *= G;
+    if (SPLIT) ld.s_stride *= G;
     stage_ws(wimg, Ws, M);
 
     // per-head constants: the S'/l fragments (A operand: row c = lane&31, k = g in accumulator
@@ -564,18 +600,26 @@ static int set_lds(K kernel, size_t bytes) {
     return HAET_OK;
 }
 
-#define SLICE_CASE(LI_, IPW_, MB_, NW_)                                                            \
-    if (p.s_li == LI_ && p.ipw == IPW_ && p.mb == MB_ && p.s_nw == NW_) {                            \
-        auto kern = slice_mfma_kernel<LI_, IPW_, MB_, NW_>;                                          \
+#define SLICE_LAUNCH(LI_, IPW_, MB_, NW_, SP_)                                                    \
+    {                                                                                                 \
+        auto kern = slice_mfma_kernel<LI_, IPW_, MB_, NW_, SP_>;                                      \
         if (int rc = set_lds(kern, p.lds_slice)) return rc;                                          \
         hipLaunchKernelGGL(kern, grid, dim3(NW_ * 64), p.lds_slice, st, x, Ws, bs, wt, bt, base_temp, \
-                           c0, N, H, p.tiles_per_chunk, parts);                                      \
+                           c0, N, H, p.tiles_per_chunk, parts, s_in);                                \
         return check_launch("slice_mfma_kernel");                                                    \
+    }
+#define SLICE_CASE(LI_, IPW_, MB_, NW_)                                                            \
+    if (p.s_li == LI_ && p.ipw == IPW_ && p.mb == MB_ && p.s_nw == NW_) {                            \
+        if (s_in) {                                                                                   \
+            if constexpr (LI_ >= 4) SLICE_LAUNCH(LI_, IPW_, MB_, NW_, true)                           \
+            return fail(HAET_E_ARG, "slice_mfma: split input needs H = 8 or 16");                     \
+        }                                                                                             \
+        SLICE_LAUNCH(LI_, IPW_, MB_, NW_, false)                                                      \
     }
 
 int slice_mfma_fwd(const float* x, const float* Ws, const float* bs, const float* wt, float bt,
                    float base_temp, float c0, int B, int N, int H, int C, int M, float* parts,
-                   hipStream_t st) {
+                   hipStream_t st, const float* s_in) {
     MfmaPlan p;
     if (!mfma_plan(B, N, H, C, M, &p)) return fail(HAET_E_ARG, "slice_mfma: unsupported shape");
     dim3 grid(p.parts, B);
@@ -593,18 +637,26 @@ int slice_mfma_fwd(const float* x, const float* Ws, const float* bs, const float
     return fail(HAET_E_ARG, "slice_mfma: no instantiation for H=%d M=%d", H, M);
 }
 
-#define DESLICE_CASE(LI_, HPW_, MB_)                                                              \
-    if (p.li == LI_ && p.hpw == HPW_ && p.mb == MB_) {                                             \
-        auto kern = deslice_mfma_kernel<LI_, HPW_, MB_>;                                           \
+#define DESLICE_LAUNCH(LI_, HPW_, MB_, SP_)                                                       \
+    {                                                                                               \
+        auto kern = deslice_mfma_kernel<LI_, HPW_, MB_, SP_>;                                       \
         if (int rc = set_lds(kern, p.lds_deslice)) return rc;                                      \
         hipLaunchKernelGGL(kern, grid, dim3(NTHR), p.lds_deslice, st, x, Ws, bs, wt, bt, base_temp, \
-                           c0, cm, cs, S2, N, H, p.tiles_per_chunk, out);                          \
+                           c0, cm, cs, S2, N, H, p.tiles_per_chunk, out, s_in);                    \
         return check_launch("deslice_mfma_kernel");                                                \
+    }
+#define DESLICE_CASE(LI_, HPW_, MB_)                                                              \
+    if (p.li == LI_ && p.hpw == HPW_ && p.mb == MB_) {                                             \
+        if (s_in) {                                                                                 \
+            if constexpr (LI_ >= 4) DESLICE_LAUNCH(LI_, HPW_, MB_, true)                            \
+            return fail(HAET_E_ARG, "deslice_mfma: split input needs H = 8 or 16");                 \
+        }                                                                                           \
+        DESLICE_LAUNCH(LI_, HPW_, MB_, false)                                                       \
     }
 
 int deslice_mfma_fwd(const float* x, const float* Ws, const float* bs, const float* wt, float bt,
                      float base_temp, float c0, const float* cm, const float* cs, const float* S2,
-                     int B, int N, int H, int C, int M, float* out, hipStream_t st) {
+                     int B, int N, int H, int C, int M, float* out, hipStream_t st, const float* s_in) {
     MfmaPlan p;
     if (!mfma_plan(B, N, H, C, M, &p)) return fail(HAET_E_ARG, "deslice_mfma: unsupported shape");
     dim3 grid(p.parts, B);

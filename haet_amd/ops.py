@@ -196,3 +196,61 @@ def linear(x: Tensor, w: SplitLinear) -> Tensor:
     check(lib.haet_linear_fwd(_p(x), _p(w.hi), _p(w.lo), _p(w.bias), rows, w.K, w.O, _p(out), _stream()),
           "haet_linear_fwd")
     return out
+
+
+# --------------------------------------------------------------------------- fused operand format
+class SplitPoints:
+    """x_lin in the streaming passes' operand format (haet_project_split_fwd): `cells` [B, N, H*C]
+    4-byte cells holding, per 4 channels, 4 bf16 hi then 4 bf16 lo, and `s` [B, N, H] = log2(e)/tau."""
+
+    def __init__(self, cells: Tensor, s: Tensor, H: int, C: int):
+        self.cells, self.s, self.H, self.C = cells, s, H, C
+
+    def to_float(self) -> Tensor:
+        """fp32 x_lin = hi + lo (for inspection / tests; 2^-17 relative to the fp32 projection)."""
+        B, N, HC = self.cells.shape
+        w = self.cells.view(torch.bfloat16).reshape(B, N, HC // 4, 2, 4).float()
+        return (w[:, :, :, 0] + w[:, :, :, 1]).reshape(B, N, HC)
+
+
+def project_split_supported(K: int, O: int, rows: int) -> bool:
+    return bool(_lib.load().haet_project_split_supported(int(K), int(O), int(rows)))
+
+
+def slice_split_supported(B: int, N: int, H: int, C: int, M: int) -> bool:
+    return bool(_lib.load().haet_slice_split_supported(B, N, H, C, M))
+
+
+def project_split(x: Tensor, w: SplitLinear, p: SliceParams, H: int, C: int) -> SplitPoints:
+    """in_project_x on the matrix cores, output in the split operand format + s = log2(e)/tau."""
+    lib = _lib.load()
+    x = _f32(x, "x")
+    B, N, K = x.shape
+    cells = torch.empty((B, N, w.O), dtype=torch.float32, device=x.device)
+    s = torch.empty((B, N, H), dtype=torch.float32, device=x.device)
+    check(lib.haet_project_split_fwd(_p(x), _p(w.hi), _p(w.lo), _p(w.bias), _p(p.wt), p.bt, p.base_temp,
+                                     B * N, K, w.O, _p(cells), _p(s), _stream()), "haet_project_split_fwd")
+    return SplitPoints(cells, s, H, C)
+
+
+def slice_partials_split(xs: SplitPoints, p: SliceParams, M: int) -> Tensor:
+    lib = _lib.load()
+    B, N, _ = xs.cells.shape
+    H, C = xs.H, xs.C
+    P = lib.haet_slice_num_parts(B, N, H, C, M)
+    if P < 0:
+        check(P, "haet_slice_num_parts")
+    parts = torch.empty((P, lib.haet_slice_part_floats(B, H, C, M)), dtype=torch.float32, device=xs.cells.device)
+    check(lib.haet_slice_fwd_split(_p(xs.cells), _p(xs.s), _p(p.Ws), _p(p.bs), p.c0, B, N, H, C, M, _p(parts),
+                                   _stream()), "haet_slice_fwd_split")
+    return parts
+
+
+def deslice_split(xs: SplitPoints, p: SliceParams, col_max: Tensor, col_sum: Tensor, S2: Tensor, M: int) -> Tensor:
+    lib = _lib.load()
+    B, N, _ = xs.cells.shape
+    out = torch.empty_like(xs.cells)
+    check(lib.haet_deslice_fwd_split(_p(xs.cells), _p(xs.s), _p(p.Ws), _p(p.bs), p.c0, _p(col_max), _p(col_sum),
+                                     _p(_f32(S2, "S2")), B, N, xs.H, xs.C, M, _p(out), _stream()),
+          "haet_deslice_fwd_split")
+    return out

@@ -205,6 +205,26 @@ int haet_deslice_fwd(const float* x_lin, const float* Ws, const float* bs, const
                      const float* S2 /*[B*H*M, C]*/, int B, int N, int H, int C, int M,
                      float* out_x /*[B,N,H*C]*/, haet_stream_t stream);
 
+/* ------------------------------------------------------------------ fused operand format
+ * The C = 32 fast path of the module keeps x_lin in the streaming passes' own operand format
+ * instead of fp32: per 4 channels 16 B = {4 x bf16 hi, 4 x bf16 lo} (hi = RNE(x), lo = RNE(x - hi)),
+ * row stride H*C*4 B like the fp32 tensor, plus s[n][h] = log2(e) / tau(n,h) (Ada-Temp,
+ * IrregularMesh.py:168).  haet_project_split_fwd is in_project_x (IrregularMesh.py:157-164) writing
+ * that format; the two *_split passes are haet_slice_fwd / haet_deslice_fwd reading it (same
+ * records, same outputs).  The projection GEMM has vector-issue slack, the passes do not.        */
+int haet_project_split_supported(int K, int O, int Nrows);
+int haet_project_split_fwd(const float* x /*[Nrows,K]*/, const uint16_t* W_hi, const uint16_t* W_lo,
+                           const float* bias /*[O] or NULL*/, const float* wt /*[32] ada_temp weight*/,
+                           float bt, float base_temp, int Nrows, int K, int O,
+                           void* x_split /*[Nrows, O] 4-B cells*/, float* s_out /*[Nrows, O/32]*/,
+                           haet_stream_t stream);
+int haet_slice_split_supported(int B, int N, int H, int C, int M);
+int haet_slice_fwd_split(const void* x_split, const float* s, const float* Ws, const float* bs, float c0,
+                         int B, int N, int H, int C, int M, float* parts, haet_stream_t stream);
+int haet_deslice_fwd_split(const void* x_split, const float* s, const float* Ws, const float* bs,
+                           float c0, const float* col_max, const float* col_sum, const float* S2,
+                           int B, int N, int H, int C, int M, float* out_x, haet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

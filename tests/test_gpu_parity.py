@@ -446,3 +446,34 @@ def test_fused_tokens_tree_matches_separate_calls(M, d, C, hip_device):
     ti2, tm2, rot2, _, pos2 = ops.balltree_build(None, n_clouds, M, strides, ball_sizes, 45.0, tokens=S, d=d)
     assert torch.equal(pos, pos2)
     assert torch.equal(ti, ti2) and torch.equal(tm, tm2) and torch.equal(rot, rot2)
+
+
+@pytest.mark.parametrize("B,N,H,M", [(1, 4133, 8, 64), (2, 1000, 8, 32), (1, 70, 16, 64), (1, 2049, 8, 128)])
+def test_split_operand_format_matches_fp32_path(B, N, H, M, hip_device):
+    """haet_project_split_fwd + the *_split passes against haet_linear_fwd + the fp32-input passes: the
+    same operands reach the matrix cores (hi / lo of the same fp32 projection), so records and
+    outputs agree to rounding; Ada-Temp comes from the GEMM epilogue instead of the loaders."""
+    from haet_amd import ops
+
+    torch.manual_seed(B * N + H + M)
+    C, K = 32, 256
+    dev = hip_device
+    x = torch.randn(B, N, K, device=dev)
+    W, b = torch.randn(H * C, K, device=dev) * 0.06, torch.randn(H * C, device=dev) * 0.1
+    sp = ops.SliceParams(torch.randn(M, C, device=dev) * 0.3, torch.randn(M, device=dev) * 0.2,
+                         torch.randn(1, C, device=dev) * 0.3, 0.05, 0.5, 1e-6)
+    w = ops.SplitLinear(W, b)
+    assert ops.project_split_supported(K, H * C, B * N) and ops.slice_split_supported(B, N, H, C, M)
+    x_lin = ops.linear(x, w)
+    xs = ops.project_split(x, w, sp, H, C)
+    assert O.rel_l2(xs.to_float().cpu(), x_lin.cpu()) < 1e-5
+    tau = 0.5 + torch.clamp((x_lin.reshape(B, N, H, C) * sp.wt.reshape(1, 1, 1, C)).sum(-1) + sp.bt, -0.4, 0.4)
+    assert torch.allclose(xs.s.cpu(), (1.4426950408889634 / tau).cpu(), rtol=2e-5)
+    cm, cs, S = ops.merge_records(ops.slice_partials(x_lin, sp, H, C, M), B, H, C, M, True)
+    cm2, cs2, S2 = ops.merge_records(ops.slice_partials_split(xs, sp, M), B, H, C, M, True)
+    assert torch.allclose((cm + cs.log()).cpu(), (cm2 + cs2.log()).cpu(), atol=2e-4)
+    assert O.rel_l2(S2.cpu(), S.cpu()) < 2e-5
+    T2 = torch.randn(B * H * M, C, device=dev)
+    a = ops.deslice(x_lin, sp, cm, cs, T2, H, C, M)
+    b2 = ops.deslice_split(xs, sp, cm, cs, T2, M)
+    assert O.rel_l2(b2.cpu(), a.cpu()) < 2e-5
