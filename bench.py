@@ -33,8 +33,8 @@ STAGES = ("project", "slice", "merge", "erwin", "deslice", "to_out")  # erwin = 
 # fp32 I/O, D = dim = H*C: projection GEMMs read D and write D floats, the slice pass reads D, the
 # de-slice pass reads and writes D.
 BYTES_PER_POINT = {"project": lambda D: 8 * D, "slice": lambda D: 4 * D, "deslice": lambda D: 8 * D,
-                   "to_out": lambda D: 8 * D}
-KERNEL_OF_STAGE = {"project": "gemm_ws", "slice": "slice", "deslice": "deslice", "to_out": "gemm_ws"}
+                   "to_out": lambda D: 8 * D}  # (the projection's 4*H B/point of s and the passes' reads of it: not credited)
+KERNEL_OF_STAGE = {"project": "gemm_ws_split", "slice": "slice", "deslice": "deslice", "to_out": "gemm_ws"}
 
 
 def build_module(dev):
