@@ -172,6 +172,11 @@ __device__ __forceinline__ void w_select_nth(LaneArr& a, int first, int nth, int
     w_insertion_sort(a, first, last);
 }
 
+template <int CTRL>
+__device__ __forceinline__ float w_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
 // Split dimension and sort keys of one tree level: all nodes have `sz` points (power of two,
 // lane-aligned segments).  cx,cy,cz: coordinates BY ELEMENT (lane e = element e).  Pure lane-parallel.
 __device__ __forceinline__ void w_level_keys(LaneArr& a, float cx, float cy, float cz, int nd, int sz) {
@@ -182,8 +187,27 @@ __device__ __forceinline__ void w_level_keys(LaneArr& a, float cx, float cy, flo
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         if (d < nd) {
+            // min / max over the aligned segment of sz lanes: xor-butterfly; the steps inside a row of
+            // 16 lanes are DPP moves (xor 1, xor 2, xor 7 = row_half_mirror, xor 15 = row_mirror: these
+            // masks generate the same groups as 1, 2, 4, 8), only 16 and 32 go through the LDS crossbar
             float lo = v[d], hi = v[d];
-            for (int off = 1; off < sz; off <<= 1) {
+            if (sz >= 2) {
+                lo = fminf(lo, w_dpp<0xB1>(lo));
+                hi = fmaxf(hi, w_dpp<0xB1>(hi));
+            }
+            if (sz >= 4) {
+                lo = fminf(lo, w_dpp<0x4E>(lo));
+                hi = fmaxf(hi, w_dpp<0x4E>(hi));
+            }
+            if (sz >= 8) {
+                lo = fminf(lo, w_dpp<0x141>(lo));
+                hi = fmaxf(hi, w_dpp<0x141>(hi));
+            }
+            if (sz >= 16) {
+                lo = fminf(lo, w_dpp<0x140>(lo));
+                hi = fmaxf(hi, w_dpp<0x140>(hi));
+            }
+            for (int off = 16; off < sz; off <<= 1) {
                 lo = fminf(lo, __shfl_xor(lo, off));
                 hi = fmaxf(hi, __shfl_xor(hi, off));
             }
