@@ -227,6 +227,14 @@ struct Rot3w {
 
 constexpr int TW = 8;  // waves per cloud
 
+#ifdef HAET_STAMPS
+// Diagnostic build only (tools/tree_stamps.py): s_memtime of wave 0 of cloud 0 along the build.
+__device__ unsigned long long haet_tree_stamps[32];
+#define TSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) haet_tree_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+
 // One tree level shared by the `nw` waves w0 .. w0+nw-1, which all hold the same lane arrays: the
 // nodes of a level are independent, so wave i runs the (sequential) introselect of nodes i, i+nw, ...
 // and the waves swap their results through `ex` (double-buffered by `par`: one barrier per level).
@@ -255,6 +263,7 @@ __global__ __launch_bounds__(64 * TW) void balltree_wave_kernel(
     const int cloud = blockIdx.x, n_clouds = gridDim.x;
     const int strides[3] = {s0, s1, s2};
     const int targets[4] = {t0, t1, t2, t3};
+    TSTAMP(0);
     float cx = 0.f, cy = 0.f, cz = 0.f;
     if (S) {
         // Fused haet_token_pos (IrregularMesh.py:204-209): every cloud's workgroup reduces the global
@@ -298,12 +307,20 @@ __global__ __launch_bounds__(64 * TW) void balltree_wave_kernel(
         cy = p[1];
         if (nd > 2) cz = p[2];
     }
+    TSTAMP(1);
     LaneArr a;
     a.idx = lane;
     a.key = 0;
     // main tree (balltree.h:121-186): halve until the nodes hold 2 points; all TW waves share a level
     int par = 0;
-    for (int sz = M; sz > 2; sz >>= 1, par ^= 1) w_shared_level(a, cx, cy, cz, nd, M, sz, true, wave, TW, par * 64);
+    {
+        int lv = 0;
+        for (int sz = M; sz > 2; sz >>= 1, par ^= 1) {
+            w_shared_level(a, cx, cy, cz, nd, M, sz, true, wave, TW, par * 64);
+            TSTAMP(2 + lv);
+            ++lv;
+        }
+    }
     if (wave == 0 && lane < M) {
         tree_idx[(size_t)cloud * M + lane] = cloud * M + a.idx;
         tree_mask[(size_t)cloud * M + lane] = 1;
@@ -353,15 +370,23 @@ __global__ __launch_bounds__(64 * TW) void balltree_wave_kernel(
             if (lev < n_levels - 1) nn /= strides[lev];
         }
     }
+    TSTAMP(10);
     a.idx = lane;
     int sz = n;
     for (int it = 0; it < max_splits; ++it, par ^= 1) {  // `par` carries on: never the buffer just read
         const bool work = mine && it < targets[mine ? grp : 0] && sz > 1;
         w_shared_level(a, rx, ry, rz, nd, n, sz, work, me, gsize, ((grp & 3) * 2 + par) * 64);
         if (work) sz >>= 1;
+        TSTAMP(11 + it);
     }
     if (mine && me == 0 && lane < n) rot[rot_off + (size_t)cloud * n + lane] = cloud * n + a.idx;
 }
+
+#ifdef HAET_STAMPS
+extern "C" int haet_debug_read_tree_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(haet_tree_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1;
+}
+#endif
 
 bool balltree_wave_ok(int M, int n_levels, const int* st) {
     if (M < 2 || M > 64 || (M & (M - 1))) return false;
