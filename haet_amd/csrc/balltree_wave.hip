@@ -319,6 +319,7 @@ __global__ __launch_bounds__(64 * TW) void balltree_wave_kernel(
             w_shared_level(a, cx, cy, cz, nd, M, sz, true, wave, TW, par * 64);
             TSTAMP(2 + lv);
             ++lv;
+            (void)lv;
         }
     }
     if (wave == 0 && lane < M) {
