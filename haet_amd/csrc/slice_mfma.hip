@@ -27,7 +27,12 @@
 // by (row>>2)&3: conflict-free for both the b128 row reads and the tr_b16 reads), and
 // Ada-Temp tau per (point, head) is reduced in the loader (8 lanes per head, DPP).  Loads
 // for tile t+1 are issued before computing tile t and written to the other LDS buffer
-// after it (one barrier per tile).
+// after it (one barrier per tile).  Tiles are dealt round-robin to one workgroup per CU.
+//
+// SPLIT = true (what the module runs at H = 8 / 16): the input is not fp32 but the projection
+// GEMM's fused operand format (haet_project_split_fwd, gemm_x3.hip) -- 16-B cells {4 x bf16 hi,
+// 4 x bf16 lo} at the fp32 row stride plus s[n][h] = log2(e)/tau -- and the loader only copies.
+// Both passes are bound by vector issue (exponent, exp2, the hi/lo split of P), the GEMM is not.
 #include <cstdlib>
 
 #include "common.h"

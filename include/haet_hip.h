@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HAET_ABI_VERSION 1
+#define HAET_ABI_VERSION 2  /* 2: + haet_tokens_tree_build, haet_project_split_fwd, haet_*_fwd_split */
 
 #define HAET_OK 0
 #define HAET_E_ARG (-1)      /* bad argument / unsupported shape */
