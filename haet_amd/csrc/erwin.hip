@@ -255,10 +255,14 @@ __device__ ERWIN_PHASE void linear_core_t(
         }
     };
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    auto step = [&](const Cur& c, const u32x4 (&wv)[4]) {
+    // the activation fragments are read one item ahead as well (an LDS round trip per item otherwise)
+    u32x4 xh, xl;
+    auto read_x = [&](const Cur& c) {
         const int xo = x.base + min(c.tt * 16 + l15, n - 1) * x.S + (32 * c.ks + 8 * kq) * 2;
-        const u32x4 xh = *reinterpret_cast<const u32x4*>(smem + xo);
-        const u32x4 xl = *reinterpret_cast<const u32x4*>(smem + xo + x.plane);
+        xh = *reinterpret_cast<const u32x4*>(smem + xo);
+        xl = *reinterpret_cast<const u32x4*>(smem + xo + x.plane);
+    };
+    auto step = [&](const Cur& c, const u32x4 (&wv)[4], const u32x4 xh, const u32x4 xl) {
         LSTAMP(42);
         // W is the A operand, X the B operand: the accumulator is Y^T -- lane = token column, registers =
         // four CONSECUTIVE outputs -- so every epilogue moves 16 B (fp32 rows) or 8 B (bf16 image rows)
@@ -347,20 +351,29 @@ __device__ ERWIN_PHASE void linear_core_t(
     if (!pre) fetch(cf, w1);
     advance(cf);
     LSTAMP(41);
+    read_x(cc);
     for (int it = 0; it < items; it += 2) {  // two named register sets, statically indexed
         {
             u32x4 c0[4] = {w0[0], w0[1], w0[2], w0[3]};
+            const u32x4 ah = xh, al = xl;
             fetch(cf, w0);
             advance(cf);
-            step(cc, c0);
-            advance(cc);
+            Cur cn = cc;
+            advance(cn);
+            read_x(cn);  // (a ghost item past the end reads a clamped, valid row)
+            step(cc, c0, ah, al);
+            cc = cn;
         }
         {
             u32x4 c1[4] = {w1[0], w1[1], w1[2], w1[3]};
+            const u32x4 ah = xh, al = xl;
             fetch(cf, w1);
             advance(cf);
-            step(cc, c1);
-            advance(cc);
+            Cur cn = cc;
+            advance(cn);
+            read_x(cn);
+            step(cc, c1, ah, al);
+            cc = cn;
         }
     }
     LSTAMP(44);
