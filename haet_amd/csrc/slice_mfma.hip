@@ -108,7 +108,7 @@ __device__ __forceinline__ float dpp(float v) {
 // LI = 16-B chunks per thread per tile (32 rows x H*8 chunks / NT threads): ceil(H/2) at 512 threads.
 // Everything that does not change from tile to tile is computed once in init(): the row / head of
 // each chunk, its LDS offsets, its global pointer (advanced by one tile per fetch).
-template <int LI, int NT = NTHR, bool SPLIT = false>
+template <int LI, int NT = NTHR, bool SPLIT = false, bool PRIV = false>
 struct Loader {
     f32x4 xr[LI];
     float wt4[4];
@@ -128,6 +128,29 @@ struct Loader {
     __device__ __forceinline__ void init(const float* __restrict__ wt, const float* xb, int H, int row0,
                                          const float* sb = nullptr) {
         q8 = threadIdx.x & 7;
+        if (PRIV) {
+            // Wave-private loading (one head per wave): wave w copies ONLY head w's 32 x 32 block of the
+            // tile (4 chunks per lane) and its 32 s values into head w's LDS images, which no other
+            // wave reads -- the tile loop then needs no workgroup barrier and the waves drift apart.
+            const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, cprp = H * 8;
+            tile_stride = (size_t)TN * cprp * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wt4[i] = 0.f;
+#pragma unroll
+            for (int i = 0; i < LI; ++i) {
+                const int e = lane + 64 * i, r = e >> 3, q = e & 7;
+                row[i] = r;
+                src[i] = xb + ((size_t)(row0 + r) * cprp + h * 8 + q) * 4;
+                loff[i] = h * (2 * IMG) + img_off(r, q >> 1) + ((q & 1) << 3);
+                soff[i] = 0;
+            }
+            srow = lane;  // lanes >= 32: no s value
+            sptr = sb + (size_t)(row0 + (lane & (TN - 1))) * H + h;
+            s_stride = (size_t)TN * H;
+            soff2 = 4 * (h * TN + (lane & (TN - 1)));
+            sv = 1.f;
+            return;
+        }
         if (SPLIT) {
             srow = (int)threadIdx.x / H;  // >= TN: no s value on this thread
             sptr = sb + (size_t)row0 * H + threadIdx.x;
@@ -259,7 +282,7 @@ __device__ __forceinline__ void stage_ws(int wimg, const float* __restrict__ Ws,
 // instead of overlapping (two waves per SIMD at ~230 VGPRs).  Tried without gain: 16 waves with
 // one item each (128 VGPRs only with spills; 25 % slower), running the two waves of a SIMD in
 // opposite stage/compute order.
-template <int LI, int IPW, int MB, int NWV = NW, bool SPLIT = false>
+template <int LI, int IPW, int MB, int NWV = NW, bool SPLIT = false, bool PRIV = false>
 __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ Ws, const float* __restrict__ bs,
     const float* __restrict__ wt, float bt, float base_temp, float c0, int N, int H,
@@ -281,7 +304,8 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
     const int wimg = sarr0 + 2 * sarr_bytes + NWV * 32 * 4;  // [MB][hi|lo] images of Ws
     const float* xb = x + (size_t)b * N * H * kC;
 
-    Loader<LI, NWV * 64, SPLIT> ld;
+    static_assert(!PRIV || (SPLIT && LI == 4), "wave-private loading: split input, H = 8 (one head per wave)");
+    Loader<LI, NWV * 64, SPLIT, PRIV> ld;
     ld.init(wt, xb, H, t_begin * TN, SPLIT ? s_in + (size_t)b * N * H : nullptr);
     ld.tile_stride *= G;
     if (SPLIT) ld.s_stride *= G;
@@ -415,7 +439,7 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
             }
         }
         if (more) ld.stage((cur ^ 1) * buf_bytes, sarr0 + (cur ^ 1) * sarr_bytes, bt, base_temp);
-        __syncthreads();
+        if (!PRIV) __syncthreads();  // (PRIV: every wave reads only what it wrote itself)
         cur ^= 1;
     }
 
@@ -613,9 +637,20 @@ static int set_lds(K kernel, size_t bytes) {
                            c0, N, H, p.tiles_per_chunk, parts, s_in);                                \
         return check_launch("slice_mfma_kernel");                                                    \
     }
+#define SLICE_LAUNCH_P(LI_, IPW_, MB_, NW_)                                                        \
+    {                                                                                                 \
+        auto kern = slice_mfma_kernel<LI_, IPW_, MB_, NW_, true, true>;                               \
+        if (int rc = set_lds(kern, p.lds_slice)) return rc;                                          \
+        hipLaunchKernelGGL(kern, grid, dim3(NW_ * 64), p.lds_slice, st, x, Ws, bs, wt, bt, base_temp, \
+                           c0, N, H, p.tiles_per_chunk, parts, s_in);                                \
+        return check_launch("slice_mfma_kernel");                                                    \
+    }
 #define SLICE_CASE(LI_, IPW_, MB_, NW_)                                                            \
     if (p.s_li == LI_ && p.ipw == IPW_ && p.mb == MB_ && p.s_nw == NW_) {                            \
         if (s_in) {                                                                                   \
+            if constexpr (LI_ == 4 && NW_ == 8) {                                                     \
+                if (!shared_load) SLICE_LAUNCH_P(LI_, IPW_, MB_, NW_)                                 \
+            }                                                                                         \
             if constexpr (LI_ >= 4) SLICE_LAUNCH(LI_, IPW_, MB_, NW_, true)                           \
             return fail(HAET_E_ARG, "slice_mfma: split input needs H = 8 or 16");                     \
         }                                                                                             \
@@ -628,6 +663,7 @@ int slice_mfma_fwd(const float* x, const float* Ws, const float* bs, const float
     MfmaPlan p;
     if (!mfma_plan(B, N, H, C, M, &p)) return fail(HAET_E_ARG, "slice_mfma: unsupported shape");
     dim3 grid(p.parts, B);
+    static const bool shared_load = getenv("HAET_SLICE_SHARED_LOAD") != nullptr;  // A/B: cooperative loader
     SLICE_CASE(4, 2, 2, 8)   // H=8,  M=64  (C3/C4)
     SLICE_CASE(4, 1, 1, 8)   // H=8,  M=32
     SLICE_CASE(4, 4, 4, 8)   // H=8,  M=128 (C5)
