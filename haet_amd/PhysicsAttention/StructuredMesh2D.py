@@ -1,6 +1,7 @@
 """Physics_Attention_Structured_Mesh_2D -- drop-in for models/PhysicsAttention/
 StructuredMesh2D.py (constructor :44-69, forward :157-262).  The 3x3 Conv2d projection is
-MIOpen via PyTorch-ROCm; everything after it is the shared HIP path."""
+an implicit GEMM on the matrix cores (haet_conv_project_fwd; MIOpen only for channel counts it does not
+take); everything after it is the shared HIP path."""
 import torch.nn as nn
 
 from ._base import PhysicsAttentionBase
@@ -22,5 +23,8 @@ class Physics_Attention_Structured_Mesh_2D(PhysicsAttentionBase):
 
     def project(self, x):
         B, N, D = x.shape
+        y = self._conv_project(x, (self.H, self.W))  # HIP implicit GEMM, channels-last
+        if y is not None:
+            return y
         g = x.reshape(B, self.H, self.W, D).permute(0, 3, 1, 2).contiguous()
         return self.in_project_x(g).permute(0, 2, 3, 1).reshape(B, N, -1)

@@ -1,6 +1,7 @@
 """Physics_Attention_Structured_Mesh_3D -- drop-in for models/PhysicsAttention/
 StructuredMesh3D.py (constructor :45-71, forward :161-266).  The 3x3x3 Conv3d projection is
-MIOpen via PyTorch-ROCm; everything after it is the shared HIP path."""
+an implicit GEMM on the matrix cores (haet_conv_project_fwd; MIOpen only for channel counts it does not
+take); everything after it is the shared HIP path."""
 import torch.nn as nn
 
 from ._base import PhysicsAttentionBase
@@ -22,5 +23,8 @@ class Physics_Attention_Structured_Mesh_3D(PhysicsAttentionBase):
 
     def project(self, x):
         B, N, Dm = x.shape
+        y = self._conv_project(x, (self.H, self.W, self.D))  # HIP implicit GEMM, channels-last
+        if y is not None:
+            return y
         g = x.reshape(B, self.H, self.W, self.D, Dm).permute(0, 4, 1, 2, 3).contiguous()
         return self.in_project_x(g).permute(0, 2, 3, 4, 1).reshape(B, N, -1)

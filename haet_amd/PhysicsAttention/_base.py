@@ -104,6 +104,23 @@ class PhysicsAttentionBase(nn.Module):
         when this variant / shape has no such path (then `project` + the fp32 passes run)."""
         return None
 
+    def _conv_project(self, x: torch.Tensor, grid):
+        """Conv2d / Conv3d in_project_x as the HIP implicit GEMM over the channels-last points, or None
+        when the channel counts are outside its envelope (the caller then runs the MIOpen conv)."""
+        conv = self.in_project_x
+        if os.environ.get("HAET_NO_HIP_CONV") or x.dtype != torch.float32:
+            return None
+        if (not ops.conv_project_supported(conv.in_channels, conv.out_channels) or conv.bias is None
+                or any(s != 1 for s in conv.stride) or any(d != 1 for d in conv.dilation) or conv.groups != 1
+                or any(k % 2 == 0 or p != k // 2 for k, p in zip(conv.kernel_size, conv.padding))
+                or conv.padding_mode != "zeros"):
+            return None
+        cache = self.__dict__.setdefault("_split_cache", {})
+        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias.data_ptr(), conv.bias._version)
+        if "in_project_x" not in cache or cache["in_project_x"][0] != key:
+            cache["in_project_x"] = (key, ops.SplitConv(conv.weight, conv.bias))
+        return ops.conv_project(x, cache["in_project_x"][1], grid)
+
     def _project_split_linear(self, name: str, lin: nn.Linear, x: torch.Tensor, sp):
         B, N, _ = x.shape
         H, C, G = self.heads, self.dim_head, self.slice_num

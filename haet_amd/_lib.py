@@ -66,6 +66,9 @@ SIGNATURES = {
     "haet_slice_fwd_split": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "haet_deslice_fwd_split": (c_int, [_P, _P, _P, _P, c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
                                        _P, _P]),
+    "haet_conv_project_supported": (c_int, [c_int, c_int]),
+    "haet_conv_project_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      _P, _P]),
     "haet_erwin_lds_bytes": (c_size_t, [POINTER(ErwinDesc), c_int]),
     "haet_erwin_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, POINTER(ErwinDesc), c_int, c_int, _P, _P]),
     "haet_deslice_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P]

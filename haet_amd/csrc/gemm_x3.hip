@@ -82,11 +82,18 @@ __device__ __forceinline__ GFrag g_read(int img, int row, int chunk) {
 // (row tile, k-tile) items.  The x loads of item i+3 and the W loads of item i+2 are issued into
 // named register sets while item i is multiplied, so ~48 KB of x per CU are always in flight
 // (HBM latency x per-CU bandwidth ~ 40-50 KB) and the stream never drains at a row-tile boundary.
-template <int NCB, int RB>  // RB = 32-row blocks per wave: workgroup tile = 64*RB rows x 32*NCB columns
+// CONV: the same GEMM as an implicit-GEMM convolution over a channels-last grid (the Conv2d / Conv3d
+// in_project_x of the structured-mesh modules, StructuredMesh2D.py:173-189, StructuredMesh3D.py:177-193):
+// row n of A for k-tile (tap, channel block) is the row of the neighbour n + tap offset, or zeros
+// outside the grid; W is [O][taps][C_in], K = taps * C_in.  x stays [B, N, C_in]: no NCHW round trip.
+struct ConvGeom {
+    int Cin, Npts, gH, gW, gD, kH, kW, kD;
+};
+template <int NCB, int RB, bool CONV = false>  // RB = 32-row blocks per wave: workgroup tile = 64*RB rows x 32*NCB columns
 __global__ __launch_bounds__(512) void gemm_x3_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ Whi,
     const unsigned short* __restrict__ Wlo, const float* __restrict__ bias, int Nrows, int K, int O,
-    int n_row_tiles, float* __restrict__ out) {
+    int n_row_tiles, float* __restrict__ out, ConvGeom cg) {
     constexpr int BN = 32 * NCB;
     constexpr int WCB = NCB / 4;  // column blocks per wave (4 waves across the columns)
     constexpr int WPT = NCB / 4;  // 16-B W chunks per thread per plane and k-tile
@@ -131,14 +138,42 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     const int krot = blockIdx.x % nkt;
     int fx_tile = blockIdx.x, fx_kt = 0, fx_it = 0;
     int fw_kt = 0, fw_it = 0;
+    int cgi[XPT], cgj[XPT], cgk[XPT], cg_tile = -1;  // CONV: grid coordinates of this thread's rows
     auto fetch_x = [&](f32x4 (&d)[XPT]) {
         if (fx_it < total) {
             int kk = fx_kt + krot;
             kk = (kk >= nkt ? kk - nkt : kk) * GBK;
+            if (!CONV) {
 #pragma unroll
-            for (int i = 0; i < XPT; ++i) {
-                const int r = min(fx_tile * BM + xrow0 + 64 * i, Nrows - 1);
-                d[i] = *reinterpret_cast<const f32x4*>(x + (size_t)r * K + kk + 4 * xq);
+                for (int i = 0; i < XPT; ++i) {
+                    const int r = min(fx_tile * BM + xrow0 + 64 * i, Nrows - 1);
+                    d[i] = *reinterpret_cast<const f32x4*>(x + (size_t)r * K + kk + 4 * xq);
+                }
+            } else {
+                if (cg_tile != fx_tile) {  // once per row tile
+                    cg_tile = fx_tile;
+#pragma unroll
+                    for (int i = 0; i < XPT; ++i) {
+                        const int r = min(fx_tile * BM + xrow0 + 64 * i, Nrows - 1);
+                        const int p = r % cg.Npts, ij = p / cg.gD;
+                        cgk[i] = p - ij * cg.gD;
+                        cgi[i] = ij / cg.gW;
+                        cgj[i] = ij - cgi[i] * cg.gW;
+                    }
+                }
+                const int tap = kk / cg.Cin, c0 = kk - tap * cg.Cin;  // wave-uniform
+                const int a = tap / (cg.kW * cg.kD), bc = tap - a * (cg.kW * cg.kD), b = bc / cg.kD, c = bc - b * cg.kD;
+                const int da = a - cg.kH / 2, db = b - cg.kW / 2, dc = c - cg.kD / 2;
+                const int shift = (da * cg.gW + db) * cg.gD + dc;
+#pragma unroll
+                for (int i = 0; i < XPT; ++i) {
+                    const int r = min(fx_tile * BM + xrow0 + 64 * i, Nrows - 1);
+                    const bool ok = (unsigned)(cgi[i] + da) < (unsigned)cg.gH && (unsigned)(cgj[i] + db) < (unsigned)cg.gW &&
+                                    (unsigned)(cgk[i] + dc) < (unsigned)cg.gD;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)(ok ? r + shift : r) * cg.Cin + c0 + 4 * xq);
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    d[i] = ok ? v : z;  // zero padding; the load itself is unconditional
+                }
             }
         }
         ++fx_it;
@@ -590,7 +625,7 @@ extern "C" int haet_linear_fwd(const float* x, const uint16_t* W_hi, const uint1
             if (e != hipSuccess) return fail(HAET_E_LAUNCH, "linear_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
         hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi, W_lo, bias, Nrows,
-                           K, O, tiles, out);
+                           K, O, tiles, out, ConvGeom{});
         return HAET_OK;
     };
     int rc;
@@ -625,4 +660,42 @@ extern "C" int haet_project_split_fwd(const float* x, const uint16_t* W_hi, cons
     if (K == 256) go(gemm_ws_kernel<8, 4, true>);
     else go(gemm_ws_kernel<4, 4, true>);
     return check_launch("gemm_ws_kernel<split>");
+}
+
+// Conv2d / Conv3d projection (kernel k, stride 1, padding k/2) over a channels-last grid, as an
+// implicit GEMM on the matrix cores.  W_hi / W_lo: split planes of the weight re-laid as
+// [O][taps][C_in] (tap order = the reference's kernel index order kH, kW, kD; 2-D: gD = kD = 1).
+extern "C" int haet_conv_project_supported(int Cin, int O) {
+    return (Cin >= 32 && Cin % 32 == 0 && O >= 128 && O % 128 == 0) ? 1 : 0;
+}
+
+extern "C" int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo,
+                                     const float* bias, int B, int gH, int gW, int gD, int Cin, int O,
+                                     int kH, int kW, int kD, float* out, haet_stream_t stream) {
+    if (!x || !W_hi || !W_lo || !out) return fail(HAET_E_ARG, "conv_project_fwd: null pointer");
+    if (!haet_conv_project_supported(Cin, O))
+        return fail(HAET_E_ARG, "conv_project_fwd: C_in=%d (multiple of 32) / O=%d (multiple of 128) unsupported", Cin, O);
+    if (B < 1 || gH < 1 || gW < 1 || gD < 1 || kH < 1 || kW < 1 || kD < 1 || !(kH & kW & kD & 1))
+        return fail(HAET_E_ARG, "conv_project_fwd: bad grid / kernel (odd kernel sizes only)");
+    const long long rows = (long long)B * gH * gW * gD;
+    if (rows > 0x7fffffffLL) return fail(HAET_E_ARG, "conv_project_fwd: too many points");
+    const int Nrows = (int)rows, K = kH * kW * kD * Cin;
+    const bool big = Nrows >= 256 * 256 && O % 256 == 0;
+    const int BM = big ? 256 : 128;
+    const int tiles = (Nrows + BM - 1) / BM;
+    const int NCBv = (O % 256 == 0) ? 8 : 4;
+    const int ny = O / (32 * NCBv);
+    const int gx = tiles < 256 / ny ? tiles : (256 / ny > 0 ? 256 / ny : 1);
+    const size_t lds = (size_t)2 * (BM / 32 + NCBv) * 2 * GIMG;
+    const ConvGeom cg{Cin, gH * gW * gD, gH, gW, gD, kH, kW, kD};
+    auto launch = [&](auto kern) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi, W_lo, bias, Nrows, K, O,
+                           tiles, out, cg);
+    };
+    if (big) launch(gemm_x3_kernel<8, 4, true>);
+    else if (NCBv == 8) launch(gemm_x3_kernel<8, 2, true>);
+    else launch(gemm_x3_kernel<4, 2, true>);
+    return check_launch("gemm_x3_kernel<conv>");
 }

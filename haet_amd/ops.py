@@ -254,3 +254,37 @@ def deslice_split(xs: SplitPoints, p: SliceParams, col_max: Tensor, col_sum: Ten
                                      _p(_f32(S2, "S2")), B, N, xs.H, xs.C, M, _p(out), _stream()),
           "haet_deslice_fwd_split")
     return out
+
+
+# --------------------------------------------------------------------------- structured projection
+class SplitConv:
+    """A Conv2d / Conv3d weight [O, C_in, k, k(, k)] as split planes laid out [O][taps][C_in]
+    (the implicit GEMM's W, haet_conv_project_fwd)."""
+
+    def __init__(self, weight: Tensor, bias: Optional[Tensor]):
+        w = weight.detach()
+        self.kernel = tuple(w.shape[2:]) + (1,) * (5 - w.dim())      # (kH, kW, kD)
+        self.Cin, self.O = w.shape[1], w.shape[0]
+        perm = (0,) + tuple(range(2, w.dim())) + (1,)                 # O, taps..., C_in
+        flat = w.permute(*perm).reshape(self.O, -1).contiguous()
+        self.lin = SplitLinear(flat, bias)
+
+
+def conv_project_supported(Cin: int, O: int) -> bool:
+    return bool(_lib.load().haet_conv_project_supported(int(Cin), int(O)))
+
+
+def conv_project(x: Tensor, w: SplitConv, grid: Tuple[int, ...]) -> Tensor:
+    """x [B, N, C_in] channels-last over grid (H, W[, D]) -> [B, N, O]; same-padded convolution."""
+    lib = _lib.load()
+    x = _f32(x, "x")
+    B, N, Cin = x.shape
+    gH, gW = grid[0], grid[1]
+    gD = grid[2] if len(grid) > 2 else 1
+    if gH * gW * gD != N or Cin != w.Cin:
+        raise HaetError("conv_project: x does not match the grid / weight")
+    out = torch.empty((B, N, w.O), dtype=torch.float32, device=x.device)
+    kH, kW, kD = w.kernel
+    check(lib.haet_conv_project_fwd(_p(x), _p(w.lin.hi), _p(w.lin.lo), _p(w.lin.bias), B, gH, gW, gD, Cin, w.O,
+                                    kH, kW, kD, _p(out), _stream()), "haet_conv_project_fwd")
+    return out

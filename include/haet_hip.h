@@ -225,6 +225,16 @@ int haet_deslice_fwd_split(const void* x_split, const float* s, const float* Ws,
                            float c0, const float* col_max, const float* col_sum, const float* S2,
                            int B, int N, int H, int C, int M, float* out_x, haet_stream_t stream);
 
+/* ------------------------------------------------------------------ structured-mesh projection
+ * in_project_x of the structured modules (nn.Conv2d / nn.Conv3d, kernel k, padding k/2:
+ * StructuredMesh2D.py:109,173-189, StructuredMesh3D.py:113,177-193) as an implicit GEMM on the
+ * matrix cores over the channels-last grid x [B, gH*gW*gD, C_in] -> out [B, gH*gW*gD, O]
+ * (2-D: gD = kD = 1).  W_hi / W_lo: haet_split_bf16 of the weight re-laid as [O][kH*kW*kD][C_in]. */
+int haet_conv_project_supported(int Cin, int O);
+int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
+                          int B, int gH, int gW, int gD, int Cin, int O, int kH, int kW, int kD,
+                          float* out, haet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
