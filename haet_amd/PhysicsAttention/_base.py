@@ -108,18 +108,44 @@ class PhysicsAttentionBase(nn.Module):
         """Conv2d / Conv3d in_project_x as the HIP implicit GEMM over the channels-last points, or None
         when the channel counts are outside its envelope (the caller then runs the MIOpen conv)."""
         conv = self.in_project_x
-        if os.environ.get("HAET_NO_HIP_CONV") or x.dtype != torch.float32:
-            return None
-        if (not ops.conv_project_supported(conv.in_channels, conv.out_channels) or conv.bias is None
+        ok = not (os.environ.get("HAET_NO_HIP_CONV") or x.dtype != torch.float32)
+        if ok and (not ops.conv_project_supported(conv.in_channels, conv.out_channels) or conv.bias is None
                 or any(s != 1 for s in conv.stride) or any(d != 1 for d in conv.dilation) or conv.groups != 1
                 or any(k % 2 == 0 or p != k // 2 for k, p in zip(conv.kernel_size, conv.padding))
                 or conv.padding_mode != "zeros"):
+            ok = False
+        if not ok:
+            if self.shard_group is not None:
+                raise HaetError("point-sharded structured meshes need the HIP convolution (fp32 input, C_in % 32 = 0, "
+                                "heads * dim_head % 128 = 0, odd kernel with padding k // 2)")
             return None
         cache = self.__dict__.setdefault("_split_cache", {})
         key = (conv.weight.data_ptr(), conv.weight._version, conv.bias.data_ptr(), conv.bias._version)
         if "in_project_x" not in cache or cache["in_project_x"][0] != key:
             cache["in_project_x"] = (key, ops.SplitConv(conv.weight, conv.bias))
-        return ops.conv_project(x, cache["in_project_x"][1], grid)
+        w = cache["in_project_x"][1]
+        if self.shard_group is None:
+            return ops.conv_project(x, w, grid)
+        # Slab sharding along the first grid axis: this rank holds whole planes; the convolution needs
+        # one plane of halo per side per kernel radius (kernel 3: one plane), fetched from the
+        # neighbour ranks; the global faces keep the zero padding.
+        from ..sharding import exchange_halo_planes
+
+        plane = 1
+        for g in grid[1:]:
+            plane *= g
+        B, n, _ = x.shape
+        if n % plane:
+            raise HaetError("structured sharding: a rank must hold whole planes of the grid's first axis")
+        rad = conv.kernel_size[0] // 2
+        if rad > 1 or n // plane < rad:
+            raise HaetError("structured sharding supports kernel 3 (one halo plane) and >= 1 plane per rank")
+        prev, nxt = exchange_halo_planes(x, plane, self.shard_group) if rad else (None, None)
+        parts = [t for t in (prev, x, nxt) if t is not None]
+        x_ext = torch.cat(parts, dim=1) if len(parts) > 1 else x
+        y = ops.conv_project(x_ext, w, (x_ext.shape[1] // plane,) + tuple(grid[1:]))
+        lo = plane if prev is not None else 0
+        return y[:, lo:lo + n].contiguous()
 
     def _project_split_linear(self, name: str, lin: nn.Linear, x: torch.Tensor, sp):
         B, N, _ = x.shape

@@ -42,3 +42,32 @@ def shard_bounds(n_points: int, rank: int, world: int):
     base, extra = divmod(n_points, world)
     start = rank * base + min(rank, extra)
     return start, start + base + (1 if rank < extra else 0)
+
+
+def exchange_halo_planes(x: torch.Tensor, plane: int, group=None):
+    """Slab sharding of a structured grid along its first axis: x [B, n_planes*plane, C]
+    is this rank's slab; returns (prev, next) = the neighbour ranks' boundary planes [B, plane, C]
+    (None at the global faces, where the convolution's zero padding applies).  One point-to-point
+    exchange per side -- ncclSend/Recv over xGMI on the GPU node."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    B, n, C = x.shape
+    first, last = x[:, :plane].contiguous(), x[:, n - plane:].contiguous()
+    via_host = x.is_cuda and dist.get_backend(group) == "gloo"  # test configuration (see allgather_records)
+    buf = (lambda: torch.empty((B, plane, C), dtype=x.dtype, device="cpu" if via_host else x.device))
+    prev = buf() if rank > 0 else None
+    nxt = buf() if rank < world - 1 else None
+    ops = []
+    peer = (lambda r: dist.get_global_rank(group, r) if group is not None else r)
+    if rank > 0:
+        ops += [dist.P2POp(dist.isend, first.cpu() if via_host else first, peer(rank - 1), group),
+                dist.P2POp(dist.irecv, prev, peer(rank - 1), group)]
+    if rank < world - 1:
+        ops += [dist.P2POp(dist.isend, last.cpu() if via_host else last, peer(rank + 1), group),
+                dist.P2POp(dist.irecv, nxt, peer(rank + 1), group)]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if via_host:
+        prev = None if prev is None else prev.to(x.device)
+        nxt = None if nxt is None else nxt.to(x.device)
+    return prev, nxt

@@ -79,3 +79,35 @@ def test_shard_bounds_cover_every_point_once():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def _halo_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from haet_amd.sharding import exchange_halo_planes, shard_bounds
+
+    torch.manual_seed(0)
+    B, gH, plane, C = 2, 7, 6, 5                    # 7 planes of 6 points over 3 ranks: 3 + 2 + 2
+    full = torch.randn(B, gH * plane, C)
+    a, b = shard_bounds(gH, rank, world)
+    prev, nxt = exchange_halo_planes(full[:, a * plane:b * plane].contiguous(), plane, None)
+    ok = True
+    ok &= (prev is None) == (rank == 0) and (nxt is None) == (rank == world - 1)
+    if prev is not None:
+        ok &= torch.equal(prev, full[:, (a - 1) * plane:a * plane])
+    if nxt is not None:
+        ok &= torch.equal(nxt, full[:, b * plane:(b + 1) * plane])
+    torch.save({"ok": bool(ok)}, os.path.join(tmp, f"h{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_halo_plane_exchange_three_ranks(tmp_path):
+    """Slab sharding of the structured grids: every rank receives its neighbours' boundary planes and
+    nothing at the global faces (the exchange the Conv2d / Conv3d projection needs)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_halo_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    for r in range(3):
+        assert torch.load(os.path.join(tmp_path, f"h{r}.pt"))["ok"]
