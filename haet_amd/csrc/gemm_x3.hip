@@ -85,7 +85,7 @@ __device__ __forceinline__ GFrag g_read(int img, int row, int chunk) {
 // CONV: the same GEMM as an implicit-GEMM convolution over a channels-last grid (the Conv2d / Conv3d
 // in_project_x of the structured-mesh modules, StructuredMesh2D.py:173-189, StructuredMesh3D.py:177-193):
 // row n of A for k-tile (tap, channel block) is the row of the neighbour n + tap offset, or zeros
-// outside the grid; W is [O][taps][C_in], K = taps * C_in.  x stays [B, N, C_in]: no NCHW round trip.
+// outside the grid; W is [O][C_in / 32][taps][32], K = taps * C_in.  x stays [B, N, C_in]: no NCHW round trip.
 struct ConvGeom {
     int Cin, Npts, gH, gW, gD, kH, kW, kD;
 };
@@ -161,7 +161,11 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
                         cgj[i] = ij - cgi[i] * cg.gW;
                     }
                 }
-                const int tap = kk / cg.Cin, c0 = kk - tap * cg.Cin;  // wave-uniform
+                // K is ordered [channel block][tap][32 channels]: the taps of one 128-B channel block follow each
+                // other, so rows shifted by one point re-read lines that are still in L1 / L2 (tap-major order
+                // re-fetched every tap's rows from the memory side: 27x read amplification in 3-D)
+                const int taps = cg.kH * cg.kW * cg.kD, kt32 = kk / GBK;
+                const int cb = kt32 / taps, tap = kt32 - cb * taps, c0 = cb * GBK;  // wave-uniform
                 const int a = tap / (cg.kW * cg.kD), bc = tap - a * (cg.kW * cg.kD), b = bc / cg.kD, c = bc - b * cg.kD;
                 const int da = a - cg.kH / 2, db = b - cg.kW / 2, dc = c - cg.kD / 2;
                 const int shift = (da * cg.gW + db) * cg.gD + dc;
@@ -664,7 +668,7 @@ extern "C" int haet_project_split_fwd(const float* x, const uint16_t* W_hi, cons
 
 // Conv2d / Conv3d projection (kernel k, stride 1, padding k/2) over a channels-last grid, as an
 // implicit GEMM on the matrix cores.  W_hi / W_lo: split planes of the weight re-laid as
-// [O][taps][C_in] (tap order = the reference's kernel index order kH, kW, kD; 2-D: gD = kD = 1).
+// [O][C_in / 32][taps][32] (tap order = the reference's kernel index order kH, kW, kD; 2-D: gD = kD = 1).
 extern "C" int haet_conv_project_supported(int Cin, int O) {
     return (Cin >= 32 && Cin % 32 == 0 && O >= 128 && O % 128 == 0) ? 1 : 0;
 }
@@ -680,7 +684,9 @@ extern "C" int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const
     const long long rows = (long long)B * gH * gW * gD;
     if (rows > 0x7fffffffLL) return fail(HAET_E_ARG, "conv_project_fwd: too many points");
     const int Nrows = (int)rows, K = kH * kW * kD * Cin;
-    const bool big = Nrows >= 256 * 256 && O % 256 == 0;
+    // 128-row tiles always: with K = taps * C_in in the thousands the kernel is compute-bound and the
+    // 256-row variant (one W register set, two x sets: 256 VGPRs) pipelines worse -- 19.5 vs 11.9 ms at 96^3
+    const bool big = false;
     const int BM = big ? 256 : 128;
     const int tiles = (Nrows + BM - 1) / BM;
     const int NCBv = (O % 256 == 0) ? 8 : 4;

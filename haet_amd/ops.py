@@ -258,15 +258,18 @@ def deslice_split(xs: SplitPoints, p: SliceParams, col_max: Tensor, col_sum: Ten
 
 # --------------------------------------------------------------------------- structured projection
 class SplitConv:
-    """A Conv2d / Conv3d weight [O, C_in, k, k(, k)] as split planes laid out [O][taps][C_in]
+    """A Conv2d / Conv3d weight [O, C_in, k, k(, k)] as split planes laid out [O][C_in/32][taps][32]
     (the implicit GEMM's W, haet_conv_project_fwd)."""
 
     def __init__(self, weight: Tensor, bias: Optional[Tensor]):
         w = weight.detach()
         self.kernel = tuple(w.shape[2:]) + (1,) * (5 - w.dim())      # (kH, kW, kD)
         self.Cin, self.O = w.shape[1], w.shape[0]
-        perm = (0,) + tuple(range(2, w.dim())) + (1,)                 # O, taps..., C_in
-        flat = w.permute(*perm).reshape(self.O, -1).contiguous()
+        taps = 1
+        for k in w.shape[2:]:
+            taps *= k
+        # [O, C_in, taps] -> [O, C_in/32, 32, taps] -> [O, C_in/32, taps, 32]: channel block, tap, channel
+        flat = (w.reshape(self.O, self.Cin // 32, 32, taps).permute(0, 1, 3, 2).reshape(self.O, -1).contiguous())
         self.lin = SplitLinear(flat, bias)
 
 

@@ -229,7 +229,8 @@ int haet_deslice_fwd_split(const void* x_split, const float* s, const float* Ws,
  * in_project_x of the structured modules (nn.Conv2d / nn.Conv3d, kernel k, padding k/2:
  * StructuredMesh2D.py:109,173-189, StructuredMesh3D.py:113,177-193) as an implicit GEMM on the
  * matrix cores over the channels-last grid x [B, gH*gW*gD, C_in] -> out [B, gH*gW*gD, O]
- * (2-D: gD = kD = 1).  W_hi / W_lo: haet_split_bf16 of the weight re-laid as [O][kH*kW*kD][C_in]. */
+ * (2-D: gD = kD = 1).  W_hi / W_lo: haet_split_bf16 of the weight re-laid as
+ * [O][C_in/32][kH*kW*kD][32] (channel block, then tap, then the block's 32 channels).              */
 int haet_conv_project_supported(int Cin, int O);
 int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
                           int B, int gH, int gW, int gD, int Cin, int O, int kH, int kW, int kD,
