@@ -22,5 +22,8 @@ class Physics_Attention_Irregular_Mesh(PhysicsAttentionBase):
         # [B, N, H*C]; no [B,H,N,C] transpose is ever made
         return self._linear("in_project_x", self.in_project_x, x)
 
+    def project_torch(self, x):
+        return self.in_project_x(x)
+
     def project_split(self, x, sp):
         return self._project_split_linear("in_project_x", self.in_project_x, x, sp)

@@ -21,6 +21,11 @@ class Physics_Attention_Structured_Mesh_3D(PhysicsAttentionBase):
                           ball_sizes, enc_num_heads, enc_depths, dec_num_heads, dec_depths, strides,
                           rotate, decode, mlp_ratio, mp_steps, embed)
 
+    def project_torch(self, x):
+        B, N, Dm = x.shape
+        g = x.reshape(B, self.H, self.W, self.D, Dm).permute(0, 4, 1, 2, 3).contiguous()
+        return self.in_project_x(g).permute(0, 2, 3, 4, 1).reshape(B, N, -1)
+
     def project(self, x):
         B, N, Dm = x.shape
         y = self._conv_project(x, (self.H, self.W, self.D))  # HIP implicit GEMM, channels-last

@@ -203,13 +203,30 @@ class PhysicsAttentionBase(nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     def forward(self, x: torch.Tensor, return_intermediates: bool = False):
-        if torch.is_grad_enabled() and (x.requires_grad or self._any_requires_grad()):
-            raise NotImplementedError(
-                "the HIP PhysicsAttention path is forward-only so far (backward is the next scope "
-                "row, SURVEY.md 8f-1): wrap the call in torch.no_grad()")
         if not x.is_cuda:
             raise HaetError("Physics_Attention_* (haet_amd) runs on a ROCm device only; move the module "
                             "and its input with .cuda() -- there is no CPU fallback")
+        wants_grad = torch.is_grad_enabled() and (x.requires_grad or self._any_requires_grad())
+        if self.training or wants_grad:
+            # The HIP kernels are forward-only (the hand-written backward is the next scope row, SURVEY.md
+            # 8f-1).  Until then: train mode runs the device-side torch restatement (BatchNorm batch
+            # statistics, dropout), eval mode with gradients runs the HIP forward and back-propagates
+            # through the restatement -- haet_amd/_autograd.py.
+            from .. import _autograd
+
+            if self.shard_group is not None or return_intermediates:
+                raise NotImplementedError("training / gradients are not available on the point-sharded path "
+                                          "or together with return_intermediates yet")
+            if self.training:
+                return _autograd.attention_forward(self, x)
+            return _autograd.HipForwardTorchBackward.apply(self, x, *self.parameters())
+        return self._forward_hip(x, return_intermediates)
+
+    def project_torch(self, x: torch.Tensor) -> torch.Tensor:
+        """The projection as stock torch ops (differentiable path, haet_amd/_autograd.py)."""
+        raise NotImplementedError
+
+    def _forward_hip(self, x: torch.Tensor, return_intermediates: bool = False):
         B, N, _ = x.shape
         H, C, G = self.heads, self.dim_head, self.slice_num
         self.__dict__["_event_chain"] = [None] if self.stage_events is not None else None

@@ -530,3 +530,97 @@ def test_structured_module_with_hip_conv_projection(kind, grid, hip_device):
         out, inter = mod.to(hip_device)(x.to(hip_device), return_intermediates=True)
     assert O.rel_l2(inter["x_lin"].cpu(), tr["x_lin"]) < FP32_TOL
     assert O.rel_l2(out.cpu(), ref) < 10 * FP32_TOL
+
+
+def _grad_case(hip_device, train):
+    from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh
+
+    torch.manual_seed(11)
+    mod = Physics_Attention_Irregular_Mesh(dim=64, heads=4, dim_head=16, slice_num=16, rotate=45, dropout=0.0)
+    with torch.no_grad():
+        for name, p in mod.erwin.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(4.0)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k and "sigma_att" not in k)
+          for k, v in mod.state_dict().items()}
+    x = torch.randn(2, 700, 64)
+    gout = torch.randn(2, 700, 64)
+    cfg = O.AttnCfg(dim=64, heads=4, dim_head=16, slice_num=16, rotate=45)
+    xr = x.clone().requires_grad_(True)
+    ref = O.physics_attention_forward(xr, sd, cfg, training=train)
+    (ref * gout).sum().backward()
+    mod = mod.to(hip_device)
+    mod.train(train)
+    xg = x.to(hip_device).requires_grad_(True)
+    out = mod(xg)
+    (out * gout.to(hip_device)).sum().backward()
+    return mod, sd, xr, ref, xg, out
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_gradients_match_the_cpu_autograd_of_the_oracle(train, hip_device):
+    """loss.backward() through the module (the training scripts' use): eval mode = HIP forward +
+    back-propagation through the device-side torch restatement, train mode = the restatement both ways
+    (BatchNorm batch statistics).  Reference: autograd through the CPU oracle."""
+    mod, sd, xr, ref, xg, out = _grad_case(hip_device, train)
+    assert O.rel_l2(out.detach().cpu(), ref.detach()) < 1e-4
+    assert O.rel_l2(xg.grad.cpu(), xr.grad) < 2e-3
+    scale = max(float(sd[n].grad.norm()) for n, _ in mod.named_parameters() if sd[n].grad is not None)
+    worst, worst_name = 0.0, ""
+    for name, p in mod.named_parameters():
+        g_ref = sd[name].grad
+        if "sigma_att" in name:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0  # unused, as in the reference
+            continue
+        assert p.grad is not None, name
+        # (a Linear bias in front of a train-mode BatchNorm has a mathematically zero gradient: both
+        # sides then hold rounding noise, compared on the scale of the real gradients)
+        err = float((p.grad.cpu() - g_ref).norm()) / max(float(g_ref.norm()), 1e-4 * scale)
+        if err > worst:
+            worst, worst_name = err, name
+    assert worst < 5e-3, (worst, worst_name)
+
+
+def test_eval_forward_with_gradients_is_the_hip_forward(hip_device):
+    """With gradients enabled in eval mode the forward still runs on the HIP kernels: bit-identical to
+    the no-grad forward."""
+    from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh
+
+    torch.manual_seed(5)
+    mod = Physics_Attention_Irregular_Mesh(dim=256, heads=8, dim_head=32, slice_num=64, rotate=45).eval().to(hip_device)
+    x = torch.randn(1, 2000, 256, device=hip_device)
+    with torch.no_grad():
+        y0 = mod(x)
+    y1 = mod(x)  # parameters require grad
+    assert y1.requires_grad and torch.equal(y1.detach(), y0)
+
+
+def test_model_trains_then_serves_on_hip(hip_device):
+    """The reference's training-script pattern on the drop-in model: a few AdamW steps in train mode
+    (device-side torch path), then eval: the HIP forward picks the updated weights up and agrees with
+    the torch path evaluated in eval mode."""
+    import haet_amd
+    from haet_amd import _autograd
+
+    torch.manual_seed(0)
+    model = haet_amd.HAETransolver_Irregular_Mesh(space_dim=3, fun_dim=4, n_hidden=64, n_layers=2, n_head=4,
+                                                 mlp_ratio=2, out_dim=4, slice_num=16).to(hip_device)
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-3)
+    x = torch.randn(2, 500, 7, device=hip_device)
+    y = torch.randn(2, 500, 4, device=hip_device)
+    model.train()
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(model(x, None), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(l == l for l in losses) and losses[-1] < losses[0]
+    model.eval()
+    with torch.no_grad():
+        out_hip = model(x, None)
+        attn = model.blocks[0].Attn
+        h = torch.randn(2, 500, 64, device=hip_device)
+        assert O.rel_l2(attn(h).cpu(), _autograd.attention_forward(attn, h).cpu()) < 1e-4
+    assert torch.isfinite(out_hip).all()

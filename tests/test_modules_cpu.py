@@ -43,10 +43,12 @@ def test_no_cpu_fallback():
         m(torch.randn(1, 100, 64))
 
 
-def test_backward_is_refused_loudly():
-    m = Physics_Attention_Irregular_Mesh(64, heads=4, dim_head=16, slice_num=8).eval()
-    with pytest.raises(NotImplementedError):
-        m(torch.randn(1, 100, 64))
+def test_no_cpu_fallback_with_gradients_or_in_train_mode_either():
+    m = Physics_Attention_Irregular_Mesh(64, heads=4, dim_head=16, slice_num=8)
+    with pytest.raises(HaetError):
+        m.eval()(torch.randn(1, 100, 64))          # gradients enabled: still no CPU path
+    with pytest.raises(HaetError):
+        m.train()(torch.randn(1, 100, 64))
 
 
 def test_embedding_variants_are_out_of_scope():
