@@ -624,3 +624,22 @@ def test_model_trains_then_serves_on_hip(hip_device):
         h = torch.randn(2, 500, 64, device=hip_device)
         assert O.rel_l2(attn(h).cpu(), _autograd.attention_forward(attn, h).cpu()) < 1e-4
     assert torch.isfinite(out_hip).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_reduced_precision_inputs_under_autocast(dtype, hip_device):
+    """The reference's scripts run under torch.autocast('cuda'): half / bfloat16 activations reach the
+    module.  They are widened once; the path computes as always and returns the caller's dtype."""
+    from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh
+
+    torch.manual_seed(9)
+    mod = Physics_Attention_Irregular_Mesh(dim=256, heads=8, dim_head=32, slice_num=64, rotate=45).eval().to(hip_device)
+    x = torch.randn(1, 3000, 256, device=hip_device)
+    with torch.no_grad():
+        ref = mod(x)
+        with torch.autocast("cuda", dtype=dtype):
+            y = mod(x.to(dtype))
+        y32 = mod(x.to(dtype).float())
+    assert y.dtype == dtype
+    assert O.rel_l2(y.float().cpu(), y32.cpu()) < 1e-2       # only the final rounding to `dtype`
+    assert O.rel_l2(y32.cpu(), ref.cpu()) < 5e-2              # input rounding
