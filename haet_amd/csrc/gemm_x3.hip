@@ -135,12 +135,15 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     // Every workgroup walks K in a rotated order (start at k-tile blockIdx % nkt): with all CUs on the
     // same k-tile at the same time, every access hits bytes [128 kt, 128 kt + 128) of a 1 KB row,
     // i.e. the same 1/8 of the address-interleaved HBM channels.
-    const int krot = blockIdx.x % nkt;
-    int fx_tile = blockIdx.x, fx_kt = 0, fx_it = 0;
-    int fw_kt = 0, fw_it = 0;
+    // (not for CONV: there W -- taps * C_in * O, 14 MB at 3x3x3 x 256 x 256 -- is far larger than an XCD's
+    // L2, and only workgroups that walk the k-tiles TOGETHER find each other's W tile still cached)
+    const int krot = CONV ? 0 : blockIdx.x % nkt;
+    int fx_tile = blockIdx.x, fx_kt = 0;
+    int fw_kt = 0;
     int cgi[XPT], cgj[XPT], cgk[XPT], cg_tile = -1;  // CONV: grid coordinates of this thread's rows
     auto fetch_x = [&](f32x4 (&d)[XPT]) {
-        if (fx_it < total) {
+        {   // unconditional (rows are clamped, ghost items past the end load valid memory): a conditional
+            // load inside the prefetch ring costs the waitcnt pass its counted waits
             int kk = fx_kt + krot;
             kk = (kk >= nkt ? kk - nkt : kk) * GBK;
             if (!CONV) {
@@ -180,14 +183,13 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
                 }
             }
         }
-        ++fx_it;
         if (++fx_kt == nkt) {
             fx_kt = 0;
             fx_tile += gridDim.x;
         }
     };
     auto fetch_w = [&](u32x4 (&d)[2 * WPT]) {
-        if (fw_it < total) {
+        {
             int kk = fw_kt + krot;
             kk = (kk >= nkt ? kk - nkt : kk) * GBK;
 #pragma unroll
@@ -197,7 +199,6 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
                 d[2 * i + 1] = *reinterpret_cast<const u32x4*>(Wlo + o);
             }
         }
-        ++fw_it;
         if (++fw_kt == nkt) fw_kt = 0;
     };
     auto stage = [&](int buf, const f32x4 (&xv)[XPT], const u32x4 (&wv)[2 * WPT]) {
