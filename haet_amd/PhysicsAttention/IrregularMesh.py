@@ -25,5 +25,15 @@ class Physics_Attention_Irregular_Mesh(PhysicsAttentionBase):
     def project_torch(self, x):
         return self.in_project_x(x)
 
+    def project_backward(self, x, g_lin, need_x, wanted):
+        lin = self.in_project_x
+        g2 = g_lin.reshape(-1, g_lin.shape[-1])
+        grads = {}
+        if id(lin.weight) in wanted:
+            grads[id(lin.weight)] = g2.t() @ x.reshape(-1, x.shape[-1]).float()
+        if lin.bias is not None and id(lin.bias) in wanted:
+            grads[id(lin.bias)] = g2.sum(dim=0)
+        return (self._linear_transposed("in_project_x", lin, g_lin) if need_x else None), grads
+
     def project_split(self, x, sp):
         return self._project_split_linear("in_project_x", self.in_project_x, x, sp)

@@ -208,23 +208,48 @@ class PhysicsAttentionBase(nn.Module):
                             "and its input with .cuda() -- there is no CPU fallback")
         wants_grad = torch.is_grad_enabled() and (x.requires_grad or self._any_requires_grad())
         if self.training or wants_grad:
-            # The HIP kernels are forward-only (the hand-written backward is the next scope row, SURVEY.md
-            # 8f-1).  Until then: train mode runs the device-side torch restatement (BatchNorm batch
-            # statistics, dropout), eval mode with gradients runs the HIP forward and back-propagates
-            # through the restatement -- haet_amd/_autograd.py.
+            # One autograd node whose N-scaled work is on the HIP kernels in both directions; only the
+            # Erwin stage (B*H*M tokens) differentiates through a torch restatement -- haet_amd/_autograd.py.
             from .. import _autograd
 
             if self.shard_group is not None or return_intermediates:
                 raise NotImplementedError("training / gradients are not available on the point-sharded path "
                                           "or together with return_intermediates yet")
-            if self.training:
-                return _autograd.attention_forward(self, x)
-            return _autograd.HipForwardTorchBackward.apply(self, x, *self.parameters())
+            if os.environ.get("HAET_TORCH_BACKWARD"):  # the previous interim path, kept for A/B runs
+                if self.training:
+                    return _autograd.attention_forward(self, x)
+                return _autograd.HipForwardTorchBackward.apply(self, x, *self.parameters())
+            y = _autograd.PhysicsAttentionFunction.apply(self, x, *self.parameters())
+            return self.to_out[1](y).to(x.dtype)
         return self._forward_hip(x, return_intermediates)
 
     def project_torch(self, x: torch.Tensor) -> torch.Tensor:
         """The projection as stock torch ops (differentiable path, haet_amd/_autograd.py)."""
         raise NotImplementedError
+
+    def project_backward(self, x: torch.Tensor, g_lin: torch.Tensor, need_x: bool, wanted: set):
+        """Backward of `project`: (dL/dx or None, {id(param): grad}).  Generic version through autograd over
+        `project_torch` (the structured variants: MIOpen's convolution backward)."""
+        params = [p for p in self.in_project_x.parameters() if id(p) in wanted]
+        if not need_x and not params:
+            return None, {}
+        with torch.enable_grad():
+            xr = x.detach().requires_grad_(bool(need_x))
+            y = self.project_torch(xr)
+        got = torch.autograd.grad(y, ([xr] if need_x else []) + params, g_lin.to(y.dtype), allow_unused=True)
+        gx = got[0] if need_x else None
+        return gx, {id(p): g for p, g in zip(params, got[1 if need_x else 0:])}
+
+    def _linear_transposed(self, name: str, lin: nn.Linear, g: torch.Tensor) -> torch.Tensor:
+        """g [..., O] @ W [O, K] -> [..., K]: the input gradient of a Linear, on the same MFMA GEMM."""
+        if not ops.linear_supported(lin.out_features, lin.in_features) or g.dtype != torch.float32:
+            return g.to(lin.weight.dtype) @ lin.weight.detach()
+        cache = self.__dict__.setdefault("_split_cache", {})
+        key = (lin.weight.data_ptr(), lin.weight._version)
+        name = name + ".T"
+        if name not in cache or cache[name][0] != key:
+            cache[name] = (key, ops.SplitLinear(lin.weight.detach().t().contiguous(), None))
+        return ops.linear(g, cache[name][1])
 
     def _forward_hip(self, x: torch.Tensor, return_intermediates: bool = False):
         B, N, _ = x.shape

@@ -1,19 +1,22 @@
-"""Differentiable path of the PhysicsAttention modules (interim state).
+"""Differentiable path of the PhysicsAttention modules.
 
-The hand-written HIP kernels are forward-only.  So that the modules still drop into the reference's
-training scripts (`loss.backward()` through `models.PhysicsAttention.*`, exp_airfoil.py:249-255):
+`loss.backward()` through `models.PhysicsAttention.*` (exp_airfoil.py:249-255) runs as ONE autograd
+node, `PhysicsAttentionFunction`, whose N-scaled work is all on the HIP kernels:
 
-* eval mode with gradients enabled (fine-tuning with frozen BatchNorm statistics): the forward runs
-  on the HIP kernels as always, and `backward` re-runs THIS file's restatement of the same forward
-  under autograd on the device and back-propagates through it (`HipForwardTorchBackward`);
-* train mode (BatchNorm batch statistics over all clouds, running-stat updates, dropout): forward
-  and backward both run here.
+    forward   projection GEMM / conv -> slice pass -> merge -> Erwin -> de-slice -> to_out GEMM
+    backward  g_out = gy . W_out (GEMM) -> haet_deslice_bwd_tokens (dS2) -> Erwin backward (dS)
+              -> haet_slice_bwd_points (dx_lin + the Rep-Slice / Ada-Temp parameter gradients)
+              -> gx = dx_lin . W_in (GEMM); the two weight gradients are plain library GEMMs (rocBLAS)
 
-Everything below is stock PyTorch on ROCm device tensors, written against the same reference lines
-as the kernels (models/PhysicsAttention/IrregularMesh.py:141-235, models/components/erwinflash/*);
-the ball tree comes from the HIP builder (`ops.balltree_build`, bit-identical to the reference's
-host builder), so there is still no CPU round trip and no path without libhaet_hip.so.  A hand-written
-HIP backward replaces this file later; the no-grad / eval forward never comes through here.
+The [B,H,N,M] slice-weight tensor is never materialised in either direction.  Only the Erwin stage --
+T = B*H*M tokens (512 at the 1M-point config), independent of N -- still differentiates through this
+file's torch restatement of it (`erwin_forward`, against models/components/erwinflash/*): in eval mode
+the forward uses the Erwin HIP kernel and the backward re-runs the restatement on the saved tokens; in
+train mode (BatchNorm batch statistics over all clouds, running-stat updates) the restatement runs in
+the forward and its graph is kept.  The ball tree comes from the HIP builder either way
+(`ops.balltree_build`, bit-identical to the reference's host builder): no CPU round trip, no path
+without libhaet_hip.so.  `attention_forward` is the whole module as stock torch ops on the device --
+the A/B reference of the tests (and `HipForwardTorchBackward`, the previous interim backward).
 """
 from __future__ import annotations
 
@@ -142,3 +145,85 @@ class HipForwardTorchBackward(torch.autograd.Function):
         gx = next(gi) if xr.requires_grad else None
         by_param = {id(p): g for p, g in zip(params, gi)}
         return (None, gx) + tuple(by_param.get(id(p)) for p in ctx.all_params)
+
+
+# --------------------------------------------------------------------------- the HIP training path
+def _tokens_through_erwin(mod, S, n_clouds):
+    """Token positions (IrregularMesh.py:196-209) + Erwin on the slice tokens S [T, C], differentiable."""
+    d = mod.dimensionality
+    lo, hi = S[:, :d].min(dim=0)[0], S[:, :d].max(dim=0)[0]
+    pos = (S[:, :d] - lo) / (hi - lo + 1e-8)
+    return erwin_forward(mod.erwin, S, pos, n_clouds)
+
+
+class PhysicsAttentionFunction(torch.autograd.Function):
+    """forward(x) up to and including the to_out Linear (dropout stays outside), see the module docstring."""
+
+    @staticmethod
+    def forward(ctx, mod, x, *params):
+        B, N, _ = x.shape
+        H, C, G = mod.heads, mod.dim_head, mod.slice_num
+        sp = mod._slice_params()
+        x_lin = mod.project(x).float().contiguous()                      # [B, N, H*C] fp32, kept for backward
+        parts = ops.slice_partials(x_lin, sp, H, C, G)
+        col_max, col_sum, S = ops.merge_records(parts, B, H, C, G, finalize=True)
+        ctx.inner = None
+        if mod.training:  # batch-statistics BatchNorm: the restatement runs now and keeps its graph
+            with torch.enable_grad():
+                S_leaf = S.detach().requires_grad_(True)
+                S2_graph = _tokens_through_erwin(mod, S_leaf, B * H)
+            S2 = S2_graph.detach()
+            ctx.inner = (S_leaf, S2_graph)
+        else:
+            S2 = mod.erwin(S, None, n_clouds=B * H)
+        out_x = ops.deslice(x_lin, sp, col_max, col_sum, S2, H, C, G)
+        y = mod._linear("to_out", mod.to_out[0], out_x)
+        ctx.save_for_backward(x, x_lin, col_max, col_sum, S, S2, out_x)
+        ctx.mod, ctx.all_params = mod, params
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        mod = ctx.mod
+        x, x_lin, col_max, col_sum, S, S2, out_x = ctx.saved_tensors
+        B, N, _ = x.shape
+        H, C, G = mod.heads, mod.dim_head, mod.slice_num
+        sp = mod._slice_params()
+        wanted = {id(p) for p, need in zip(ctx.all_params, ctx.needs_input_grad[2:]) if need}
+        grads = {}
+        gy = gy.float().contiguous()
+        gy2 = gy.view(B * N, -1)
+        lin_out = mod.to_out[0]
+        if id(lin_out.weight) in wanted:
+            grads[id(lin_out.weight)] = gy2.t() @ out_x.view(B * N, -1)
+        if lin_out.bias is not None and id(lin_out.bias) in wanted:
+            grads[id(lin_out.bias)] = gy2.sum(dim=0)
+        g_out = mod._linear_transposed("to_out", lin_out, gy)           # dL/d out_x [B, N, H*C]
+        dS2 = ops.deslice_bwd_tokens(x_lin, sp, col_max, col_sum, g_out, H, C, G)
+
+        erwin_params = [p for p in mod.erwin.parameters() if id(p) in wanted]
+        if ctx.inner is None:
+            with torch.enable_grad():
+                S_leaf = S.detach().requires_grad_(True)
+                S2_graph = _tokens_through_erwin(mod, S_leaf, B * H)
+        else:
+            S_leaf, S2_graph = ctx.inner
+        got = torch.autograd.grad(S2_graph, [S_leaf] + erwin_params, dS2, allow_unused=True)
+        dS = got[0] if got[0] is not None else torch.zeros_like(S)
+        for p, g in zip(erwin_params, got[1:]):
+            grads[id(p)] = g
+        A = (dS2 * S2).sum(dim=-1) + (S * dS).sum(dim=-1)              # sum_n w[n,g] a[n,g], [B*H*M]
+        dx_lin, dWs, dbs, dwt, dbt = ops.slice_bwd_points(x_lin, sp, col_max, col_sum, g_out, S2, dS, A, H, C, G)
+        grads[id(mod.in_project_slice.weight)] = dWs
+        grads[id(mod.in_project_slice.bias)] = dbs
+        grads[id(mod.ada_temp_linear.weight)] = dwt.view(1, C)
+        grads[id(mod.ada_temp_linear.bias)] = dbt.view(1)
+        gx, proj_grads = mod.project_backward(x, dx_lin, ctx.needs_input_grad[1], wanted)
+        grads.update(proj_grads)
+        if gx is not None:
+            gx = gx.to(x.dtype)
+        out = []
+        for p in ctx.all_params:
+            g = grads.get(id(p)) if id(p) in wanted else None
+            out.append(None if g is None else g.to(p.dtype).reshape(p.shape))
+        return (None, gx) + tuple(out)

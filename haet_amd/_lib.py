@@ -69,6 +69,11 @@ SIGNATURES = {
     "haet_conv_project_supported": (c_int, [c_int, c_int]),
     "haet_conv_project_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       _P, _P]),
+    "haet_slice_bwd_num_parts": (c_int, [c_int] * 5),
+    "haet_slice_bwd_param_floats": (c_size_t, [c_int, c_int]),
+    "haet_deslice_bwd_tokens": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P] + [c_int] * 5 + [_P, _P]),
+    "haet_slice_bwd_points": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P]
+                              + [c_int] * 5 + [_P, _P, _P]),
     "haet_erwin_lds_bytes": (c_size_t, [POINTER(ErwinDesc), c_int]),
     "haet_erwin_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, POINTER(ErwinDesc), c_int, c_int, _P, _P]),
     "haet_deslice_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P]
@@ -91,8 +96,8 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
             fn.restype, fn.argtypes = res, args
-        if lib.haet_abi_version() != 2:
-            raise HaetError(f"libhaet_hip.so ABI {lib.haet_abi_version()} != 2")
+        if lib.haet_abi_version() != 3:
+            raise HaetError(f"libhaet_hip.so ABI {lib.haet_abi_version()} != 3")
         _lib = lib
     return _lib
 

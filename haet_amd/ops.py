@@ -169,6 +169,43 @@ def deslice(x_lin: Tensor, p: SliceParams, col_max: Tensor, col_sum: Tensor, S2:
     return out
 
 
+# --------------------------------------------------------------------------- backward of the two passes
+def deslice_bwd_tokens(x_lin: Tensor, p: SliceParams, col_max: Tensor, col_sum: Tensor, g_out: Tensor,
+                       H: int, C: int, M: int) -> Tensor:
+    """dS2 [B*H*M, C] = sum_n w[n,g] g_out[n]  (haet_deslice_bwd_tokens + the sum of its partials)."""
+    lib = _lib.load()
+    x_lin, g_out = _f32(x_lin, "x_lin"), _f32(g_out, "g_out")
+    B, N, _ = x_lin.shape
+    P = lib.haet_slice_bwd_num_parts(B, N, H, C, M)
+    if P < 0:
+        check(P, "haet_slice_bwd_num_parts")
+    parts = torch.empty((P, B * H * M, C), dtype=torch.float32, device=x_lin.device)
+    check(lib.haet_deslice_bwd_tokens(_p(x_lin), _p(p.Ws), _p(p.bs), _p(p.wt), p.bt, p.base_temp, p.c0,
+                                      _p(col_max), _p(col_sum), _p(g_out), B, N, H, C, M, _p(parts), _stream()),
+          "haet_deslice_bwd_tokens")
+    return parts.sum(dim=0)
+
+
+def slice_bwd_points(x_lin: Tensor, p: SliceParams, col_max: Tensor, col_sum: Tensor, g_out: Tensor,
+                     S2: Tensor, dS: Tensor, A: Tensor, H: int, C: int, M: int):
+    """haet_slice_bwd_points -> (dx_lin [B,N,H*C], dWs [M,C], dbs [M], dwt [C], dbt [])."""
+    lib = _lib.load()
+    x_lin, g_out = _f32(x_lin, "x_lin"), _f32(g_out, "g_out")
+    S2, dS, A = _f32(S2, "S2"), _f32(dS, "dS"), _f32(A, "A")
+    B, N, _ = x_lin.shape
+    P = lib.haet_slice_bwd_num_parts(B, N, H, C, M)
+    if P < 0:
+        check(P, "haet_slice_bwd_num_parts")
+    R = lib.haet_slice_bwd_param_floats(C, M)
+    dx = torch.empty_like(x_lin)
+    pp = torch.empty((P * B * H, R), dtype=torch.float32, device=x_lin.device)
+    check(lib.haet_slice_bwd_points(_p(x_lin), _p(p.Ws), _p(p.bs), _p(p.wt), p.bt, p.base_temp, p.c0,
+                                    _p(col_max), _p(col_sum), _p(g_out), _p(S2), _p(dS), _p(A), B, N, H, C, M,
+                                    _p(dx), _p(pp), _stream()), "haet_slice_bwd_points")
+    g = pp.sum(dim=0)
+    return dx, g[:M * C].view(M, C), g[M * C:M * C + M], g[M * C + M:M * C + M + C], g[M * C + M + C]
+
+
 class SplitLinear:
     """A Linear layer's weight as bf16 hi/lo planes for haet_linear_fwd (built once per weight
     version by haet_split_bf16 on the device)."""

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HAET_ABI_VERSION 2  /* 2: + haet_tokens_tree_build, haet_project_split_fwd, haet_*_fwd_split */
+#define HAET_ABI_VERSION 3  /* 2: + haet_tokens_tree_build, haet_project_split_fwd, haet_*_fwd_split */
 
 #define HAET_OK 0
 #define HAET_E_ARG (-1)      /* bad argument / unsupported shape */
@@ -224,6 +224,32 @@ int haet_slice_fwd_split(const void* x_split, const float* s, const float* Ws, c
 int haet_deslice_fwd_split(const void* x_split, const float* s, const float* Ws, const float* bs,
                            float c0, const float* col_max, const float* col_sum, const float* S2,
                            int B, int N, int H, int C, int M, float* out_x, haet_stream_t stream);
+
+/* ------------------------------------------------------------------ backward of the two passes
+ * The N-scaled part of loss.backward() through Physics_Attention_* (the reference relies on torch
+ * autograd over models/PhysicsAttention/IrregularMesh.py:168-188,228; scripts: exp_airfoil.py:249-255).
+ * The slice weights w[n,g] are recomputed from x_lin and the forward's column statistics.
+ *   g_out = dL/d out_x [B,N,H*C]  (gradient arriving at haet_deslice_fwd's output)
+ * pass 1, haet_deslice_bwd_tokens: partial sums of dS2[b,h,g,:] = sum_n w[n,g] g_out[b,n,h,:]
+ *   -> parts [P][B*H*M*C], P = haet_slice_bwd_num_parts(...); the caller sums over P and runs the
+ *   Erwin backward, which yields dS = dL/dS (S = the normalised eidetic states of haet_slice_merge).
+ * pass 2, haet_slice_bwd_points: with A[b,h,g] = dS2[g].S2[g] + S[g].dS[g] from the caller,
+ *   dx_lin [B,N,H*C] (complete gradient w.r.t. x_lin: de-slice + slice + Ada-Temp terms) and
+ *   param_parts [P][B*H][M*C + M + C + 1] = per-workgroup partials of
+ *   (d in_project_slice.weight [M,C], d in_project_slice.bias [M], d ada_temp_linear.weight [C],
+ *   d ada_temp_linear.bias), to be summed over P and B*H by the caller.                            */
+int haet_slice_bwd_num_parts(int B, int N, int H, int C, int M);
+size_t haet_slice_bwd_param_floats(int C, int M);
+int haet_deslice_bwd_tokens(const float* x_lin, const float* Ws, const float* bs, const float* wt,
+                            float bt, float base_temp, float c0, const float* col_max,
+                            const float* col_sum, const float* g_out, int B, int N, int H, int C, int M,
+                            float* parts, haet_stream_t stream);
+int haet_slice_bwd_points(const float* x_lin, const float* Ws, const float* bs, const float* wt,
+                          float bt, float base_temp, float c0, const float* col_max,
+                          const float* col_sum, const float* g_out, const float* S2 /*[B*H*M, C]*/,
+                          const float* dS /*[B*H*M, C]*/, const float* A /*[B*H*M]*/,
+                          int B, int N, int H, int C, int M, float* dx_lin, float* param_parts,
+                          haet_stream_t stream);
 
 /* ------------------------------------------------------------------ structured-mesh projection
  * in_project_x of the structured modules (nn.Conv2d / nn.Conv3d, kernel k, padding k/2:

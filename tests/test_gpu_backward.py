@@ -1,0 +1,153 @@
+"""GPU: the hand-written backward of the slice / de-slice passes (haet_deslice_bwd_tokens,
+haet_slice_bwd_points) and the autograd node built on them, against torch autograd.
+
+Kernel level: an fp64 torch restatement of the two passes (IrregularMesh.py:168-188, 228) is
+differentiated by autograd for the loss  <out, g_out> + <S, dS>  with random g_out / dS, which is
+exactly what the two kernels are handed by the module's backward.  Module level: gradients of all
+three module variants against the device-side torch restatement of the whole forward.
+"""
+import pytest
+import torch
+
+from oracle import haet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+K_NORM = 1.0 / (1.0 + 1e-5)
+
+
+def _passes_fp64(x, Ws, bs, wt, bt, base, c0, S2):
+    """x [B,N,H,C] -> (w [B,H,N,M], S [B,H,M,C], out [B,N,H,C]); fp64."""
+    xp = x.permute(0, 2, 1, 3)
+    t = xp @ wt + bt
+    tau = base + torch.clamp(t, -0.4, 0.4)
+    z = (xp @ Ws.t() + bs - c0) / tau[..., None]
+    w = torch.softmax(z, dim=2)
+    S = torch.einsum("bhnc,bhng->bhgc", xp, w) / (w.sum(2) + 1e-5)[..., None]
+    out = torch.einsum("bhgc,bhng->bhnc", S2, w).permute(0, 2, 1, 3)
+    return w, S, out
+
+
+@pytest.mark.parametrize("B,N,H,C,M", [(1, 700, 4, 16, 16), (2, 333, 8, 32, 64), (1, 1, 2, 32, 32), (1, 5000, 8, 32, 64),
+                                       (1, 1025, 4, 64, 32), (1, 257, 2, 32, 128), (2, 64, 3, 8, 8), (1, 300, 2, 64, 100),
+                                       (1, 4097, 2, 16, 48)])
+def test_backward_passes_vs_fp64_autograd(B, N, H, C, M, hip_device):
+    from haet_amd import ops
+
+    dev = hip_device
+    g = torch.Generator().manual_seed(B * 1000 + N + M)
+    x = torch.randn(B, N, H, C, generator=g)
+    Ws = torch.randn(M, C, generator=g) * 0.4
+    bs = torch.randn(M, generator=g) * 0.3
+    wt = torch.randn(C, generator=g) * (1.2 / C ** 0.5)  # t spreads over the clamp's range and beyond it
+    bt = 0.05
+    S2 = torch.randn(B, H, M, C, generator=g)
+    g_out = torch.randn(B, N, H, C, generator=g)
+    dS = torch.randn(B, H, M, C, generator=g)
+    sp = ops.SliceParams(Ws.to(dev), bs.to(dev), wt.to(dev), bt, 0.5, 1e-6)
+
+    # fp64 autograd reference
+    leaves = [t.double().requires_grad_(True) for t in (x, Ws, bs, wt, torch.tensor(bt), S2)]
+    w, S, out = _passes_fp64(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], 0.5, sp.c0, leaves[5])
+    loss = (out * g_out.double()).sum() + (S * dS.double()).sum()
+    gx, gWs, gbs, gwt, gbt, gS2 = torch.autograd.grad(loss, leaves)
+    inside = ((leaves[0].detach().permute(0, 2, 1, 3) @ wt.double() + bt).abs() < 0.4).double().mean()
+
+    # column statistics and S of the forward from the fp64 reference (the bf16x3 forward's own statistics
+    # carry its |z| 2^-16 logit envelope, which the module-level tests cover): isolates the two kernels
+    x_lin = x.reshape(B, N, H * C).to(dev)
+    with torch.no_grad():
+        xp = leaves[0].permute(0, 2, 1, 3)
+        tau = 0.5 + torch.clamp(xp @ leaves[3] + bt, -0.4, 0.4)
+        z = (xp @ leaves[1].t() + leaves[2] - sp.c0) / tau[..., None]
+        m = z.max(dim=2)[0]
+        cm = m.reshape(-1).float().to(dev)
+        cs = torch.exp(z - m[:, :, None]).sum(2).reshape(-1).float().to(dev)
+        S_hip = (S * (w.sum(2) + 1e-5)[..., None] * K_NORM).reshape(-1, C).float().to(dev)  # k sum_n w x
+    go = g_out.reshape(B, N, H * C).to(dev)
+    S2d, dSd = S2.reshape(-1, C).to(dev), dS.reshape(-1, C).to(dev)
+    dS2 = ops.deslice_bwd_tokens(x_lin, sp, cm, cs, go, H, C, M)
+    assert O.rel_l2(dS2.cpu().double(), gS2.reshape(-1, C)) < 5e-5
+    A = (dS2 * S2d).sum(-1) + (S_hip * dSd).sum(-1)
+    dx, dWs, dbs, dwt, dbt = ops.slice_bwd_points(x_lin, sp, cm, cs, go, S2d, dSd, A, H, C, M)
+    tol = 2e-4  # fp32 accumulation over N points with cancellation in (a - A)
+    assert O.rel_l2(dx.cpu().double().reshape(B, N, H, C), gx) < tol
+    if N == 1:  # softmax over one point: w = 1, dz = 0 -- every parameter gradient is rounding noise around zero
+        assert float(dWs.abs().max()) < 1e-3 and float(dbs.abs().max()) < 1e-3 and float(dwt.abs().max()) < 1e-3
+        return
+    assert O.rel_l2(dWs.cpu().double(), gWs) < tol
+    # sum_n dlogit cancels almost completely (exactly, for a constant tau): measured on the scale of its terms,
+    # which is the scale of dWs = sum_n dlogit x_n with unit-variance x
+    assert float((dbs.cpu().double() - gbs).norm()) / max(float(gbs.norm()), float(gWs.norm()) / C ** 0.5) < tol
+    if 0.0 < float(inside):
+        assert O.rel_l2(dwt.cpu().double(), gwt) < 5 * tol
+        assert abs(float(dbt) - float(gbt)) < 5 * tol * max(1.0, abs(float(gbt)), float(gwt.norm()))
+
+
+@pytest.mark.parametrize("kind", ["irregular_c3", "structured2d", "structured3d"])
+@pytest.mark.parametrize("train", [False, True])
+def test_module_gradients_vs_device_restatement(kind, train, hip_device):
+    """All parameter gradients and the input gradient of the three variants: the HIP autograd node
+    against autograd through the stock-torch restatement of the same forward on the device."""
+    from haet_amd import _autograd
+    from haet_amd.PhysicsAttention import (Physics_Attention_Irregular_Mesh, Physics_Attention_Structured_Mesh_2D,
+                                           Physics_Attention_Structured_Mesh_3D)
+
+    torch.manual_seed(3)
+    if kind == "irregular_c3":
+        mod, N, dim = Physics_Attention_Irregular_Mesh(dim=256, heads=8, dim_head=32, slice_num=64, rotate=45), 3001, 256
+    elif kind == "structured2d":
+        mod, N, dim = Physics_Attention_Structured_Mesh_2D(dim=64, heads=4, dim_head=32, slice_num=16, H=20, W=12,
+                                                           rotate=45), 240, 64
+    else:
+        mod, N, dim = Physics_Attention_Structured_Mesh_3D(dim=32, heads=4, dim_head=32, slice_num=32, H=6, W=8, D=5,
+                                                           rotate=45), 240, 32
+    with torch.no_grad():
+        for name, p in mod.erwin.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(3.0)  # make the Erwin stage matter in the output
+    mod = mod.to(hip_device).train(train)
+    x = torch.randn(2, N, dim, device=hip_device)
+    gout = torch.randn(2, N, dim, device=hip_device)
+
+    def run(fn):
+        mod.zero_grad(set_to_none=True)
+        xr = x.clone().requires_grad_(True)
+        (fn(xr) * gout).sum().backward()
+        return xr.grad.clone(), {n: (None if p.grad is None else p.grad.clone()) for n, p in mod.named_parameters()}
+
+    state = {k: v.clone() for k, v in mod.state_dict().items()}
+    gx_ref, gp_ref = run(lambda t: _autograd.attention_forward(mod, t))
+    mod.load_state_dict(state)  # train mode: undo the running-statistics update of the first run
+    gx, gp = run(mod)
+    assert O.rel_l2(gx.cpu(), gx_ref.cpu()) < 1e-3
+    scale = max(float(g.norm()) for g in gp_ref.values() if g is not None)
+    for name, g_ref in gp_ref.items():
+        if g_ref is None:
+            assert gp[name] is None or float(gp[name].abs().max()) == 0.0, name
+            continue
+        assert gp[name] is not None, name
+        err = float((gp[name] - g_ref).norm()) / max(float(g_ref.norm()), 1e-4 * scale)
+        assert err < 2e-3, (name, err)
+
+
+def test_backward_never_materialises_the_slice_weights(hip_device):
+    """Memory of one training step at 200k points: well under the [B,H,N,M] fp32 weight tensor the
+    torch path keeps several copies of (200k x 8 x 64 x 4 B = 410 MB each)."""
+    from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh
+
+    torch.manual_seed(0)
+    mod = Physics_Attention_Irregular_Mesh(dim=256, heads=8, dim_head=32, slice_num=64, rotate=45).to(hip_device).train()
+    N = 200_000
+    x = torch.randn(1, N, 256, device=hip_device, requires_grad=True)
+    mod(x).sum().backward()  # warm-up: caches, workspace
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    mod(x).square().mean().backward()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    row = N * 256 * 4
+    # saved: x_lin, out_x; transient: y, gy, g_out, dx_lin, gx (+ partial records)
+    assert peak < 9 * row, (peak / row)
+    assert torch.isfinite(x.grad).all() and all(torch.isfinite(p.grad).all() for p in mod.parameters() if p.grad is not None)

@@ -559,9 +559,9 @@ def _grad_case(hip_device, train):
 
 @pytest.mark.parametrize("train", [False, True])
 def test_gradients_match_the_cpu_autograd_of_the_oracle(train, hip_device):
-    """loss.backward() through the module (the training scripts' use): eval mode = HIP forward +
-    back-propagation through the device-side torch restatement, train mode = the restatement both ways
-    (BatchNorm batch statistics).  Reference: autograd through the CPU oracle."""
+    """loss.backward() through the module (the training scripts' use): the HIP autograd node of
+    haet_amd/_autograd.py in eval and in train mode (BatchNorm batch statistics).  Reference: autograd
+    through the CPU oracle."""
     mod, sd, xr, ref, xg, out = _grad_case(hip_device, train)
     assert O.rel_l2(out.detach().cpu(), ref.detach()) < 1e-4
     assert O.rel_l2(xg.grad.cpu(), xr.grad) < 2e-3
@@ -582,8 +582,8 @@ def test_gradients_match_the_cpu_autograd_of_the_oracle(train, hip_device):
 
 
 def test_eval_forward_with_gradients_is_the_hip_forward(hip_device):
-    """With gradients enabled in eval mode the forward still runs on the HIP kernels: bit-identical to
-    the no-grad forward."""
+    """With gradients enabled in eval mode the forward still runs on the HIP kernels (fp32 x_lin kept
+    for the backward instead of the fused operand format: same result to rounding)."""
     from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh
 
     torch.manual_seed(5)
@@ -592,7 +592,7 @@ def test_eval_forward_with_gradients_is_the_hip_forward(hip_device):
     with torch.no_grad():
         y0 = mod(x)
     y1 = mod(x)  # parameters require grad
-    assert y1.requires_grad and torch.equal(y1.detach(), y0)
+    assert y1.requires_grad and O.rel_l2(y1.detach().cpu(), y0.cpu()) < 1e-5
 
 
 def test_model_trains_then_serves_on_hip(hip_device):
