@@ -15,6 +15,8 @@
 //        dz     = w (a - A);   dlogit = dz / tau;   dtau = -sum_g dz z / tau;   dt = dtau [|t| <= 0.4]
 //        dx_n   = sum_g dlogit Ws[g] + k sum_g w dS[g] + dt wt
 //        dWs[g] += dlogit x_n;  dbs[g] += dlogit;  dwt += dt x_n;  dbt += dt  (per-workgroup partials)
+#include <cstdlib>
+
 #include "common.h"
 
 namespace haet {
@@ -311,6 +313,16 @@ __global__ __launch_bounds__(256) void slice_bwd_points_kernel(
 
 // ----------------------------------------------------------------------------- host side
 int slice_shape_ok(int B, int N, int H, int C, int M);  // slice_valu.hip
+// slice_bwd_mfma.hip: the same passes on v_mfma_f32_32x32x2_f32 (C = 32, M in {32, 64, 128}), same records
+bool slice_bwd_mfma_ok(int C, int M);
+int slice_bwd_mfma(int mode, const float*, const float*, const float*, const float*, float, float, float,
+                   const float*, const float*, const float*, const float*, const float*, const float*, int, int, int,
+                   int, float*, float*, hipStream_t);
+
+static bool use_bwd_mfma(int C, int M) {  // HAET_FORCE_VALU=1 routes every shape through the generic kernels (tests)
+    const char* e = getenv("HAET_FORCE_VALU");
+    return !(e && e[0] == '1') && slice_bwd_mfma_ok(C, M);
+}
 
 template <int C, int NG>
 static int launch_tokens(dim3 grid, hipStream_t st, const float* x, const float* Ws, const float* bs,
@@ -375,6 +387,9 @@ extern "C" int haet_deslice_bwd_tokens(const float* x_lin, const float* Ws, cons
         return fail(HAET_E_ARG, "deslice_bwd_tokens: null pointer");
     int rc = slice_shape_ok(B, N, H, C, M);
     if (rc != HAET_OK) return rc;
+    if (use_bwd_mfma(C, M))
+        return slice_bwd_mfma(0, x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, g_out, nullptr, nullptr,
+                              nullptr, B, N, H, M, nullptr, parts, as_stream(stream));
     const int chunk = pick_chunk(N);
     dim3 grid((N + chunk - 1) / chunk, B * H);
     HAET_BWD_DISPATCH(launch_tokens, grid, as_stream(stream), x_lin, Ws, bs, wt, bt, base_temp, c0, col_max,
@@ -390,6 +405,9 @@ extern "C" int haet_slice_bwd_points(const float* x_lin, const float* Ws, const 
         return fail(HAET_E_ARG, "slice_bwd_points: null pointer");
     int rc = slice_shape_ok(B, N, H, C, M);
     if (rc != HAET_OK) return rc;
+    if (use_bwd_mfma(C, M))
+        return slice_bwd_mfma(1, x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, g_out, S2, dS, A, B, N, H, M,
+                              dx_lin, param_parts, as_stream(stream));
     const int chunk = pick_chunk(N);
     dim3 grid((N + chunk - 1) / chunk, B * H);
     HAET_BWD_DISPATCH(launch_points, grid, as_stream(stream), x_lin, Ws, bs, wt, bt, base_temp, c0, col_max,

@@ -1,0 +1,370 @@
+// Backward of the slice / de-slice passes on the matrix cores (dim_head C = 32, slice_num M in {32, 64, 128}):
+// the same two passes as slice_bwd.hip (maths and record layouts in its header comment), with every
+// contraction on v_mfma_f32_32x32x2_f32 -- f32 operands, f32 accumulate, exact f32 products, so the
+// gradients need no split-precision envelope.
+//
+// One wave owns tiles of 32 points of one (cloud, head).  Everything point-wise lives in the MFMA
+// accumulator layout with the POINT in the lane (column n = lane % 32) and the slice column g in the
+// register index (row = 8 (v / 4) + 4 (lane / 32) + v % 4 per 32-row block):
+//   Z^T [g][n] = Ws [g][c] X^T [c][n]                         (step 1; X^T straight from global, 16 channels per lane)
+//   a^T [g][n] = S2 [g][c] GO^T [c][n] + k dS [g][c] X^T      (step 2)
+//   tau, the clamp mask and sum_g dz z are per-lane scalars (one shuffle across the two half-waves)
+//   dX^T [c][n] = Ws^T [c][g] dlogit^T [g][n] + k dS^T P^T    (step 3: the accumulators ARE the B operands: the
+//                 two half-waves hold rows g and g + 4 of register v, which is one k-pair of the instruction)
+//   dWs [g][c] += dlogit [g][n] X [n][c]                      (step 4: the one contraction over the points; both
+//                 operands go through a wave-private LDS tile to get n into the register index)
+// The constant A operands are per-workgroup LDS images read with one ds_read_b128 per four MFMAs.
+#include "common.h"
+
+namespace haet {
+
+namespace {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+constexpr float kNormK = 1.0f / (1.0f + 1e-5f);
+constexpr int kTS = 36;  // row stride (floats) of the wave-private tiles: 16-B aligned rows, conflict-free b128 access
+
+__device__ __forceinline__ f16v mfma(float a, float b, f16v c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float half_sum(float v) {  // sum over the 32 lanes of a half-wave
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {  // wave-private LDS hand-off: ordering only
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+int pick_chunk(int N) {
+    int c = (N + 255) / 256;
+    c = ((c + 255) / 256) * 256;
+    return c < 256 ? 256 : c;
+}
+
+}  // namespace
+
+// MODE 0: pass 1 (dS2 partials).  MODE 1: pass 2 (dx_lin + parameter-gradient partials).
+template <int MB, int NW, int MODE>
+__global__ __launch_bounds__(NW * 64) void slice_bwd_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ Ws, const float* __restrict__ bs,
+    const float* __restrict__ wt, float bt, float base_temp, float c0,
+    const float* __restrict__ col_max, const float* __restrict__ col_sum,
+    const float* __restrict__ go, const float* __restrict__ S2, const float* __restrict__ dS,
+    const float* __restrict__ A, int N, int H, int chunk,
+    float* __restrict__ dx, float* __restrict__ parts) {
+    constexpr int M = 32 * MB, C = 32, IMG = M * C;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // operand images [blk][q][lane][4]
+    float* WsA = lds;                                   // A of step 1: Ws[32 blk + l%32][4q+j + 16 (l/32)]
+    float* S2A = WsA + IMG;                             // MODE 1 from here on
+    float* dSA = S2A + (MODE ? IMG : 0);
+    float* WsT = dSA + (MODE ? IMG : 0);                // A of step 3: Ws[32 blk + 8q + 4 (l/32) + j][l%32]
+    float* dST = WsT + (MODE ? IMG : 0);
+    float* biasL = dST + (MODE ? IMG : 0);              // [M] bs - c0
+    float* cmlL = biasL + M;                            // [M] col_max + ln col_sum
+    float* ArL = cmlL + M;                              // [M] A
+    float* wtL = ArL + M;                               // [32]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+    float* T = wtL + 32 + wave * (2 * 32 * kTS);        // [32 g][kTS]: one 32-row block of dlogit / P, n in the columns
+    float* X = T + 32 * kTS;                            // [32 n][kTS]: the tile's x (MODE 1) or g_out (MODE 0) rows
+    const int bh = blockIdx.y, b = bh / H, h = bh % H, BH = gridDim.y;
+    const int n0 = blockIdx.x * chunk, n1 = min(N, n0 + chunk);
+
+    for (int i = threadIdx.x; i < IMG; i += NW * 64) {
+        const int j = i & 3, l = (i >> 2) & 63, q = (i >> 8) & 3, blk = i >> 10;
+        const int ga = 32 * blk + (l & 31), ca = 4 * q + j + 16 * (l >> 5);
+        WsA[i] = Ws[ga * C + ca];
+        if (MODE) {
+            const int gt = 32 * blk + 8 * q + 4 * (l >> 5) + j, ct = l & 31;
+            S2A[i] = S2[((size_t)bh * M + ga) * C + ca];
+            dSA[i] = kNormK * dS[((size_t)bh * M + ga) * C + ca];
+            WsT[i] = Ws[gt * C + ct];
+            dST[i] = kNormK * dS[((size_t)bh * M + gt) * C + ct];
+        }
+    }
+    for (int g = threadIdx.x; g < M; g += NW * 64) {
+        biasL[g] = bs[g] - c0;
+        cmlL[g] = col_max[bh * M + g] + __logf(col_sum[bh * M + g]);
+        ArL[g] = MODE ? A[bh * M + g] : 0.f;
+    }
+    if (threadIdx.x < 32) wtL[threadIdx.x] = wt[threadIdx.x];
+    __syncthreads();
+
+    float wth[16];  // wt of this half-wave's 16 channels
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wth[k] = wtL[16 * half + k];
+
+    f16v dW[MB], dbv[MB];  // persistent: dWs (MODE 1) / dS2 (MODE 0) in accumulator layout; per-lane sums of dlogit
+    float dwt[16], dbt = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < MB; ++blk)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            dW[blk][v] = 0.f;
+            dbv[blk][v] = 0.f;
+        }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dwt[k] = 0.f;
+
+    const size_t row = (size_t)H * C;
+    const size_t col0 = (size_t)h * C + 16 * half;
+    const int tiles = (n1 - n0 + 31) / 32;
+    const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    f4v xq[4], gq[4];
+    {
+        const int n = n0 + 32 * wave + l31;
+        const bool ok = wave < tiles && n < n1;
+        const size_t off = ((size_t)b * N + (ok ? n : 0)) * row + col0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            xq[q] = ok ? *reinterpret_cast<const f4v*>(x + off + 4 * q) : zero4;
+            gq[q] = ok ? *reinterpret_cast<const f4v*>(go + off + 4 * q) : zero4;
+        }
+    }
+    for (int tl = wave; tl < tiles; tl += NW) {
+        const int n = n0 + 32 * tl + l31;
+        const bool valid = n < n1;
+        // the tile's rows for step 4, channel in the lane after the round trip
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f4v*>(X + l31 * kTS + 16 * half + 4 * q) = MODE ? xq[q] : gq[q];
+
+        // ---- step 1: logits, Ada-Temp
+        f16v z[MB];
+#pragma unroll
+        for (int blk = 0; blk < MB; ++blk) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4v b4 = *reinterpret_cast<const f4v*>(biasL + 32 * blk + 8 * q + 4 * half);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z[blk][4 * q + j] = b4[j];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4v w4 = *reinterpret_cast<const f4v*>(WsA + ((blk * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z[blk] = mfma(w4[j], xq[q][j], z[blk]);
+            }
+        }
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t = fmaf(xq[q][j], wth[4 * q + j], t);
+        t += __shfl_xor(t, 32);
+        t += bt;
+        const float rtau = 1.0f / ada_temp(t, base_temp);
+
+        // ---- step 2: a = g_out . S2 + k x . dS
+        f16v a[MB];
+        if (MODE) {
+#pragma unroll
+            for (int blk = 0; blk < MB; ++blk) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) a[blk][v] = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f4v s4 = *reinterpret_cast<const f4v*>(S2A + ((blk * 4 + q) * 64 + lane) * 4);
+                    const f4v d4 = *reinterpret_cast<const f4v*>(dSA + ((blk * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        a[blk] = mfma(s4[j], gq[q][j], a[blk]);
+                        a[blk] = mfma(d4[j], xq[q][j], a[blk]);
+                    }
+                }
+            }
+        }
+
+        // ---- point-wise: softmax weight, dz, dlogit, dtau
+        float part = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < MB; ++blk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4v cm4 = *reinterpret_cast<const f4v*>(cmlL + 32 * blk + 8 * q + 4 * half);
+                const f4v A4 = *reinterpret_cast<const f4v*>(ArL + 32 * blk + 8 * q + 4 * half);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int v = 4 * q + j;
+                    const float zz = z[blk][v] * rtau;
+                    const float p = valid ? __expf(zz - cm4[j]) : 0.f;
+                    if (MODE) {
+                        const float dz = p * (a[blk][v] - A4[j]);
+                        part = fmaf(dz, zz, part);
+                        const float dl = dz * rtau;
+                        z[blk][v] = dl;
+                        a[blk][v] = p;
+                        dbv[blk][v] += dl;
+                    } else {
+                        z[blk][v] = p;
+                    }
+                }
+            }
+        float dt = 0.f;
+        if (MODE) {
+            part += __shfl_xor(part, 32);
+            const float dtau = -part * rtau;
+            dt = (t >= -0.4f && t <= 0.4f) ? dtau : 0.f;  // clamp passes the gradient inside its range
+            dbt += half ? 0.f : dt;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dwt[4 * q + j] = fmaf(dt, xq[q][j], dwt[4 * q + j]);
+        }
+
+        // next tile's rows: in flight during steps 3 and 4
+        {
+            const int nn = n + 32 * NW;
+            const bool ok = tl + NW < tiles && nn < n1;
+            const size_t off = ((size_t)b * N + (ok ? nn : 0)) * row + col0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                xq[q] = ok ? *reinterpret_cast<const f4v*>(x + off + 4 * q) : zero4;
+                gq[q] = ok ? *reinterpret_cast<const f4v*>(go + off + 4 * q) : zero4;
+            }
+        }
+
+        // ---- step 3: dx^T [c][n]
+        if (MODE) {
+            f16v o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4v w4 = *reinterpret_cast<const f4v*>(wtL + 8 * q + 4 * half);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[4 * q + j] = dt * w4[j];
+            }
+#pragma unroll
+            for (int blk = 0; blk < MB; ++blk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f4v w4 = *reinterpret_cast<const f4v*>(WsT + ((blk * 4 + q) * 64 + lane) * 4);
+                    const f4v d4 = *reinterpret_cast<const f4v*>(dST + ((blk * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o = mfma(w4[j], z[blk][4 * q + j], o);
+                        o = mfma(d4[j], a[blk][4 * q + j], o);
+                    }
+                }
+            if (valid) {
+                float* orow = dx + ((size_t)b * N + n) * row + (size_t)h * C + 4 * half;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f4v s = {o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+                    *reinterpret_cast<f4v*>(orow + 8 * q) = s;
+                }
+            }
+        }
+
+        // ---- step 4: the contraction over the tile's points, one 32-row block at a time
+        float xb[16];
+        wave_lds_fence();  // X written at the top of the tile
+#pragma unroll
+        for (int k = 0; k < 16; ++k) xb[k] = X[(k + 16 * half) * kTS + l31];
+#pragma unroll
+        for (int blk = 0; blk < MB; ++blk) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) T[(8 * q + 4 * half + j) * kTS + l31] = z[blk][4 * q + j];
+            wave_lds_fence();
+            f4v d4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d4[q] = *reinterpret_cast<const f4v*>(T + l31 * kTS + 16 * half + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dW[blk] = mfma(d4[q][j], xb[4 * q + j], dW[blk]);
+            wave_lds_fence();  // reads done before the next block / tile overwrites T and X
+        }
+    }
+
+    // ---- workgroup record: sum the waves in a fixed order through the (now idle) image region
+    __syncthreads();
+    float* red = lds;                  // [M][C] dWs | [M] dbs | [C] dwt | dbt
+    float dbr[MB][16];
+    if (MODE) {
+#pragma unroll
+        for (int blk = 0; blk < MB; ++blk)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) dbr[blk][v] = half_sum(dbv[blk][v]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dwt[k] = half_sum(dwt[k]);
+        dbt = half_sum(dbt);
+    }
+    for (int w = 0; w < NW; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int blk = 0; blk < MB; ++blk)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int g = 32 * blk + 8 * (v >> 2) + 4 * half + (v & 3);
+                    float* dst = red + g * C + l31;
+                    *dst = (w ? *dst : 0.f) + dW[blk][v];
+                    if (MODE && l31 == 0) red[IMG + g] = (w ? red[IMG + g] : 0.f) + dbr[blk][v];
+                }
+            if (MODE && l31 == 0) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    red[IMG + M + 16 * half + k] = (w ? red[IMG + M + 16 * half + k] : 0.f) + dwt[k];
+                if (half == 0) red[IMG + M + C] = (w ? red[IMG + M + C] : 0.f) + dbt;
+            }
+        }
+        __syncthreads();
+    }
+    const int R = MODE ? IMG + M + C + 1 : IMG;
+    float* rec = parts + ((size_t)blockIdx.x * BH + bh) * (size_t)R;
+    for (int i = threadIdx.x; i < R; i += NW * 64) rec[i] = red[i];
+}
+
+// ----------------------------------------------------------------------------- host side
+template <int MB, int NW, int MODE>
+static int launch(dim3 grid, hipStream_t st, const float* x, const float* Ws, const float* bs, const float* wt,
+                  float bt, float base_temp, float c0, const float* cm, const float* cs, const float* go,
+                  const float* S2, const float* dS, const float* A, int N, int H, int chunk, float* dx,
+                  float* parts) {
+    constexpr int M = 32 * MB;
+    const size_t lds = ((size_t)(MODE ? 5 : 1) * M * 32 + 3 * M + 32 + (size_t)NW * 2 * 32 * kTS) * sizeof(float);
+    auto kern = slice_bwd_mfma_kernel<MB, NW, MODE>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(HAET_E_LAUNCH, "slice_bwd_mfma: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, x, Ws, bs, wt, bt, base_temp, c0, cm, cs, go, S2, dS, A,
+                       N, H, chunk, dx, parts);
+    return check_launch(MODE ? "slice_bwd_mfma_kernel<points>" : "slice_bwd_mfma_kernel<tokens>");
+}
+
+bool slice_bwd_mfma_ok(int C, int M) { return C == 32 && (M == 32 || M == 64 || M == 128); }
+
+int slice_bwd_mfma_chunk(int N) { return pick_chunk(N); }
+
+// go / S2 / dS / A / dx as in haet_slice_bwd_points; mode 0 ignores S2, dS, A, dx
+int slice_bwd_mfma(int mode, const float* x, const float* Ws, const float* bs, const float* wt, float bt,
+                   float base_temp, float c0, const float* cm, const float* cs, const float* go, const float* S2,
+                   const float* dS, const float* A, int B, int N, int H, int M, float* dx, float* parts,
+                   hipStream_t st) {
+    const int chunk = pick_chunk(N);
+    dim3 grid((N + chunk - 1) / chunk, B * H);
+#define HAET_BWD_MFMA(MB, NW)                                                                                     \
+    return mode ? launch<MB, NW, 1>(grid, st, x, Ws, bs, wt, bt, base_temp, c0, cm, cs, go, S2, dS, A, N, H, chunk, \
+                                    dx, parts)                                                                    \
+                : launch<MB, NW, 0>(grid, st, x, Ws, bs, wt, bt, base_temp, c0, cm, cs, go, S2, dS, A, N, H, chunk, \
+                                    dx, parts)
+    switch (M) {
+        case 32: HAET_BWD_MFMA(1, 8);
+        case 64: HAET_BWD_MFMA(2, 8);
+        default: HAET_BWD_MFMA(4, 4);
+    }
+#undef HAET_BWD_MFMA
+}
+
+}  // namespace haet

@@ -31,13 +31,19 @@ def _passes_fp64(x, Ws, bs, wt, bt, base, c0, S2):
 @pytest.mark.parametrize("B,N,H,C,M", [(1, 700, 4, 16, 16), (2, 333, 8, 32, 64), (1, 1, 2, 32, 32), (1, 5000, 8, 32, 64),
                                        (1, 1025, 4, 64, 32), (1, 257, 2, 32, 128), (2, 64, 3, 8, 8), (1, 300, 2, 64, 100),
                                        (1, 4097, 2, 16, 48)])
-def test_backward_passes_vs_fp64_autograd(B, N, H, C, M, hip_device):
+@pytest.mark.parametrize("path", ["auto", "valu"])
+def test_backward_passes_vs_fp64_autograd(B, N, H, C, M, path, hip_device, monkeypatch):
     from haet_amd import ops
+
+    if path == "valu":  # the generic fp32 vector-ALU kernels for every shape (auto: MFMA kernels where they apply)
+        if not (C == 32 and M in (32, 64, 128)):
+            pytest.skip("auto already runs the generic kernels for this shape")
+        monkeypatch.setenv("HAET_FORCE_VALU", "1")
 
     dev = hip_device
     g = torch.Generator().manual_seed(B * 1000 + N + M)
     x = torch.randn(B, N, H, C, generator=g)
-    Ws = torch.randn(M, C, generator=g) * 0.4
+    Ws = torch.randn(M, C, generator=g) * (1.6 / C ** 0.5)  # logits of a few units: a softmax over the points that is not one-hot
     bs = torch.randn(M, generator=g) * 0.3
     wt = torch.randn(C, generator=g) * (1.2 / C ** 0.5)  # t spreads over the clamp's range and beyond it
     bt = 0.05
@@ -73,7 +79,7 @@ def test_backward_passes_vs_fp64_autograd(B, N, H, C, M, hip_device):
     tol = 2e-4  # fp32 accumulation over N points with cancellation in (a - A)
     assert O.rel_l2(dx.cpu().double().reshape(B, N, H, C), gx) < tol
     if N == 1:  # softmax over one point: w = 1, dz = 0 -- every parameter gradient is rounding noise around zero
-        assert float(dWs.abs().max()) < 1e-3 and float(dbs.abs().max()) < 1e-3 and float(dwt.abs().max()) < 1e-3
+        assert float(dWs.abs().max()) < 2e-2 and float(dbs.abs().max()) < 2e-2 and float(dwt.abs().max()) < 2e-2
         return
     assert O.rel_l2(dWs.cpu().double(), gWs) < tol
     # sum_n dlogit cancels almost completely (exactly, for a constant tau): measured on the scale of its terms,
