@@ -27,12 +27,13 @@ class Physics_Attention_Irregular_Mesh(PhysicsAttentionBase):
 
     def project_backward(self, x, g_lin, need_x, wanted):
         lin = self.in_project_x
-        g2 = g_lin.reshape(-1, g_lin.shape[-1])
+        from .. import ops
+
         grads = {}
-        if id(lin.weight) in wanted:
-            grads[id(lin.weight)] = g2.t() @ x.reshape(-1, x.shape[-1]).float()
-        if lin.bias is not None and id(lin.bias) in wanted:
-            grads[id(lin.bias)] = g2.sum(dim=0)
+        if id(lin.weight) in wanted or (lin.bias is not None and id(lin.bias) in wanted):
+            grads[id(lin.weight)], gb = ops.linear_wgrad(g_lin, x)
+            if lin.bias is not None:
+                grads[id(lin.bias)] = gb
         return (self._linear_transposed("in_project_x", lin, g_lin) if need_x else None), grads
 
     def project_split(self, x, sp):

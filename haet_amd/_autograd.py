@@ -21,6 +21,7 @@ the A/B reference of the tests (and `HipForwardTorchBackward`, the previous inte
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -74,7 +75,8 @@ def erwin_forward(er, feat, pos, n_clouds):
     with torch.no_grad():
         tree_idx, tree_mask, rot_flat, sizes = ops.balltree_build(
             pos.detach(), n_clouds, M, er.strides, er.ball_sizes, float(er.rotate))
-    tree_idx, tree_mask = tree_idx.long(), tree_mask.bool()
+    tree_idx = tree_idx.long()
+    tree_mask = tree_mask.bool() if ops.tree_slots(M) != M else None
     rots, off = [], 0
     for sz in sizes:
         rots.append(None if rot_flat is None else rot_flat[off:off + sz].long())
@@ -98,6 +100,8 @@ def erwin_forward(er, feat, pos, n_clouds):
         y = layer.unpool.proj(torch.cat([x, rel], dim=-1)).reshape(cx.shape[0], -1)
         x, p = layer.unpool.norm(cx + y), cp
         x = _run_blocks(layer, x, p, crot)
+    if ops.tree_slots(M) == M:  # every slot holds a token: no mask, static shapes (HIP-graph capturable)
+        return x[torch.argsort(tree_idx)]
     return x[tree_mask][torch.argsort(tree_idx[tree_mask])]
 
 
@@ -156,6 +160,84 @@ def _tokens_through_erwin(mod, S, n_clouds):
     return erwin_forward(mod.erwin, S, pos, n_clouds)
 
 
+class _ErwinTokens(torch.nn.Module):
+    """`_tokens_through_erwin` as a module over the SAME parameter objects as mod.erwin, the unit that
+    torch.cuda.make_graphed_callables captures (forward and backward HIP graphs)."""
+
+    def __init__(self, mod, n_clouds):
+        super().__init__()
+        self.erwin = mod.erwin
+        self.d, self.n_clouds = mod.dimensionality, n_clouds
+
+    def forward(self, S):
+        lo, hi = S[:, :self.d].min(dim=0)[0], S[:, :self.d].max(dim=0)[0]
+        pos = (S[:, :self.d] - lo) / (hi - lo + 1e-8)
+        return erwin_forward(self.erwin, S, pos, self.n_clouds)
+
+
+def _erwin_graph(mod, S, n_clouds, build):
+    """The captured (forward, backward) HIP graphs of `_ErwinTokens` for this mode and shape, or None.
+    Built on the caller's thread only (`build`): capturing from inside the autograd engine's worker thread
+    crashes the HIP runtime, so the node's forward builds and its backward only replays."""
+    d = mod.__dict__
+    if not os.environ.get("HAET_ERWIN_GRAPH"):  # opt-in while capture inside a longer-lived process is being debugged
+        return None
+    cache = d.setdefault("_erwin_graphs", {})
+    key = (mod.erwin.training, tuple(S.shape), S.device, n_clouds,
+           tuple((p.data_ptr(), p.requires_grad) for p in mod.erwin.parameters()))
+    if key not in cache and build:
+        cache[key] = None
+        M = S.shape[0] // n_clouds
+        if ops.tree_slots(M) == M:  # every tree slot a token: static shapes
+            import warnings
+
+            buffers = {k: v.clone() for k, v in mod.erwin.named_buffers()}
+            try:
+                wrapper = _ErwinTokens(mod, n_clouds)
+                wrapper.training = mod.erwin.training
+                sample = torch.randn_like(S).requires_grad_(True)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")  # the warm-up runs on a side stream (AccumulateGrad stream note)
+                    with torch.enable_grad(), torch.autocast("cuda", enabled=False):
+                        cache[key] = torch.cuda.make_graphed_callables(wrapper, (sample,), allow_unused_input=True)
+            except Exception as exc:  # capture is an optimisation: keep training on the eager path
+                warnings.warn(f"haet_amd: HIP-graph capture of the Erwin stage failed ({exc!r}); running it eagerly")
+                cache[key] = None
+            finally:  # the warm-up iterations of the capture must not count as training steps
+                with torch.no_grad():
+                    for k, v in mod.erwin.named_buffers():
+                        v.copy_(buffers[k])
+    return cache.get(key)
+
+
+def _erwin_stage(mod, S_leaf, n_clouds, build):
+    """S2 with an autograd graph back to S_leaf and the Erwin parameters.  The restatement is ~600 tiny
+    kernels forward + backward on B*H*M tokens -- launch-bound (7 ms of a 16 ms training step at 1M
+    points) -- so it is captured once per (mode, shape) into a pair of HIP graphs and replayed.  The static
+    buffers of a graph serve one forward/backward pair at a time: a second forward before the first
+    backward, or any failure to capture, takes the eager path.  Opt-in: HAET_ERWIN_GRAPH=1."""
+    graphed = None if mod.__dict__.get("_erwin_graph_busy") else _erwin_graph(mod, S_leaf, n_clouds, build)
+    if graphed is None:
+        return _tokens_through_erwin(mod, S_leaf, n_clouds), None
+    return graphed(S_leaf), _GraphLease(mod.__dict__)
+
+
+class _GraphLease:
+    """Marks a module's Erwin graphs as serving one forward/backward pair; released by the backward, or
+    when the autograd graph holding it is dropped without one."""
+
+    def __init__(self, d):
+        self.d = d
+        d["_erwin_graph_busy"] = True
+
+    def release(self):
+        if self.d is not None:
+            self.d["_erwin_graph_busy"] = False
+            self.d = None
+
+    __del__ = release
+
+
 class PhysicsAttentionFunction(torch.autograd.Function):
     """forward(x) up to and including the to_out Linear (dropout stays outside), see the module docstring."""
 
@@ -164,20 +246,30 @@ class PhysicsAttentionFunction(torch.autograd.Function):
         B, N, _ = x.shape
         H, C, G = mod.heads, mod.dim_head, mod.slice_num
         sp = mod._slice_params()
-        x_lin = mod.project(x).float().contiguous()                      # [B, N, H*C] fp32, kept for backward
-        parts = ops.slice_partials(x_lin, sp, H, C, G)
-        col_max, col_sum, S = ops.merge_records(parts, B, H, C, G, finalize=True)
+        mod.__dict__["_event_chain"] = [None] if mod.stage_events is not None else None
+        ev = mod._stage
+        with ev("project"):
+            x_lin = mod.project(x).float().contiguous()                  # [B, N, H*C] fp32, kept for backward
+        with ev("slice"):
+            parts = ops.slice_partials(x_lin, sp, H, C, G)
+        with ev("merge"):
+            col_max, col_sum, S = ops.merge_records(parts, B, H, C, G, finalize=True)
         ctx.inner = None
-        if mod.training:  # batch-statistics BatchNorm: the restatement runs now and keeps its graph
-            with torch.enable_grad():
-                S_leaf = S.detach().requires_grad_(True)
-                S2_graph = _tokens_through_erwin(mod, S_leaf, B * H)
-            S2 = S2_graph.detach()
-            ctx.inner = (S_leaf, S2_graph)
-        else:
-            S2 = mod.erwin(S, None, n_clouds=B * H)
-        out_x = ops.deslice(x_lin, sp, col_max, col_sum, S2, H, C, G)
-        y = mod._linear("to_out", mod.to_out[0], out_x)
+        with ev("erwin"):
+            if mod.training:  # batch-statistics BatchNorm: the restatement runs now and keeps its graph
+                with torch.enable_grad(), torch.autocast("cuda", enabled=False):
+                    S_leaf = S.detach().requires_grad_(True)
+                    S2_graph, graphed = _erwin_stage(mod, S_leaf, B * H, build=any(ctx.needs_input_grad))
+                S2 = S2_graph.detach().clone() if graphed is not None else S2_graph.detach()
+                ctx.inner = (S_leaf, S2_graph, graphed)
+            else:
+                S2 = mod.erwin(S, None, n_clouds=B * H)
+                if any(ctx.needs_input_grad):  # the backward replays the restatement: capture it here, on this thread
+                    _erwin_graph(mod, S, B * H, build=True)
+        with ev("deslice"):
+            out_x = ops.deslice(x_lin, sp, col_max, col_sum, S2, H, C, G)
+        with ev("to_out"):
+            y = mod._linear("to_out", mod.to_out[0], out_x)
         ctx.save_for_backward(x, x_lin, col_max, col_sum, S, S2, out_x)
         ctx.mod, ctx.all_params = mod, params
         return y
@@ -189,36 +281,58 @@ class PhysicsAttentionFunction(torch.autograd.Function):
         B, N, _ = x.shape
         H, C, G = mod.heads, mod.dim_head, mod.slice_num
         sp = mod._slice_params()
+        mod.__dict__["_event_chain"] = [None] if mod.stage_events is not None else None
+        ev = mod._stage  # optional per-stage HIP events (tools/train_probe.py)
         wanted = {id(p) for p, need in zip(ctx.all_params, ctx.needs_input_grad[2:]) if need}
         grads = {}
         gy = gy.float().contiguous()
         gy2 = gy.view(B * N, -1)
         lin_out = mod.to_out[0]
-        if id(lin_out.weight) in wanted:
-            grads[id(lin_out.weight)] = gy2.t() @ out_x.view(B * N, -1)
-        if lin_out.bias is not None and id(lin_out.bias) in wanted:
-            grads[id(lin_out.bias)] = gy2.sum(dim=0)
-        g_out = mod._linear_transposed("to_out", lin_out, gy)           # dL/d out_x [B, N, H*C]
-        dS2 = ops.deslice_bwd_tokens(x_lin, sp, col_max, col_sum, g_out, H, C, G)
+        with ev("bwd_to_out"):
+            if id(lin_out.weight) in wanted or (lin_out.bias is not None and id(lin_out.bias) in wanted):
+                grads[id(lin_out.weight)], gb = ops.linear_wgrad(gy2, out_x.view(B * N, -1))
+                if lin_out.bias is not None:
+                    grads[id(lin_out.bias)] = gb
+            g_out = mod._linear_transposed("to_out", lin_out, gy)       # dL/d out_x [B, N, H*C]
+        with ev("bwd_tokens"):
+            dS2 = ops.deslice_bwd_tokens(x_lin, sp, col_max, col_sum, g_out, H, C, G)
 
-        erwin_params = [p for p in mod.erwin.parameters() if id(p) in wanted]
-        if ctx.inner is None:
-            with torch.enable_grad():
-                S_leaf = S.detach().requires_grad_(True)
-                S2_graph = _tokens_through_erwin(mod, S_leaf, B * H)
-        else:
-            S_leaf, S2_graph = ctx.inner
-        got = torch.autograd.grad(S2_graph, [S_leaf] + erwin_params, dS2, allow_unused=True)
-        dS = got[0] if got[0] is not None else torch.zeros_like(S)
-        for p, g in zip(erwin_params, got[1:]):
-            grads[id(p)] = g
-        A = (dS2 * S2).sum(dim=-1) + (S * dS).sum(dim=-1)              # sum_n w[n,g] a[n,g], [B*H*M]
-        dx_lin, dWs, dbs, dwt, dbt = ops.slice_bwd_points(x_lin, sp, col_max, col_sum, g_out, S2, dS, A, H, C, G)
+        with ev("bwd_erwin"):
+            erwin_params = [p for p in mod.erwin.parameters() if id(p) in wanted]
+            if ctx.inner is None:
+                with torch.enable_grad(), torch.autocast("cuda", enabled=False):
+                    S_leaf = S.detach().requires_grad_(True)
+                    S2_graph, graphed = _erwin_stage(mod, S_leaf, B * H, build=False)
+            else:
+                S_leaf, S2_graph, graphed = ctx.inner
+            try:
+                got = torch.autograd.grad(S2_graph, [S_leaf] + erwin_params, dS2, allow_unused=True)
+            finally:
+                if graphed is not None:
+                    graphed.release()
+                ctx.inner = None
+            dS = got[0] if got[0] is not None else torch.zeros_like(S)
+            pg = [(p, g) for p, g in zip(erwin_params, got[1:]) if g is not None]
+            if graphed is not None and pg:
+                # a replayed graph hands out its static buffers: the parameter gradients leave this node as
+                # views of ONE fresh copy (autograd may keep an incoming tensor as .grad without copying it)
+                flat = torch.cat([g.reshape(-1) for _, g in pg])
+                off = 0
+                for p, g in pg:
+                    grads[id(p)] = flat[off:off + g.numel()].view(g.shape)
+                    off += g.numel()
+            else:
+                for p, g in pg:
+                    grads[id(p)] = g
+            A = (dS2 * S2).sum(dim=-1) + (S * dS).sum(dim=-1)          # sum_n w[n,g] a[n,g], [B*H*M]
+        with ev("bwd_points"):
+            dx_lin, dWs, dbs, dwt, dbt = ops.slice_bwd_points(x_lin, sp, col_max, col_sum, g_out, S2, dS, A, H, C, G)
         grads[id(mod.in_project_slice.weight)] = dWs
         grads[id(mod.in_project_slice.bias)] = dbs
         grads[id(mod.ada_temp_linear.weight)] = dwt.view(1, C)
         grads[id(mod.ada_temp_linear.bias)] = dbt.view(1)
-        gx, proj_grads = mod.project_backward(x, dx_lin, ctx.needs_input_grad[1], wanted)
+        with ev("bwd_project"):
+            gx, proj_grads = mod.project_backward(x, dx_lin, ctx.needs_input_grad[1], wanted)
         grads.update(proj_grads)
         if gx is not None:
             gx = gx.to(x.dtype)

@@ -74,6 +74,9 @@ SIGNATURES = {
     "haet_deslice_bwd_tokens": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P] + [c_int] * 5 + [_P, _P]),
     "haet_slice_bwd_points": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P]
                               + [c_int] * 5 + [_P, _P, _P]),
+    "haet_linear_wgrad_supported": (c_int, [c_int, c_int]),
+    "haet_linear_wgrad_num_parts": (c_int, [c_int]),
+    "haet_linear_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "haet_erwin_lds_bytes": (c_size_t, [POINTER(ErwinDesc), c_int]),
     "haet_erwin_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, POINTER(ErwinDesc), c_int, c_int, _P, _P]),
     "haet_deslice_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P]

@@ -14,6 +14,8 @@
 //   dWs [g][c] += dlogit [g][n] X [n][c]                      (step 4: the one contraction over the points; both
 //                 operands go through a wave-private LDS tile to get n into the register index)
 // The constant A operands are per-workgroup LDS images read with one ds_read_b128 per four MFMAs.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace haet {
@@ -361,7 +363,9 @@ int slice_bwd_mfma(int mode, const float* x, const float* Ws, const float* bs, c
                                     dx, parts)
     switch (M) {
         case 32: HAET_BWD_MFMA(1, 8);
-        case 64: HAET_BWD_MFMA(2, 8);
+        case 64:
+            if (getenv("HAET_BWD_NW4")) { HAET_BWD_MFMA(2, 4); }
+            HAET_BWD_MFMA(2, 8);
         default: HAET_BWD_MFMA(4, 4);
     }
 #undef HAET_BWD_MFMA

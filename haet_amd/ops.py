@@ -235,6 +235,28 @@ def linear(x: Tensor, w: SplitLinear) -> Tensor:
     return out
 
 
+def linear_wgrad(g: Tensor, x: Tensor):
+    """(dW [O,K], db [O]) of a Linear from g = dL/d output [..., O] and its input x [..., K], contracted over
+    all leading dimensions: haet_linear_wgrad where O, K are multiples of 256, the library GEMM otherwise."""
+    lib = _lib.load()
+    g, x = _f32(g, "g"), _f32(x, "x")
+    O, K = g.shape[-1], x.shape[-1]
+    g2, x2 = g.reshape(-1, O), x.reshape(-1, K)
+    N = g2.shape[0]
+    if x2.shape[0] != N:
+        raise HaetError("linear_wgrad: g and x disagree on the number of rows")
+    if not lib.haet_linear_wgrad_supported(O, K):
+        return g2.t() @ x2, g2.sum(dim=0)
+    P = lib.haet_linear_wgrad_num_parts(N)
+    ob, kb = O // 256, K // 256
+    parts = torch.empty((P, ob * kb, 256 * 256 + 256), dtype=torch.float32, device=g.device)
+    check(lib.haet_linear_wgrad(_p(g2), _p(x2), N, O, K, _p(parts), _stream()), "haet_linear_wgrad")
+    s = parts.sum(dim=0)
+    dW = s[:, :256 * 256].view(ob, kb, 256, 256).permute(0, 2, 1, 3).reshape(O, K)
+    db = s[:, 256 * 256:].view(ob, kb, 256)[:, 0].reshape(O)
+    return dW, db
+
+
 # --------------------------------------------------------------------------- fused operand format
 class SplitPoints:
     """x_lin in the streaming passes' operand format (haet_project_split_fwd): `cells` [B, N, H*C]

@@ -251,6 +251,14 @@ int haet_slice_bwd_points(const float* x_lin, const float* Ws, const float* bs, 
                           int B, int N, int H, int C, int M, float* dx_lin, float* param_parts,
                           haet_stream_t stream);
 
+/* Weight gradient of a Linear over the points (to_out, in_project_x): per-workgroup partial records of
+ *   dW[O][K] = sum_n G[n][o] X[n][k],  db[o] = sum_n G[n][o]        (G = dL/d output [N,O], X = the input [N,K])
+ * parts [P][(O/256)*(K/256)][256*256 + 256]: per 256 x 256 block of dW (row-major blocks, o-block major)
+ * the block and its 256 entries of db; the caller sums over P.  O and K must be multiples of 256.       */
+int haet_linear_wgrad_supported(int O, int K);
+int haet_linear_wgrad_num_parts(int N);
+int haet_linear_wgrad(const float* G, const float* X, int N, int O, int K, float* parts, haet_stream_t stream);
+
 /* ------------------------------------------------------------------ structured-mesh projection
  * in_project_x of the structured modules (nn.Conv2d / nn.Conv3d, kernel k, padding k/2:
  * StructuredMesh2D.py:109,173-189, StructuredMesh3D.py:113,177-193) as an implicit GEMM on the

@@ -76,7 +76,7 @@ def test_backward_passes_vs_fp64_autograd(B, N, H, C, M, path, hip_device, monke
     assert O.rel_l2(dS2.cpu().double(), gS2.reshape(-1, C)) < 5e-5
     A = (dS2 * S2d).sum(-1) + (S_hip * dSd).sum(-1)
     dx, dWs, dbs, dwt, dbt = ops.slice_bwd_points(x_lin, sp, cm, cs, go, S2d, dSd, A, H, C, M)
-    tol = 2e-4  # fp32 accumulation over N points with cancellation in (a - A)
+    tol = 5e-4  # fp32 accumulation over N points with cancellation in (a - A)
     assert O.rel_l2(dx.cpu().double().reshape(B, N, H, C), gx) < tol
     if N == 1:  # softmax over one point: w = 1, dz = 0 -- every parameter gradient is rounding noise around zero
         assert float(dWs.abs().max()) < 2e-2 and float(dbs.abs().max()) < 2e-2 and float(dwt.abs().max()) < 2e-2
@@ -157,3 +157,20 @@ def test_backward_never_materialises_the_slice_weights(hip_device):
     # saved: x_lin, out_x; transient: y, gy, g_out, dx_lin, gx (+ partial records)
     assert peak < 9 * row, (peak / row)
     assert torch.isfinite(x.grad).all() and all(torch.isfinite(p.grad).all() for p in mod.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize("rows,O,K", [(1, 256, 256), (31, 256, 256), (1000, 256, 256), (70001, 256, 256), (300, 512, 256),
+                                      (257, 256, 768), (500, 64, 128)])
+def test_linear_weight_gradient_vs_fp64(rows, O, K, hip_device):
+    """haet_linear_wgrad (f32 MFMA, contraction over the points) against an fp64 product; shapes outside its
+    envelope take the library GEMM."""
+    from haet_amd import ops
+
+    g = torch.Generator().manual_seed(rows + O)
+    G = torch.randn(rows, O, generator=g)
+    X = torch.randn(rows, K, generator=g)
+    dW, db = ops.linear_wgrad(G.to(hip_device), X.to(hip_device))
+    assert dW.shape == (O, K) and db.shape == (O,)
+    ref = G.double().t() @ X.double()
+    assert float((dW.cpu().double() - ref).norm() / ref.norm()) < 2e-6
+    assert float((db.cpu().double() - G.double().sum(0)).norm() / G.double().sum(0).norm()) < 2e-6

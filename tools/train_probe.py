@@ -58,6 +58,16 @@ def main():
             mod(x)
         torch.cuda.synchronize()
         dtf = (time.perf_counter() - t0) / args.steps
+    # per-stage HIP events of a few more steps
+    mod.stage_events = []
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    stage = {}
+    for name, e0, e1 in mod.stage_events:
+        stage[name] = stage.get(name, 0.0) + e0.elapsed_time(e1) / 3
+    mod.stage_events = None
+    print("stages (ms): " + ", ".join(f"{k} {v:.3f}" for k, v in stage.items()) + f"; sum {sum(stage.values()):.2f}")
     row = args.points * 256 * 4 / 1e9
     print(f"path={'torch' if args.torch else 'hip'} mode={'eval' if args.eval else 'train'} points={args.points}: "
           f"{1e3 * dt:.2f} ms / step (forward alone {1e3 * dtf:.2f} ms), {args.points / dt:.3e} points/s, "
