@@ -31,8 +31,9 @@ from . import ops
 
 # --------------------------------------------------------------------------- Erwin (erwin_flash.py:138-195)
 def _rms_norm(x, weight):
-    eps = torch.finfo(x.dtype).eps  # nn.RMSNorm(dim) with eps=None (components/layers.py:25-26)
-    return x * torch.rsqrt(x.pow(2).mean(dim=-1, keepdim=True) + eps) * weight
+    # nn.RMSNorm(dim) with eps=None -> finfo(dtype).eps (components/layers.py:25-26); the fused op is one
+    # kernel forward and one backward instead of ~six and ~twelve (the stage is launch-bound)
+    return F.rms_norm(x, (x.shape[-1],), weight, None)
 
 
 def _ball_msa(att, x, pos):
@@ -160,84 +161,6 @@ def _tokens_through_erwin(mod, S, n_clouds):
     return erwin_forward(mod.erwin, S, pos, n_clouds)
 
 
-class _ErwinTokens(torch.nn.Module):
-    """`_tokens_through_erwin` as a module over the SAME parameter objects as mod.erwin, the unit that
-    torch.cuda.make_graphed_callables captures (forward and backward HIP graphs)."""
-
-    def __init__(self, mod, n_clouds):
-        super().__init__()
-        self.erwin = mod.erwin
-        self.d, self.n_clouds = mod.dimensionality, n_clouds
-
-    def forward(self, S):
-        lo, hi = S[:, :self.d].min(dim=0)[0], S[:, :self.d].max(dim=0)[0]
-        pos = (S[:, :self.d] - lo) / (hi - lo + 1e-8)
-        return erwin_forward(self.erwin, S, pos, self.n_clouds)
-
-
-def _erwin_graph(mod, S, n_clouds, build):
-    """The captured (forward, backward) HIP graphs of `_ErwinTokens` for this mode and shape, or None.
-    Built on the caller's thread only (`build`): capturing from inside the autograd engine's worker thread
-    crashes the HIP runtime, so the node's forward builds and its backward only replays."""
-    d = mod.__dict__
-    if not os.environ.get("HAET_ERWIN_GRAPH"):  # opt-in while capture inside a longer-lived process is being debugged
-        return None
-    cache = d.setdefault("_erwin_graphs", {})
-    key = (mod.erwin.training, tuple(S.shape), S.device, n_clouds,
-           tuple((p.data_ptr(), p.requires_grad) for p in mod.erwin.parameters()))
-    if key not in cache and build:
-        cache[key] = None
-        M = S.shape[0] // n_clouds
-        if ops.tree_slots(M) == M:  # every tree slot a token: static shapes
-            import warnings
-
-            buffers = {k: v.clone() for k, v in mod.erwin.named_buffers()}
-            try:
-                wrapper = _ErwinTokens(mod, n_clouds)
-                wrapper.training = mod.erwin.training
-                sample = torch.randn_like(S).requires_grad_(True)
-                with warnings.catch_warnings():
-                    warnings.simplefilter("ignore")  # the warm-up runs on a side stream (AccumulateGrad stream note)
-                    with torch.enable_grad(), torch.autocast("cuda", enabled=False):
-                        cache[key] = torch.cuda.make_graphed_callables(wrapper, (sample,), allow_unused_input=True)
-            except Exception as exc:  # capture is an optimisation: keep training on the eager path
-                warnings.warn(f"haet_amd: HIP-graph capture of the Erwin stage failed ({exc!r}); running it eagerly")
-                cache[key] = None
-            finally:  # the warm-up iterations of the capture must not count as training steps
-                with torch.no_grad():
-                    for k, v in mod.erwin.named_buffers():
-                        v.copy_(buffers[k])
-    return cache.get(key)
-
-
-def _erwin_stage(mod, S_leaf, n_clouds, build):
-    """S2 with an autograd graph back to S_leaf and the Erwin parameters.  The restatement is ~600 tiny
-    kernels forward + backward on B*H*M tokens -- launch-bound (7 ms of a 16 ms training step at 1M
-    points) -- so it is captured once per (mode, shape) into a pair of HIP graphs and replayed.  The static
-    buffers of a graph serve one forward/backward pair at a time: a second forward before the first
-    backward, or any failure to capture, takes the eager path.  Opt-in: HAET_ERWIN_GRAPH=1."""
-    graphed = None if mod.__dict__.get("_erwin_graph_busy") else _erwin_graph(mod, S_leaf, n_clouds, build)
-    if graphed is None:
-        return _tokens_through_erwin(mod, S_leaf, n_clouds), None
-    return graphed(S_leaf), _GraphLease(mod.__dict__)
-
-
-class _GraphLease:
-    """Marks a module's Erwin graphs as serving one forward/backward pair; released by the backward, or
-    when the autograd graph holding it is dropped without one."""
-
-    def __init__(self, d):
-        self.d = d
-        d["_erwin_graph_busy"] = True
-
-    def release(self):
-        if self.d is not None:
-            self.d["_erwin_graph_busy"] = False
-            self.d = None
-
-    __del__ = release
-
-
 class PhysicsAttentionFunction(torch.autograd.Function):
     """forward(x) up to and including the to_out Linear (dropout stays outside), see the module docstring."""
 
@@ -259,13 +182,11 @@ class PhysicsAttentionFunction(torch.autograd.Function):
             if mod.training:  # batch-statistics BatchNorm: the restatement runs now and keeps its graph
                 with torch.enable_grad(), torch.autocast("cuda", enabled=False):
                     S_leaf = S.detach().requires_grad_(True)
-                    S2_graph, graphed = _erwin_stage(mod, S_leaf, B * H, build=any(ctx.needs_input_grad))
-                S2 = S2_graph.detach().clone() if graphed is not None else S2_graph.detach()
-                ctx.inner = (S_leaf, S2_graph, graphed)
+                    S2_graph = _tokens_through_erwin(mod, S_leaf, B * H)
+                S2 = S2_graph.detach()
+                ctx.inner = (S_leaf, S2_graph)
             else:
                 S2 = mod.erwin(S, None, n_clouds=B * H)
-                if any(ctx.needs_input_grad):  # the backward replays the restatement: capture it here, on this thread
-                    _erwin_graph(mod, S, B * H, build=True)
         with ev("deslice"):
             out_x = ops.deslice(x_lin, sp, col_max, col_sum, S2, H, C, G)
         with ev("to_out"):
@@ -302,28 +223,14 @@ class PhysicsAttentionFunction(torch.autograd.Function):
             if ctx.inner is None:
                 with torch.enable_grad(), torch.autocast("cuda", enabled=False):
                     S_leaf = S.detach().requires_grad_(True)
-                    S2_graph, graphed = _erwin_stage(mod, S_leaf, B * H, build=False)
+                    S2_graph = _tokens_through_erwin(mod, S_leaf, B * H)
             else:
-                S_leaf, S2_graph, graphed = ctx.inner
-            try:
-                got = torch.autograd.grad(S2_graph, [S_leaf] + erwin_params, dS2, allow_unused=True)
-            finally:
-                if graphed is not None:
-                    graphed.release()
-                ctx.inner = None
+                S_leaf, S2_graph = ctx.inner
+            got = torch.autograd.grad(S2_graph, [S_leaf] + erwin_params, dS2, allow_unused=True)
+            ctx.inner = None
             dS = got[0] if got[0] is not None else torch.zeros_like(S)
-            pg = [(p, g) for p, g in zip(erwin_params, got[1:]) if g is not None]
-            if graphed is not None and pg:
-                # a replayed graph hands out its static buffers: the parameter gradients leave this node as
-                # views of ONE fresh copy (autograd may keep an incoming tensor as .grad without copying it)
-                flat = torch.cat([g.reshape(-1) for _, g in pg])
-                off = 0
-                for p, g in pg:
-                    grads[id(p)] = flat[off:off + g.numel()].view(g.shape)
-                    off += g.numel()
-            else:
-                for p, g in pg:
-                    grads[id(p)] = g
+            for p, g in zip(erwin_params, got[1:]):
+                grads[id(p)] = g
             A = (dS2 * S2).sum(dim=-1) + (S * dS).sum(dim=-1)          # sum_n w[n,g] a[n,g], [B*H*M]
         with ev("bwd_points"):
             dx_lin, dWs, dbs, dwt, dbt = ops.slice_bwd_points(x_lin, sp, col_max, col_sum, g_out, S2, dS, A, H, C, G)

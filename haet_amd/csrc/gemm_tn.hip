@@ -2,8 +2,9 @@
 // (to_out and in_project_x of the Physics_Attention modules; the reference gets them from torch autograd,
 // exp_airfoil.py:249-255).  N is ~1e6, O = K = 256: an output-stationary GEMM whose contraction runs
 // over the ROW index of both operands, so the f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32 products)
-// takes both operands straight from global memory, the output column in the lane: no LDS, no transposes.
-// A workgroup (8 waves, 2 x 4) keeps a 256 x 256 block of dW in its accumulators over its chunk of rows
+// takes both operands as plain row-major tiles, the output column in the lane: no transposes.  A workgroup
+// (8 waves, 2 x 4) keeps a 256 x 256 block of dW in its accumulators over its chunk of rows, stages 32-row
+// tiles of both operands through a double-buffered LDS copy (each element leaves HBM / L2 once per workgroup)
 // and writes one partial record; the caller sums the records.
 #include "common.h"
 
@@ -23,13 +24,18 @@ int wgrad_chunk(int N) {  // rows per workgroup: ~256 workgroups, whole 32-row t
 
 }  // namespace
 
+// LDS: two buffers of one 32-row tile of both operands, [G 32 x 256 | X 32 x 256] floats = 64 KB each.
+constexpr int kTileFloats = 2 * kRowsTile * 256;
+
 __global__ __launch_bounds__(512) void gemm_tn_f32_kernel(const float* __restrict__ G, const float* __restrict__ X,
                                                           int N, int O, int K, int chunk,
                                                           float* __restrict__ parts) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int kblocks = K / 256;
-    const int o0 = (blockIdx.y / kblocks) * 256 + 128 * (wave >> 2);  // this wave's 128 x 64 block of dW
-    const int k0 = (blockIdx.y % kblocks) * 256 + 64 * (wave & 3);
+    const int ob0 = (blockIdx.y / kblocks) * 256, kb0 = (blockIdx.y % kblocks) * 256;  // this workgroup's block of dW
+    const int ol = 128 * (wave >> 2), kl = 64 * (wave & 3);                             // this wave's 128 x 64 part
     const int n0 = blockIdx.x * chunk, n1 = min(N, n0 + chunk);
 
     f16v acc[4][2];
@@ -41,56 +47,60 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_kernel(const float* __restric
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[ob][kb][v] = 0.f;
 
-    const float* gp = G + o0 + l31;
-    const float* xp = X + k0 + l31;
-    // A 32-row tile is two groups of 8 k-pairs; k-pair kk of the instruction = rows nb + kk (lanes 0-31) and
-    // nb + kk + 16 (lanes 32-63) of both operands.  The loads of one group are in flight while the 64 MFMAs of
-    // the other run (4096 cycles per SIMD: more than the memory latency); they are unconditional (rows past the
-    // chunk read row n0 and select 0) so that the waits stay counted.
-    auto load_group = [&](int nb, int grp, float (&a)[4][8], float (&b)[2][8]) {
+    // staging: thread t moves float4 column t % 64 of rows t / 64 + 8 i (i < 4) of both operands -- whole 1-KB
+    // rows per 64 lanes from global, consecutive 16-B cells into LDS
+    const int sr = tid >> 6, sc = (tid & 63) * 4;
+    const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    f4v sg[4], sx[4];
+    auto fetch = [&](int nb) {
 #pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) {
-            const int n = nb + 8 * grp + k8 + 16 * half;
+        for (int i = 0; i < 4; ++i) {
+            const int n = nb + sr + 8 * i;
             const bool ok = n < n1;
-            const size_t r = ok ? (size_t)n : (size_t)n0;
-#pragma unroll
-            for (int ob = 0; ob < 4; ++ob) {
-                const float v = gp[r * O + 32 * ob];
-                a[ob][k8] = ok ? v : 0.f;
-            }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const float v = xp[r * K + 32 * kb];
-                b[kb][k8] = ok ? v : 0.f;
-            }
+            const size_t r = ok ? (size_t)n : (size_t)n0;  // unconditional loads: the waits stay counted
+            const f4v g4 = *reinterpret_cast<const f4v*>(G + r * O + ob0 + sc);
+            const f4v x4 = *reinterpret_cast<const f4v*>(X + r * K + kb0 + sc);
+            sg[i] = ok ? g4 : zero4;
+            sx[i] = ok ? x4 : zero4;
         }
     };
-    auto mma_group = [&](const float (&a)[4][8], const float (&b)[2][8]) {
+    auto stash = [&](float* buf) {
 #pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8)
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f4v*>(buf + (sr + 8 * i) * 256 + sc) = sg[i];
+            *reinterpret_cast<f4v*>(buf + kRowsTile * 256 + (sr + 8 * i) * 256 + sc) = sx[i];
+        }
+    };
+    fetch(n0);
+    stash(lds);
+    __syncthreads();
+    int cur = 0;
+    for (int nb = n0; nb < n1; nb += kRowsTile) {
+        fetch(nb + kRowsTile);  // in flight under this tile's 128 MFMAs
+        const float* gs = lds + cur * kTileFloats + ol + l31;
+        const float* xs = lds + cur * kTileFloats + kRowsTile * 256 + kl + l31;
+        // k-pair kk of the instruction = rows kk (lanes 0-31) and kk + 16 (lanes 32-63) of the tile, both operands
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[2];
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) a[ob] = gs[(kk + 16 * half) * 256 + 32 * ob];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) b[kb] = xs[(kk + 16 * half) * 256 + 32 * kb];
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) {
-                dbl[ob] += a[ob][k8];
+                dbl[ob] += a[ob];
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
-                    acc[ob][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ob][k8], b[kb][k8], acc[ob][kb], 0, 0, 0);
+                    acc[ob][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ob], b[kb], acc[ob][kb], 0, 0, 0);
             }
-    };
-    float a0[4][8], b0[2][8], a1[4][8], b1[2][8];
-    load_group(n0, 0, a0, b0);
-    for (int nb = n0; nb < n1; nb += kRowsTile) {
-        load_group(nb, 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_group(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_group(nb + kRowsTile, 0, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_group(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
+        }
+        cur ^= 1;
+        stash(lds + cur * kTileFloats);  // last read as tile nb - 32, before the barrier that ended that iteration
+        __syncthreads();
     }
 
     float* rec = parts + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (size_t)(256 * 256 + 256);
-    const int ol = 128 * (wave >> 2), kl = 64 * (wave & 3);
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
 #pragma unroll
@@ -124,6 +134,14 @@ extern "C" int haet_linear_wgrad(const float* G, const float* X, int N, int O, i
         return fail(HAET_E_ARG, "linear_wgrad: N=%d O=%d K=%d unsupported (O, K multiples of 256)", N, O, K);
     const int chunk = wgrad_chunk(N);
     dim3 grid((N + chunk - 1) / chunk, (O / 256) * (K / 256));
-    hipLaunchKernelGGL(gemm_tn_f32_kernel, grid, dim3(512), 0, as_stream(stream), G, X, N, O, K, chunk, parts);
+    const size_t lds = 2 * (size_t)kTileFloats * sizeof(float);  // 128 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f32_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(HAET_E_LAUNCH, "linear_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_f32_kernel, grid, dim3(512), lds, as_stream(stream), G, X, N, O, K, chunk, parts);
     return check_launch("gemm_tn_f32_kernel");
 }
