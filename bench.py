@@ -165,10 +165,45 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res.update(cpu_leg(mod, x_full, out))
+        if world == 1:
+            res.update(train_leg(mod, x))
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def train_leg(mod, x, steps=5):
+    """Extra, not the headline metric: one training step of the same module on the same cloud (train mode,
+    forward + backward through the hand-written backward kernels).  Never fails the bench."""
+    try:
+        state = {k: v.clone() for k, v in mod.state_dict().items()}
+        mod.train()
+        xg = x.detach().requires_grad_(True)
+        gout = torch.randn_like(x)
+
+        def step():
+            mod.zero_grad(set_to_none=True)
+            xg.grad = None
+            mod(xg).backward(gout)
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        peak = torch.cuda.max_memory_allocated() / 1e9
+        mod.eval()
+        mod.zero_grad(set_to_none=True)
+        mod.load_state_dict(state)
+        return {"train_step": {"ms_per_step": 1e3 * dt, "points_per_s": x.shape[1] / dt, "steps": steps,
+                               "what": "forward + backward of the module, train mode, fp32 gradients",
+                               "peak_memory_gb": round(peak, 2)}}
+    except Exception as exc:  # noqa: BLE001 -- informational leg only
+        return {"train_step": {"error": repr(exc)}}
 
 
 def pmc_traffic_bytes(kernel, n_points):

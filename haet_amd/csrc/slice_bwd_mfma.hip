@@ -14,8 +14,6 @@
 //   dWs [g][c] += dlogit [g][n] X [n][c]                      (step 4: the one contraction over the points; both
 //                 operands go through a wave-private LDS tile to get n into the register index)
 // The constant A operands are per-workgroup LDS images read with one ds_read_b128 per four MFMAs.
-#include <cstdlib>
-
 #include "common.h"
 
 namespace haet {
@@ -99,21 +97,16 @@ __global__ __launch_bounds__(NW * 64) void slice_bwd_mfma_kernel(
     if (threadIdx.x < 32) wtL[threadIdx.x] = wt[threadIdx.x];
     __syncthreads();
 
-    float wth[16];  // wt of this half-wave's 16 channels
+    // persistent: dWs (MODE 1) / dS2 (MODE 0) in accumulator layout; dbs of row g = 32 blk + lane % 32 (this
+    // half-wave's 16 points of every tile); dwt of channel lane % 32 (ditto); dbt of point column lane % 32
+    f16v dW[MB];
+    float dbr[MB], dwt = 0.f, dbt = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) wth[k] = wtL[16 * half + k];
-
-    f16v dW[MB], dbv[MB];  // persistent: dWs (MODE 1) / dS2 (MODE 0) in accumulator layout; per-lane sums of dlogit
-    float dwt[16], dbt = 0.f;
+    for (int blk = 0; blk < MB; ++blk) {
+        dbr[blk] = 0.f;
 #pragma unroll
-    for (int blk = 0; blk < MB; ++blk)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            dW[blk][v] = 0.f;
-            dbv[blk][v] = 0.f;
-        }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) dwt[k] = 0.f;
+        for (int v = 0; v < 16; ++v) dW[blk][v] = 0.f;
+    }
 
     const size_t row = (size_t)H * C;
     const size_t col0 = (size_t)h * C + 16 * half;
@@ -158,9 +151,11 @@ __global__ __launch_bounds__(NW * 64) void slice_bwd_mfma_kernel(
         }
         float t = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
+            const f4v w4 = *reinterpret_cast<const f4v*>(wtL + 16 * half + 4 * q);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) t = fmaf(xq[q][j], wth[4 * q + j], t);
+            for (int j = 0; j < 4; ++j) t = fmaf(xq[q][j], w4[j], t);
+        }
         t += __shfl_xor(t, 32);
         t += bt;
         const float rtau = 1.0f / ada_temp(t, base_temp);
@@ -204,7 +199,6 @@ __global__ __launch_bounds__(NW * 64) void slice_bwd_mfma_kernel(
                         const float dl = dz * rtau;
                         z[blk][v] = dl;
                         a[blk][v] = p;
-                        dbv[blk][v] += dl;
                     } else {
                         z[blk][v] = p;
                     }
@@ -216,10 +210,7 @@ __global__ __launch_bounds__(NW * 64) void slice_bwd_mfma_kernel(
             const float dtau = -part * rtau;
             dt = (t >= -0.4f && t <= 0.4f) ? dtau : 0.f;  // clamp passes the gradient inside its range
             dbt += half ? 0.f : dt;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dwt[4 * q + j] = fmaf(dt, xq[q][j], dwt[4 * q + j]);
+            if (half == 0) X[l31 * kTS + 32] = dt;  // pad column of the x tile: dt by point, for dwt in step 4
         }
 
         // next tile's rows: in flight during steps 3 and 4
@@ -270,6 +261,10 @@ __global__ __launch_bounds__(NW * 64) void slice_bwd_mfma_kernel(
         wave_lds_fence();  // X written at the top of the tile
 #pragma unroll
         for (int k = 0; k < 16; ++k) xb[k] = X[(k + 16 * half) * kTS + l31];
+        if (MODE) {  // dwt[c] += sum_n dt_n x[n][c] over this half-wave's 16 points
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dwt = fmaf(X[(k + 16 * half) * kTS + 32], xb[k], dwt);
+        }
 #pragma unroll
         for (int blk = 0; blk < MB; ++blk) {
 #pragma unroll
@@ -280,6 +275,10 @@ __global__ __launch_bounds__(NW * 64) void slice_bwd_mfma_kernel(
             f4v d4[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) d4[q] = *reinterpret_cast<const f4v*>(T + l31 * kTS + 16 * half + 4 * q);
+            if (MODE) {  // dbs[g] += sum_n dlogit[n][g]: the row sums of the tile
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dbr[blk] += (d4[q][0] + d4[q][1]) + (d4[q][2] + d4[q][3]);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -291,32 +290,27 @@ __global__ __launch_bounds__(NW * 64) void slice_bwd_mfma_kernel(
     // ---- workgroup record: sum the waves in a fixed order through the (now idle) image region
     __syncthreads();
     float* red = lds;                  // [M][C] dWs | [M] dbs | [C] dwt | dbt
-    float dbr[MB][16];
     if (MODE) {
 #pragma unroll
-        for (int blk = 0; blk < MB; ++blk)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) dbr[blk][v] = half_sum(dbv[blk][v]);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) dwt[k] = half_sum(dwt[k]);
+        for (int blk = 0; blk < MB; ++blk) dbr[blk] += __shfl_xor(dbr[blk], 32);
+        dwt += __shfl_xor(dwt, 32);
         dbt = half_sum(dbt);
     }
     for (int w = 0; w < NW; ++w) {
         if (wave == w) {
 #pragma unroll
-            for (int blk = 0; blk < MB; ++blk)
+            for (int blk = 0; blk < MB; ++blk) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int g = 32 * blk + 8 * (v >> 2) + 4 * half + (v & 3);
                     float* dst = red + g * C + l31;
                     *dst = (w ? *dst : 0.f) + dW[blk][v];
-                    if (MODE && l31 == 0) red[IMG + g] = (w ? red[IMG + g] : 0.f) + dbr[blk][v];
                 }
-            if (MODE && l31 == 0) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    red[IMG + M + 16 * half + k] = (w ? red[IMG + M + 16 * half + k] : 0.f) + dwt[k];
-                if (half == 0) red[IMG + M + C] = (w ? red[IMG + M + C] : 0.f) + dbt;
+                if (MODE && half == 0) red[IMG + 32 * blk + l31] = (w ? red[IMG + 32 * blk + l31] : 0.f) + dbr[blk];
+            }
+            if (MODE && half == 0) {
+                red[IMG + M + l31] = (w ? red[IMG + M + l31] : 0.f) + dwt;
+                if (l31 == 0) red[IMG + M + C] = (w ? red[IMG + M + C] : 0.f) + dbt;
             }
         }
         __syncthreads();
@@ -363,9 +357,7 @@ int slice_bwd_mfma(int mode, const float* x, const float* Ws, const float* bs, c
                                     dx, parts)
     switch (M) {
         case 32: HAET_BWD_MFMA(1, 8);
-        case 64:
-            if (getenv("HAET_BWD_NW4")) { HAET_BWD_MFMA(2, 4); }
-            HAET_BWD_MFMA(2, 8);
+        case 64: HAET_BWD_MFMA(2, 8);
         default: HAET_BWD_MFMA(4, 4);
     }
 #undef HAET_BWD_MFMA
