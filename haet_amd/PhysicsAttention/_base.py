@@ -212,10 +212,12 @@ class PhysicsAttentionBase(nn.Module):
             # Erwin stage (B*H*M tokens) differentiates through a torch restatement -- haet_amd/_autograd.py.
             from .. import _autograd
 
-            if self.shard_group is not None or return_intermediates:
-                raise NotImplementedError("training / gradients are not available on the point-sharded path "
-                                          "or together with return_intermediates yet")
-            if os.environ.get("HAET_TORCH_BACKWARD"):  # the previous interim path, kept for A/B runs
+            if return_intermediates:
+                raise NotImplementedError("return_intermediates is a no-grad / eval facility")
+            if self.shard_group is not None and not isinstance(self.in_project_x, nn.Linear):
+                raise NotImplementedError("gradients on the slab-sharded structured meshes (halo exchange in the "
+                                          "convolution's backward) are not available yet")
+            if os.environ.get("HAET_TORCH_BACKWARD") and self.shard_group is None:  # the interim path, for A/B runs
                 if self.training:
                     return _autograd.attention_forward(self, x)
                 return _autograd.HipForwardTorchBackward.apply(self, x, *self.parameters())

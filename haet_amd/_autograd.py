@@ -176,6 +176,10 @@ class PhysicsAttentionFunction(torch.autograd.Function):
         with ev("slice"):
             parts = ops.slice_partials(x_lin, sp, H, C, G)
         with ev("merge"):
+            if mod.shard_group is not None:  # point-sharded: one all-gather of the per-rank records
+                from .sharding import allgather_records
+
+                parts = allgather_records(ops.merge_records(parts, B, H, C, G, finalize=False), mod.shard_group)
             col_max, col_sum, S = ops.merge_records(parts, B, H, C, G, finalize=True)
         ctx.inner = None
         with ev("erwin"):
@@ -217,6 +221,14 @@ class PhysicsAttentionFunction(torch.autograd.Function):
             g_out = mod._linear_transposed("to_out", lin_out, gy)       # dL/d out_x [B, N, H*C]
         with ev("bwd_tokens"):
             dS2 = ops.deslice_bwd_tokens(x_lin, sp, col_max, col_sum, g_out, H, C, G)
+            share = 1.0
+            if mod.shard_group is not None:  # the backward's one exchange; everything token-level is replicated
+                import torch.distributed as dist
+
+                from .sharding import allreduce_sum
+
+                allreduce_sum(dS2, mod.shard_group)
+                share = 1.0 / dist.get_world_size(mod.shard_group)
 
         with ev("bwd_erwin"):
             erwin_params = [p for p in mod.erwin.parameters() if id(p) in wanted]
@@ -229,8 +241,8 @@ class PhysicsAttentionFunction(torch.autograd.Function):
             got = torch.autograd.grad(S2_graph, [S_leaf] + erwin_params, dS2, allow_unused=True)
             ctx.inner = None
             dS = got[0] if got[0] is not None else torch.zeros_like(S)
-            for p, g in zip(erwin_params, got[1:]):
-                grads[id(p)] = g
+            for p, g in zip(erwin_params, got[1:]):  # replicated: each rank reports its additive share (sharding.py)
+                grads[id(p)] = g if share == 1.0 or g is None else g * share
             A = (dS2 * S2).sum(dim=-1) + (S * dS).sum(dim=-1)          # sum_n w[n,g] a[n,g], [B*H*M]
         with ev("bwd_points"):
             dx_lin, dWs, dbs, dwt, dbt = ops.slice_bwd_points(x_lin, sp, col_max, col_sum, g_out, S2, dS, A, H, C, G)

@@ -6,6 +6,12 @@ all-gather of the per-rank slice record  [B*H*M*(C+2)] floats  (~70 KB at C3), m
 the log-sum-exp rule on every rank.  The message is latency-bound, so it is a single
 all-gather (one hop on the fully connected xGMI node), not a ring all-reduce of max + sum.
 Everything after the merge (token positions, ball tree, Erwin) is replicated.
+
+Gradients (Physics_Attention_Irregular_Mesh): the backward mirrors it with ONE all-reduce of the partial
+dS2 [B*H*M, C] (64 KB at C3); the Erwin backward is replicated.  Every rank then holds its ADDITIVE SHARE of
+each parameter gradient -- the sums over its own points for in_project_x / in_project_slice / ada_temp_linear /
+to_out, and 1/R of the (replicated) Erwin gradients -- so that the trainer's ordinary SUM all-reduce over all
+parameters (the same one the point-wise layers around the module need) yields the full gradient.
 """
 from __future__ import annotations
 
@@ -25,6 +31,17 @@ def allgather_records(local_record: torch.Tensor, group=None) -> torch.Tensor:
     out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
     dist.all_gather_into_tensor(out, flat, group=group)  # flat output: accepted by RCCL and gloo
     return out.view(world, flat.numel())
+
+
+def allreduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum over the ranks (the backward's one exchange: the partial dS2 of every shard)."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":  # test configuration, see allgather_records
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+        return t
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
 
 
 def shard_points(model: torch.nn.Module, group=None) -> torch.nn.Module:

@@ -96,3 +96,66 @@ def test_two_rank_slab_sharding_of_structured_meshes(tmp_path, hip_device):
     for r in range(2):
         for name, err in torch.load(os.path.join(tmp_path, f"s{r}.pt")).items():
             assert err < 2e-4, (r, name, err)
+
+
+def _grad_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from haet_amd import _autograd
+    from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh
+    from haet_amd.sharding import shard_bounds, shard_points
+
+    dev = torch.device("cuda:0")
+    out = {}
+    for train in (False, True):
+        torch.manual_seed(21)
+        mod = Physics_Attention_Irregular_Mesh(dim=256, heads=8, dim_head=32, slice_num=64, rotate=45)
+        with torch.no_grad():
+            for name, p in mod.erwin.named_parameters():
+                if p.dim() >= 2:
+                    p.mul_(3.0)
+        mod = mod.to(dev).train(train)
+        x = torch.randn(1, 2500, 256).to(dev)
+        gout = torch.randn(1, 2500, 256).to(dev)
+        state = {k: v.clone() for k, v in mod.state_dict().items()}
+        # reference: the whole cloud on this rank, autograd through the device restatement
+        xr = x.clone().requires_grad_(True)
+        (_autograd.attention_forward(mod, xr) * gout).sum().backward()
+        ref = {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}
+        ref_gx = xr.grad.clone()
+        mod.zero_grad(set_to_none=True)
+        mod.load_state_dict(state)
+        # sharded: this rank's half of the points, the HIP autograd node with one all-gather + one all-reduce
+        shard_points(mod)
+        a, b = shard_bounds(x.shape[1], rank, world)
+        xs = x[:, a:b].contiguous().requires_grad_(True)
+        (mod(xs) * gout[:, a:b]).sum().backward()
+        out[train] = dict(gx=xs.grad.cpu(), ref_gx=ref_gx[:, a:b].cpu(),
+                          grads={n: p.grad.cpu() for n, p in mod.named_parameters() if p.grad is not None},
+                          ref={n: g.cpu() for n, g in ref.items()})
+    torch.save(out, os.path.join(tmp, f"g{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_point_sharded_gradients(tmp_path, hip_device):
+    """Training on the point-sharded path: every rank back-propagates its own points (one all-reduce of
+    dS2); its input gradient is its slice of the unsharded one and the ranks' parameter gradients are
+    additive shares of the unsharded gradient (haet_amd/sharding.py)."""
+    from oracle import haet_oracle as O
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"g{r}.pt")) for r in range(2)]
+    for train in (False, True):
+        for r in range(2):
+            assert O.rel_l2(res[r][train]["gx"], res[r][train]["ref_gx"]) < 1e-3, (train, r)
+        ref = res[0][train]["ref"]
+        scale = max(float(g.norm()) for g in ref.values())
+        for name, g_ref in ref.items():
+            total = res[0][train]["grads"][name] + res[1][train]["grads"][name]
+            err = float((total - g_ref).norm()) / max(float(g_ref.norm()), 1e-4 * scale)
+            assert err < 2e-3, (train, name, err)
