@@ -77,6 +77,11 @@ SIGNATURES = {
     "haet_linear_wgrad_supported": (c_int, [c_int, c_int]),
     "haet_linear_wgrad_num_parts": (c_int, [c_int]),
     "haet_linear_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
+    "haet_linear_act_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "haet_layernorm_supported": (c_int, [c_int]),
+    "haet_layernorm_fwd": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P]),
+    "haet_linear_narrow_supported": (c_int, [c_int, c_int]),
+    "haet_linear_narrow_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "haet_erwin_lds_bytes": (c_size_t, [POINTER(ErwinDesc), c_int]),
     "haet_erwin_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, POINTER(ErwinDesc), c_int, c_int, _P, _P]),
     "haet_deslice_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P]

@@ -1,9 +1,9 @@
 """Shared body of the three HAETransolver_* model wrappers.
 
-API surface only: constructor kwargs, forward(x, fx, T) and
-state_dict keys follow models/HAETransolver_Irregular_Mesh.py:26-376 (and the
-Structured_Mesh_2D / _3D twins); LayerNorm / MLP arithmetic is stock PyTorch-ROCm, the
-attention inside every block is the HIP path.
+Constructor kwargs, forward(x, fx, T) and state_dict keys follow
+models/HAETransolver_Irregular_Mesh.py:26-376 (and the Structured_Mesh_2D / _3D twins).  The attention
+inside every block is the HIP path; the LayerNorm / MLP layers around it are stock PyTorch-ROCm modules
+that, with gradients disabled, also run on HIP kernels (haet_amd/_fast.py).
 """
 from __future__ import annotations
 
@@ -13,6 +13,7 @@ import torch.nn as nn
 import torch.utils.checkpoint as checkpoint
 from torch.nn.init import trunc_normal_
 
+from . import _fast
 from .components import MLP, timestep_embedding
 
 
@@ -31,6 +32,12 @@ class TransolverErwinBlockBase(nn.Module):
             self.mlp2 = nn.Linear(hidden_dim, out_dim)
 
     def forward(self, fx):
+        if _fast.enabled(fx):  # inference: LayerNorms / MLP on the HIP kernels too (haet_amd/_fast.py)
+            fx = self.Attn(_fast.layer_norm(self.ln_1, fx)) + fx
+            fx = self.mlp(_fast.layer_norm(self.ln_2, fx)) + fx
+            if self.last_layer:
+                return _fast.linear(self.mlp2, _fast.layer_norm(self.ln_3, fx))
+            return fx
         fx = self.Attn(self.ln_1(fx)) + fx
         fx = self.mlp(self.ln_2(fx)) + fx
         if self.last_layer:
@@ -68,12 +75,15 @@ class ModelBase(nn.Module):
     def forward(self, x, fx, T=None):
         if self.unified_pos:
             x = self.unified_positions(x)
-        if fx is not None:
-            fx = self.preprocess(torch.cat((x, fx), -1))
-            if self.placeholder_always:
-                fx = fx + self.placeholder[None, None, :]
+        inp = torch.cat((x, fx), -1) if fx is not None else x
+        with_placeholder = fx is None or self.placeholder_always
+        fast = _fast.mlp(self.preprocess, inp, self.placeholder if with_placeholder else None)
+        if fast is not None:  # inference: the placeholder rides in the last Linear's bias
+            fx = fast
         else:
-            fx = self.preprocess(x) + self.placeholder[None, None, :]
+            fx = self.preprocess(inp)
+            if with_placeholder:
+                fx = fx + self.placeholder[None, None, :]
         if T is not None:
             emb = timestep_embedding(T, self.n_hidden).repeat(1, x.shape[1], 1)
             fx = fx + self.time_fc(emb)

@@ -1,6 +1,8 @@
-"""Generic MLP used by the model wrappers (API surface only; mirrors models/components/mlp.py:23-96).
-Stock PyTorch-ROCm arithmetic -- outside the accelerated path."""
+"""Generic MLP used by the model wrappers (mirrors models/components/mlp.py:23-96).  Stock PyTorch-ROCm
+modules; with gradients disabled the GELU variant runs on the HIP GEMM (haet_amd/_fast.py)."""
 import torch.nn as nn
+
+from .. import _fast
 
 ACTIVATION = {
     "gelu": nn.GELU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "relu": nn.ReLU,
@@ -22,6 +24,9 @@ class MLP(nn.Module):
             [nn.Sequential(nn.Linear(n_hidden, n_hidden), act()) for _ in range(n_layers)])
 
     def forward(self, x):
+        y = _fast.mlp(self, x)  # inference fast path (None: does not apply)
+        if y is not None:
+            return y
         x = self.linear_pre(x)
         for i in range(self.n_layers):
             x = self.linears[i](x) + x if self.res else self.linears[i](x)

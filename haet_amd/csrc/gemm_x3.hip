@@ -47,6 +47,9 @@ __device__ __forceinline__ f32x16 g_mfma3(const GFrag& a, const GFrag& b, f32x16
     return c;
 }
 
+// optional epilogue activation (ACT = 1): nn.GELU(approximate='none'), the MLPs of the Transolver block
+__device__ __forceinline__ float g_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
 // fp32 -> bf16 hi / lo planes (weights; once per parameter version)
 __global__ void split_bf16_kernel(const float* __restrict__ w, size_t n, unsigned short* __restrict__ hi,
                                   unsigned short* __restrict__ lo) {
@@ -89,7 +92,7 @@ __device__ __forceinline__ GFrag g_read(int img, int row, int chunk) {
 struct ConvGeom {
     int Cin, Npts, gH, gW, gD, kH, kW, kD;
 };
-template <int NCB, int RB, bool CONV = false>  // RB = 32-row blocks per wave: workgroup tile = 64*RB rows x 32*NCB columns
+template <int NCB, int RB, bool CONV = false, int ACT = 0>  // RB = 32-row blocks per wave: workgroup tile = 64*RB rows x 32*NCB columns
 __global__ __launch_bounds__(512) void gemm_x3_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ Whi,
     const unsigned short* __restrict__ Wlo, const float* __restrict__ bias, int Nrows, int K, int O,
@@ -245,12 +248,13 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
                     if (full) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            oc[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * O] = acc[i][j][r];
+                            oc[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * O] = ACT ? g_gelu(acc[i][j][r]) : acc[i][j][r];
                     } else {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int rr = 32 * i + (r & 3) + 8 * (r >> 2);
-                            if (row0 + 32 * RB * wm + 4 * hf + rr < Nrows) oc[(size_t)rr * O] = acc[i][j][r];
+                            if (row0 + 32 * RB * wm + 4 * hf + rr < Nrows)
+                                oc[(size_t)rr * O] = ACT ? g_gelu(acc[i][j][r]) : acc[i][j][r];
                         }
                     }
 #pragma unroll
@@ -347,7 +351,7 @@ struct SplitArgs {
     float bt, base_temp;
     float* s_out;     // [Nrows][O / 32]
 };
-template <int NKT, int S, bool SPLIT = false>
+template <int NKT, int S, bool SPLIT = false, int ACT = 0>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ Whi,
     const unsigned short* __restrict__ Wlo, const float* __restrict__ bias, int Nrows, int O,
@@ -448,7 +452,11 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(
             v[m + 2] = up ? v[m + 2] : recv;
         }
         if (!SPLIT) {
-            const f32x4 o4 = {__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])};
+            f32x4 o4 = {__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])};
+            if (ACT) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o4[q] = g_gelu(o4[q]);
+            }
             *reinterpret_cast<f32x4*>(ob + o_voff + (unsigned)((32 * i + 8 * g) * O * 4)) = o4;
         } else {
             // this lane: ONE row, four consecutive channels of head `wave` (+ 8 blockIdx.y)
@@ -591,10 +599,9 @@ extern "C" int haet_linear_supported(int K, int O) {
     return (K >= 32 && K % 32 == 0 && O >= 128 && O % 128 == 0) ? 1 : 0;
 }
 
-extern "C" int haet_linear_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo,
-                               const float* bias, int Nrows, int K, int O, float* out,
-                               haet_stream_t stream) {
-    if (!x || !W_hi || !W_lo || !out || Nrows < 1) return fail(HAET_E_ARG, "linear_fwd: bad arguments");
+static int linear_fwd_impl(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias, int Nrows,
+                           int K, int O, int act, float* out, haet_stream_t stream) {
+    if (!x || !W_hi || !W_lo || !out || Nrows < 1 || (act != 0 && act != 1)) return fail(HAET_E_ARG, "linear_fwd: bad arguments");
     if (!haet_linear_supported(K, O))
         return fail(HAET_E_ARG, "linear_fwd: K=%d (multiple of 32) / O=%d (multiple of 128) unsupported", K, O);
     // W-stationary kernel wherever the weight fits the register file
@@ -610,8 +617,8 @@ extern "C" int haet_linear_fwd(const float* x, const uint16_t* W_hi, const uint1
             hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi, W_lo, bias, Nrows,
                                O, tiles, out, SplitArgs{nullptr, 0.f, 0.f, nullptr});
         };
-        if (K == 256) go(gemm_ws_kernel<8, 4>);
-        else go(gemm_ws_kernel<4, 4>);
+        if (K == 256) { if (act) go(gemm_ws_kernel<8, 4, false, 1>); else go(gemm_ws_kernel<8, 4>); }
+        else { if (act) go(gemm_ws_kernel<4, 4, false, 1>); else go(gemm_ws_kernel<4, 4>); }
         return check_launch("gemm_ws_kernel");
     }
     // 256-row workgroup tiles (W staged once per 256 rows) when there are enough rows to fill the
@@ -634,11 +641,27 @@ extern "C" int haet_linear_fwd(const float* x, const uint16_t* W_hi, const uint1
         return HAET_OK;
     };
     int rc;
-    if (big) rc = launch(gemm_x3_kernel<8, 4>);
-    else if (NCBv == 8) rc = launch(gemm_x3_kernel<8, 2>);
-    else rc = launch(gemm_x3_kernel<4, 2>);
+    if (act) {
+        if (big) rc = launch(gemm_x3_kernel<8, 4, false, 1>);
+        else if (NCBv == 8) rc = launch(gemm_x3_kernel<8, 2, false, 1>);
+        else rc = launch(gemm_x3_kernel<4, 2, false, 1>);
+    } else {
+        if (big) rc = launch(gemm_x3_kernel<8, 4>);
+        else if (NCBv == 8) rc = launch(gemm_x3_kernel<8, 2>);
+        else rc = launch(gemm_x3_kernel<4, 2>);
+    }
     if (rc != HAET_OK) return rc;
     return check_launch("gemm_x3_kernel");
+}
+
+extern "C" int haet_linear_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
+                               int Nrows, int K, int O, float* out, haet_stream_t stream) {
+    return linear_fwd_impl(x, W_hi, W_lo, bias, Nrows, K, O, 0, out, stream);
+}
+
+extern "C" int haet_linear_act_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
+                                   int Nrows, int K, int O, int act, float* out, haet_stream_t stream) {
+    return linear_fwd_impl(x, W_hi, W_lo, bias, Nrows, K, O, act, out, stream);
 }
 
 extern "C" int haet_project_split_supported(int K, int O, int Nrows) {

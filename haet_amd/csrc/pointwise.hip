@@ -1,0 +1,154 @@
+// Point-wise callers either side of the path (the Transolver block around the attention,
+// models/HAETransolver_Irregular_Mesh.py:114-134 and the preprocess MLP :186, 338-376): the LayerNorms and
+// the narrow first Linear of the preprocess MLP.  Both are pure HBM streams over ~1e6 rows; the stock ops
+// run them at ~1/4 of the copy rate (LayerNorm) or in three passes (Linear, bias, GELU).
+#include "common.h"
+
+namespace haet {
+
+namespace {
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float gelu_erf(float v) {  // nn.GELU(approximate='none')
+    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+}  // namespace
+
+// One wave per row: D / 4 float4 chunks over the 64 lanes (D <= 1024), two-pass statistics in registers
+// (mean, then the centred sum of squares: torch's numerics), biased variance, eps inside the root.
+template <int CH>  // chunks per lane
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, int rows, int D,
+                                                        float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int nch = D >> 2;
+    f4v g[CH], b[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int ch = lane + 64 * c;
+        const bool ok = ch < nch;
+        g[c] = ok ? *reinterpret_cast<const f4v*>(gamma + 4 * ch) : f4v{0.f, 0.f, 0.f, 0.f};
+        b[c] = ok ? *reinterpret_cast<const f4v*>(beta + 4 * ch) : f4v{0.f, 0.f, 0.f, 0.f};
+    }
+    const float inv_d = 1.0f / (float)D;
+    for (int r = wave; r < rows; r += nwaves) {
+        const float* xr = x + (size_t)r * D;
+        f4v v[CH];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int ch = lane + 64 * c;
+            v[c] = ch < nch ? *reinterpret_cast<const f4v*>(xr + 4 * ch) : f4v{0.f, 0.f, 0.f, 0.f};
+            s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        }
+        const float mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[c][j] - mean;
+                    q = fmaf(d, d, q);
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+        float* orow = out + (size_t)r * D;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                f4v o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = fmaf((v[c][j] - mean) * rstd, g[c][j], b[c][j]);
+                *reinterpret_cast<f4v*>(orow + 4 * ch) = o;
+            }
+        }
+    }
+}
+
+// out[n][o] = act(sum_k x[n][k] W[o][k] + b[o]) for a narrow input (K <= 16: coordinates + a few fields):
+// a thread owns 4 consecutive outputs of one row; W^T sits in LDS as [k][O]; the row's K inputs are
+// wave-uniform scalar loads when O/4 >= 64.  One pass, the output written once.
+template <int ACT>
+__global__ __launch_bounds__(256) void linear_narrow_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, int rows, int K, int O,
+                                                            float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [K][O] W^T | [O] bias
+    for (int i = threadIdx.x; i < K * O; i += 256) {
+        const int k = i / O, o = i % O;
+        lds[i] = W[o * K + k];
+    }
+    for (int o = threadIdx.x; o < O; o += 256) lds[K * O + o] = bias ? bias[o] : 0.f;
+    __syncthreads();
+    const int o4 = O >> 2;
+    const size_t total = (size_t)rows * o4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / o4;
+        const int c = (int)(i % o4) * 4;
+        f4v acc = *reinterpret_cast<const f4v*>(lds + K * O + c);
+        const float* xr = x + r * K;
+        for (int k = 0; k < K; ++k) {
+            const float xv = xr[k];
+            const f4v w = *reinterpret_cast<const f4v*>(lds + k * O + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(xv, w[j], acc[j]);
+        }
+        if (ACT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = gelu_erf(acc[j]);
+        }
+        *reinterpret_cast<f4v*>(out + r * O + c) = acc;
+    }
+}
+
+}  // namespace haet
+
+using namespace haet;
+
+extern "C" int haet_layernorm_supported(int D) { return (D >= 4 && D % 4 == 0 && D <= 1024) ? 1 : 0; }
+
+extern "C" int haet_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int rows, int D,
+                                  float* out, haet_stream_t stream) {
+    if (!x || !gamma || !beta || !out || rows < 1) return fail(HAET_E_ARG, "layernorm_fwd: bad arguments");
+    if (!haet_layernorm_supported(D)) return fail(HAET_E_ARG, "layernorm_fwd: D=%d unsupported (multiple of 4, <= 1024)", D);
+    const int blocks = rows < 4 * 2048 ? (rows + 3) / 4 : 2048;  // 8 workgroups of 4 waves per CU
+    const int ch = (D / 4 + 63) / 64;
+    hipStream_t st = as_stream(stream);
+    switch (ch) {
+        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out); break;
+        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out); break;
+        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out); break;
+        default: hipLaunchKernelGGL(layernorm_kernel<4>, dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out); break;
+    }
+    return check_launch("layernorm_kernel");
+}
+
+extern "C" int haet_linear_narrow_supported(int K, int O) { return (K >= 1 && K <= 16 && O >= 4 && O % 4 == 0 && O <= 2048) ? 1 : 0; }
+
+extern "C" int haet_linear_narrow_fwd(const float* x, const float* W, const float* bias, int rows, int K, int O,
+                                      int act, float* out, haet_stream_t stream) {
+    if (!x || !W || !out || rows < 1) return fail(HAET_E_ARG, "linear_narrow_fwd: bad arguments");
+    if (!haet_linear_narrow_supported(K, O) || (act != 0 && act != 1))
+        return fail(HAET_E_ARG, "linear_narrow_fwd: K=%d (<= 16) / O=%d (multiple of 4, <= 2048) / act=%d unsupported", K, O, act);
+    const size_t lds = ((size_t)K * O + O) * sizeof(float);
+    const size_t total = (size_t)rows * (O / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    auto go = [&](auto kern) -> int {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail(HAET_E_LAUNCH, "linear_narrow: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, as_stream(stream), x, W, bias, rows, K, O, out);
+        return HAET_OK;
+    };
+    int rc = act ? go(linear_narrow_kernel<1>) : go(linear_narrow_kernel<0>);
+    if (rc != HAET_OK) return rc;
+    return check_launch("linear_narrow_kernel");
+}

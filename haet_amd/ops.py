@@ -224,14 +224,51 @@ def linear_supported(K: int, O: int) -> bool:
     return bool(_lib.load().haet_linear_supported(int(K), int(O)))
 
 
-def linear(x: Tensor, w: SplitLinear) -> Tensor:
-    """out[..., O] = x[..., K] @ W^T + b on the matrix cores (split-bf16, fp32-class accuracy)."""
+def linear(x: Tensor, w: SplitLinear, gelu: bool = False) -> Tensor:
+    """out[..., O] = x[..., K] @ W^T + b on the matrix cores (split-bf16, fp32-class accuracy), optionally
+    followed by GELU (erf) in the epilogue."""
     lib = _lib.load()
     x = _f32(x, "x")
     rows = x.numel() // w.K
     out = torch.empty(x.shape[:-1] + (w.O,), dtype=torch.float32, device=x.device)
-    check(lib.haet_linear_fwd(_p(x), _p(w.hi), _p(w.lo), _p(w.bias), rows, w.K, w.O, _p(out), _stream()),
-          "haet_linear_fwd")
+    if gelu:
+        check(lib.haet_linear_act_fwd(_p(x), _p(w.hi), _p(w.lo), _p(w.bias), rows, w.K, w.O, 1, _p(out), _stream()),
+              "haet_linear_act_fwd")
+    else:
+        check(lib.haet_linear_fwd(_p(x), _p(w.hi), _p(w.lo), _p(w.bias), rows, w.K, w.O, _p(out), _stream()),
+              "haet_linear_fwd")
+    return out
+
+
+# --------------------------------------------------------------------------- the block around the path
+def layernorm_supported(D: int) -> bool:
+    return bool(_lib.load().haet_layernorm_supported(int(D)))
+
+
+def layernorm(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
+    """nn.LayerNorm over the last dimension (haet_layernorm_fwd)."""
+    lib = _lib.load()
+    x = _f32(x, "x")
+    D = x.shape[-1]
+    out = torch.empty_like(x)
+    check(lib.haet_layernorm_fwd(_p(x), _p(_f32(weight.detach(), "weight")), _p(_f32(bias.detach(), "bias")), float(eps),
+                                 x.numel() // D, D, _p(out), _stream()), "haet_layernorm_fwd")
+    return out
+
+
+def linear_narrow_supported(K: int, O: int) -> bool:
+    return bool(_lib.load().haet_linear_narrow_supported(int(K), int(O)))
+
+
+def linear_narrow(x: Tensor, weight: Tensor, bias: Optional[Tensor], gelu: bool = False) -> Tensor:
+    """Linear (+ GELU) with at most 16 input features (haet_linear_narrow_fwd)."""
+    lib = _lib.load()
+    x = _f32(x, "x")
+    O, K = weight.shape
+    out = torch.empty(x.shape[:-1] + (O,), dtype=torch.float32, device=x.device)
+    check(lib.haet_linear_narrow_fwd(_p(x), _p(_f32(weight.detach(), "weight")),
+                                     _p(None if bias is None else _f32(bias.detach(), "bias")), x.numel() // K, K, O,
+                                     1 if gelu else 0, _p(out), _stream()), "haet_linear_narrow_fwd")
     return out
 
 

@@ -259,6 +259,23 @@ int haet_linear_wgrad_supported(int O, int K);
 int haet_linear_wgrad_num_parts(int N);
 int haet_linear_wgrad(const float* G, const float* X, int N, int O, int K, float* parts, haet_stream_t stream);
 
+/* ------------------------------------------------------------------ the block around the path
+ * Point-wise callers either side of Physics_Attention inside a Transolver block
+ * (models/HAETransolver_Irregular_Mesh.py:114-134: LayerNorm -> Attn -> +res -> LayerNorm -> MLP -> +res;
+ * preprocess MLP :186, 338-376), inference only.
+ *   haet_linear_act_fwd:    haet_linear_fwd with an epilogue activation (act 0 = none, 1 = GELU erf): the
+ *                           Linear + nn.GELU pairs of models/components' MLP
+ *   haet_layernorm_fwd:     nn.LayerNorm(D) over rows (biased variance, eps inside the root)
+ *   haet_linear_narrow_fwd: Linear (+ GELU) with K <= 16 inputs (coordinates + fields), fp32 vector ALUs  */
+int haet_linear_act_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
+                        int Nrows, int K, int O, int act, float* out, haet_stream_t stream);
+int haet_layernorm_supported(int D);
+int haet_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int rows, int D,
+                       float* out, haet_stream_t stream);
+int haet_linear_narrow_supported(int K, int O);
+int haet_linear_narrow_fwd(const float* x, const float* W /*[O,K]*/, const float* bias, int rows, int K, int O,
+                           int act, float* out, haet_stream_t stream);
+
 /* ------------------------------------------------------------------ structured-mesh projection
  * in_project_x of the structured modules (nn.Conv2d / nn.Conv3d, kernel k, padding k/2:
  * StructuredMesh2D.py:109,173-189, StructuredMesh3D.py:113,177-193) as an implicit GEMM on the
