@@ -20,9 +20,6 @@ the A/B reference of the tests (and `HipForwardTorchBackward`, the previous inte
 """
 from __future__ import annotations
 
-import math
-import os
-
 import torch
 import torch.nn.functional as F
 
@@ -44,10 +41,10 @@ def _ball_msa(att, x, pos):
     x = x + att.pe_proj(rel)
     c = x.shape[1]
     hd = c // heads
-    qkv = att.qkv(x).view(-1, ball, 3, heads, hd)
-    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-    w = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * (1.0 / math.sqrt(hd)), dim=-1)
-    return att.proj(torch.matmul(w, v).permute(0, 2, 1, 3).reshape(-1, c))
+    # one permuted copy for q, k and v: [3, balls, heads, ball, hd] (the stage is launch-bound: every op counts)
+    qkv = att.qkv(x).view(-1, ball, 3, heads, hd).permute(2, 0, 3, 1, 4).contiguous()
+    o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])  # softmax(q k^T / sqrt(hd)) v, one autograd node
+    return att.proj(o.permute(0, 2, 1, 3).reshape(-1, c))
 
 
 def _block(blk, x, pos):
