@@ -41,12 +41,26 @@ int deslice_mfma_fwd(const float*, const float*, const float*, const float*, flo
                      const float*, const float*, const float*, int, int, int, int, int, float*,
                      hipStream_t, const float* s_in);
 
-// HAET_FORCE_VALU=1 routes every shape through the generic fp32 VALU kernels (tests)
+// slice_f32_mfma.hip: the two passes on the f32 matrix cores (C in {32, 64}, M in {32, 64, 128})
+bool slice_f32_ok(int C, int M);
+int slice_f32_num_parts(int N);
+int slice_f32_fwd(const float*, const float*, const float*, const float*, float, float, float, int, int, int, int,
+                  int, float*, hipStream_t);
+int deslice_f32_fwd(const float*, const float*, const float*, const float*, float, float, float, const float*,
+                    const float*, const float*, int, int, int, int, int, float*, hipStream_t);
+
+// HAET_FORCE_VALU=1 routes every shape through the generic fp32 VALU kernels, HAET_FORCE_F32_MFMA=1 every
+// shape the f32-MFMA kernels cover through those (tests)
+static bool env_on(const char* name) {
+    const char* e = getenv(name);
+    return e && e[0] == '1';
+}
 static bool use_mfma(int B, int N, int H, int C, int M, MfmaPlan* p) {
-    const char* e = getenv("HAET_FORCE_VALU");
-    if (e && e[0] == '1') return false;
+    if (env_on("HAET_FORCE_VALU") || (env_on("HAET_FORCE_F32_MFMA") && slice_f32_ok(C, M))) return false;
     return mfma_plan(B, N, H, C, M, p);
 }
+// the split-bf16 kernels where they apply (C = 32), else the f32-MFMA kernels (C = 64), else vector ALUs
+static bool use_f32_mfma(int C, int M) { return !env_on("HAET_FORCE_VALU") && slice_f32_ok(C, M); }
 
 }  // namespace haet
 
@@ -59,6 +73,7 @@ extern "C" int haet_slice_num_parts(int B, int N, int H, int C, int M) {
     if (slice_shape_ok(B, N, H, C, M) != HAET_OK) return HAET_E_ARG;
     MfmaPlan p;
     if (use_mfma(B, N, H, C, M, &p)) return p.parts;
+    if (use_f32_mfma(C, M)) return slice_f32_num_parts(N);
     return slice_valu_num_parts(N);
 }
 
@@ -74,6 +89,8 @@ extern "C" int haet_slice_fwd(const float* x_lin, const float* Ws, const float* 
     if (rc != HAET_OK) return rc;
     if (use_mfma(B, N, H, C, M, nullptr))
         return slice_mfma_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, B, N, H, C, M, parts, as_stream(stream), nullptr);
+    if (use_f32_mfma(C, M))
+        return slice_f32_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, B, N, H, C, M, parts, as_stream(stream));
     return slice_valu_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, B, N, H, C, M, parts, as_stream(stream));
 }
 
@@ -88,6 +105,9 @@ extern "C" int haet_deslice_fwd(const float* x_lin, const float* Ws, const float
     if (use_mfma(B, N, H, C, M, nullptr))
         return deslice_mfma_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, S2, B, N, H, C,
                                 M, out_x, as_stream(stream), nullptr);
+    if (use_f32_mfma(C, M))
+        return deslice_f32_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, S2, B, N, H, C, M, out_x,
+                               as_stream(stream));
     return deslice_valu_fwd(x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, S2, B, N, H, C, M,
                             out_x, as_stream(stream));
 }

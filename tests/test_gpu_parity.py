@@ -38,18 +38,21 @@ def _slice_params(sd, cfg, dev):
                            cfg.base_temp, cfg.epsilon)
 
 
-@pytest.fixture(params=["auto", "valu"])
+@pytest.fixture(params=["auto", "valu", "f32"])
 def kernel_path(request):
-    """'auto' = MFMA kernels where the shape allows, 'valu' = generic fp32 kernels everywhere."""
+    """'auto' = the fastest kernels the shape allows (split-bf16 MFMA at C = 32, f32 MFMA at C = 64),
+    'valu' = generic fp32 vector-ALU kernels everywhere, 'f32' = the f32-MFMA kernels wherever they apply."""
     import os
 
-    old = os.environ.get("HAET_FORCE_VALU")
+    old = {k: os.environ.get(k) for k in ("HAET_FORCE_VALU", "HAET_FORCE_F32_MFMA")}
     os.environ["HAET_FORCE_VALU"] = "1" if request.param == "valu" else "0"
+    os.environ["HAET_FORCE_F32_MFMA"] = "1" if request.param == "f32" else "0"
     yield request.param
-    if old is None:
-        os.environ.pop("HAET_FORCE_VALU", None)
-    else:
-        os.environ["HAET_FORCE_VALU"] = old
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -299,13 +302,17 @@ def test_full_size_properties_1m_points(hip_device, kernel_path):
 
 
 @pytest.mark.parametrize("N", [1, 31, 33, 1057])
-@pytest.mark.parametrize("H,M", [(4, 64), (8, 32), (2, 128), (8, 128), (16, 32), (16, 64), (4, 128), (2, 32)])
-def test_ragged_point_counts_mfma_shapes(N, H, M, hip_device):
-    """Shapes the MFMA kernels take (C = 32), partial last tile, B = 2, chunk boundaries."""
+@pytest.mark.parametrize("H,M,C", [(4, 64, 32), (8, 32, 32), (2, 128, 32), (8, 128, 32), (16, 32, 32), (16, 64, 32),
+                                   (4, 128, 32), (2, 32, 32), (4, 32, 64), (2, 64, 64), (3, 128, 64)])
+def test_ragged_point_counts_mfma_shapes(N, H, M, C, hip_device, kernel_path):
+    """Shapes the MFMA kernels take (C = 32: split-bf16 or f32; C = 64: f32), partial last tile, B = 2,
+    chunk boundaries."""
     from haet_amd import ops
 
+    if kernel_path == "valu":
+        pytest.skip("the generic kernels have their own ragged test")
     torch.manual_seed(N + H + M)
-    B, C = 2, 32
+    B = 2
     x_lin = torch.randn(B, N, H * C)
     sd = {"in_project_slice.weight": torch.randn(M, C) * 0.3, "in_project_slice.bias": torch.randn(M),
           "ada_temp_linear.weight": torch.randn(1, C) * 0.2, "ada_temp_linear.bias": torch.tensor([0.05])}
