@@ -32,7 +32,7 @@ class TransolverErwinBlockBase(nn.Module):
             self.mlp2 = nn.Linear(hidden_dim, out_dim)
 
     def forward(self, fx):
-        if _fast.enabled(fx):  # inference: LayerNorms / MLP on the HIP kernels too (haet_amd/_fast.py)
+        if _fast.usable(fx):  # LayerNorms / MLP on the HIP kernels too, both directions (haet_amd/_fast.py)
             fx = self.Attn(_fast.layer_norm(self.ln_1, fx)) + fx
             fx = self.mlp(_fast.layer_norm(self.ln_2, fx)) + fx
             if self.last_layer:

@@ -72,6 +72,98 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// Backward of the same LayerNorm (training through the block, exp_airfoil.py:249-255): per row, with
+// xhat = (x - mean) rstd and gg = gy gamma,   dx = rstd (gg - mean(gg) - xhat mean(gg xhat));
+// dgamma = sum_rows gy xhat, dbeta = sum_rows gy: a lane owns the same 4 * CH columns in every row it visits,
+// so the column sums stay in registers and leave as one partial record per workgroup ([dgamma D | dbeta D]).
+template <int CH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ gy, float eps, int rows, int D,
+                                                            float* __restrict__ dx, float* __restrict__ parts) {
+    __shared__ float red[4][2 * 1024];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
+    const int nch = D >> 2;
+    const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    f4v g[CH], dg[CH], db[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int ch = lane + 64 * c;
+        g[c] = ch < nch ? *reinterpret_cast<const f4v*>(gamma + 4 * ch) : zero4;
+        dg[c] = zero4;
+        db[c] = zero4;
+    }
+    const float inv_d = 1.0f / (float)D;
+    for (int r = wave; r < rows; r += nwaves) {
+        const float* xr = x + (size_t)r * D;
+        const float* gr = gy + (size_t)r * D;
+        f4v v[CH], go[CH];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int ch = lane + 64 * c;
+            v[c] = ch < nch ? *reinterpret_cast<const f4v*>(xr + 4 * ch) : zero4;
+            go[c] = ch < nch ? *reinterpret_cast<const f4v*>(gr + 4 * ch) : zero4;
+            s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        }
+        const float mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (lane + 64 * c < nch) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[c][j] - mean;
+                    q = fmaf(d, d, q);
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (lane + 64 * c < nch) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (v[c][j] - mean) * rstd, gg = go[c][j] * g[c][j];
+                    v[c][j] = xh;  // keep xhat
+                    s1 += gg;
+                    s2 = fmaf(gg, xh, s2);
+                    dg[c][j] = fmaf(go[c][j], xh, dg[c][j]);
+                    db[c][j] += go[c][j];
+                }
+            }
+        }
+        s1 = wave_sum(s1) * inv_d;
+        s2 = wave_sum(s2) * inv_d;
+        float* orow = dx + (size_t)r * D;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                f4v o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = rstd * (go[c][j] * g[c][j] - s1 - v[c][j] * s2);
+                *reinterpret_cast<f4v*>(orow + 4 * ch) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                red[wv][4 * ch + j] = dg[c][j];
+                red[wv][D + 4 * ch + j] = db[c][j];
+            }
+        }
+    }
+    __syncthreads();
+    float* rec = parts + (size_t)blockIdx.x * 2 * D;
+    for (int i = threadIdx.x; i < 2 * D; i += 256) rec[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
 // out[n][o] = act(sum_k x[n][k] W[o][k] + b[o]) for a narrow input (K <= 16: coordinates + a few fields):
 // a thread owns 4 consecutive outputs of one row; W^T sits in LDS as [k][O]; the row's K inputs are
 // wave-uniform scalar loads when O/4 >= 64.  One pass, the output written once.
@@ -127,6 +219,24 @@ extern "C" int haet_layernorm_fwd(const float* x, const float* gamma, const floa
         default: hipLaunchKernelGGL(layernorm_kernel<4>, dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out); break;
     }
     return check_launch("layernorm_kernel");
+}
+
+extern "C" int haet_layernorm_bwd_num_parts(int rows) { return rows < 4 * 1024 ? (rows + 3) / 4 : 1024; }
+
+extern "C" int haet_layernorm_bwd(const float* x, const float* gamma, const float* gy, float eps, int rows, int D,
+                                  float* dx, float* parts, haet_stream_t stream) {
+    if (!x || !gamma || !gy || !dx || !parts || rows < 1) return fail(HAET_E_ARG, "layernorm_bwd: bad arguments");
+    if (!haet_layernorm_supported(D)) return fail(HAET_E_ARG, "layernorm_bwd: D=%d unsupported (multiple of 4, <= 1024)", D);
+    const int blocks = haet_layernorm_bwd_num_parts(rows);
+    const int ch = (D / 4 + 63) / 64;
+    hipStream_t st = as_stream(stream);
+    switch (ch) {
+        case 1: hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), 0, st, x, gamma, gy, eps, rows, D, dx, parts); break;
+        case 2: hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, st, x, gamma, gy, eps, rows, D, dx, parts); break;
+        case 3: hipLaunchKernelGGL(layernorm_bwd_kernel<3>, dim3(blocks), dim3(256), 0, st, x, gamma, gy, eps, rows, D, dx, parts); break;
+        default: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, st, x, gamma, gy, eps, rows, D, dx, parts); break;
+    }
+    return check_launch("layernorm_bwd_kernel");
 }
 
 extern "C" int haet_linear_narrow_supported(int K, int O) { return (K >= 1 && K <= 16 && O >= 4 && O % 4 == 0 && O <= 2048) ? 1 : 0; }

@@ -256,6 +256,21 @@ def layernorm(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
     return out
 
 
+def layernorm_bwd(x: Tensor, weight: Tensor, gy: Tensor, eps: float):
+    """(dx, dgamma, dbeta) of nn.LayerNorm over the last dimension (haet_layernorm_bwd + the sum of its partials)."""
+    lib = _lib.load()
+    x, gy = _f32(x, "x"), _f32(gy, "gy")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    P = lib.haet_layernorm_bwd_num_parts(rows)
+    dx = torch.empty_like(x)
+    parts = torch.empty((P, 2 * D), dtype=torch.float32, device=x.device)
+    check(lib.haet_layernorm_bwd(_p(x), _p(_f32(weight.detach(), "weight")), _p(gy), float(eps), rows, D, _p(dx),
+                                 _p(parts), _stream()), "haet_layernorm_bwd")
+    s = parts.sum(dim=0)
+    return dx, s[:D], s[D:]
+
+
 def linear_narrow_supported(K: int, O: int) -> bool:
     return bool(_lib.load().haet_linear_narrow_supported(int(K), int(O)))
 

@@ -262,7 +262,7 @@ int haet_linear_wgrad(const float* G, const float* X, int N, int O, int K, float
 /* ------------------------------------------------------------------ the block around the path
  * Point-wise callers either side of Physics_Attention inside a Transolver block
  * (models/HAETransolver_Irregular_Mesh.py:114-134: LayerNorm -> Attn -> +res -> LayerNorm -> MLP -> +res;
- * preprocess MLP :186, 338-376), inference only.
+ * preprocess MLP :186, 338-376); forward kernels, plus the LayerNorm backward for training.
  *   haet_linear_act_fwd:    haet_linear_fwd with an epilogue activation (act 0 = none, 1 = GELU erf): the
  *                           Linear + nn.GELU pairs of models/components' MLP
  *   haet_layernorm_fwd:     nn.LayerNorm(D) over rows (biased variance, eps inside the root)
@@ -272,6 +272,11 @@ int haet_linear_act_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_
 int haet_layernorm_supported(int D);
 int haet_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int rows, int D,
                        float* out, haet_stream_t stream);
+/* backward of haet_layernorm_fwd: dx [rows, D] and per-workgroup partials parts [P][2 D] = {dgamma, dbeta}
+ * (P = haet_layernorm_bwd_num_parts(rows)); the statistics are recomputed from x.                        */
+int haet_layernorm_bwd_num_parts(int rows);
+int haet_layernorm_bwd(const float* x, const float* gamma, const float* gy, float eps, int rows, int D,
+                       float* dx, float* parts, haet_stream_t stream);
 int haet_linear_narrow_supported(int K, int O);
 int haet_linear_narrow_fwd(const float* x, const float* W /*[O,K]*/, const float* bias, int rows, int K, int O,
                            int act, float* out, haet_stream_t stream);

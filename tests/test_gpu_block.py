@@ -70,3 +70,48 @@ def test_model_fast_block_matches_stock_layers(family, hip_device, monkeypatch):
         stock = model(*args)
     assert torch.isfinite(fast).all()
     assert O.rel_l2(fast.cpu(), stock.cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("rows,D", [(1, 256), (1000, 256), (50001, 256), (33, 64), (100, 1024), (64, 36)])
+def test_layernorm_backward_vs_fp64(rows, D, hip_device):
+    from haet_amd import ops
+
+    g = torch.Generator().manual_seed(rows + D)
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.5)
+    w, b, gy = torch.randn(D, generator=g), torch.randn(D, generator=g), torch.randn(rows, D, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    torch.nn.functional.layer_norm(xr, (D,), wr, br, 1e-5).backward(gy.double())
+    dx, dg, db = ops.layernorm_bwd(x.to(hip_device), w.to(hip_device), gy.to(hip_device), 1e-5)
+    assert O.rel_l2(dx.cpu().double(), xr.grad) < 5e-6
+    assert O.rel_l2(dg.cpu().double(), wr.grad) < 5e-6
+    assert O.rel_l2(db.cpu().double(), br.grad) < 5e-6
+
+
+def test_model_training_step_fast_layers_match_stock(hip_device, monkeypatch):
+    """loss.backward() through the whole model with the LayerNorm / Linear layers as HIP autograd nodes against
+    the same step on the stock torch layers: loss, and every parameter gradient."""
+    import haet_amd
+
+    torch.manual_seed(2)
+    model = haet_amd.HAETransolver_Irregular_Mesh(space_dim=3, fun_dim=4, n_hidden=256, n_layers=2, n_head=8,
+                                                  mlp_ratio=2, out_dim=4, slice_num=64).to(hip_device).train()
+    x = torch.randn(1, 2500, 7, device=hip_device)
+    y = torch.randn(1, 2500, 4, device=hip_device)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def step():
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.mse_loss(model(x, None), y)
+        loss.backward()
+        return float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    loss_fast, g_fast = step()
+    monkeypatch.setenv("HAET_NO_BLOCK_FAST", "1")
+    loss_ref, g_ref = step()
+    assert abs(loss_fast - loss_ref) < 1e-5 * max(1.0, abs(loss_ref))
+    assert set(g_fast) == set(g_ref)
+    scale = max(float(g.norm()) for g in g_ref.values())
+    for name, gr in g_ref.items():
+        err = float((g_fast[name] - gr).norm()) / max(float(gr.norm()), 1e-4 * scale)
+        assert err < 2e-3, (name, err)

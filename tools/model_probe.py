@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--layers", type=int, default=1)
+    ap.add_argument("--train", action="store_true", help="time a training step (forward + backward, train mode)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
@@ -36,6 +37,18 @@ def main():
         torch.cuda.synchronize()
         return out, 1e3 * (time.perf_counter() - t0) / args.steps
 
+    if args.train:
+        model.train()
+        y = torch.randn(1, args.points, 4, device=dev)
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            torch.nn.functional.mse_loss(model(x, None), y).backward()
+
+        _, t = timed(step)
+        print(f"model training step ({args.layers} layer(s), {args.points} points): {t:.2f} ms, "
+              f"peak memory {torch.cuda.max_memory_allocated() / 1e9:.1f} GB")
+        return
     with torch.no_grad():
         _, t_all = timed(lambda: model(x, None))
         blk = model.blocks[0]
