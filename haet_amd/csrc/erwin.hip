@@ -521,8 +521,8 @@ __device__ __attribute__((noinline)) void ball_attention(int qkv, int ldq, int n
     }
 }
 
-// Ball attention on the matrix cores for head dim 8 (both hierarchy levels of the C3 shape) and
-// balls of <= 32 tokens: one wave per (32-token tile, head).
+// Ball attention on the matrix cores for head dims 8 (both hierarchy levels of the C3 shape), 16 and 32
+// (config C2) and balls of <= 32 tokens: one wave per (32-token tile, head).
 //   St[k][q] = sum_d K[k][d] Q[q][d]        v_mfma_f32_32x32x16_bf16 x 3 (split bf16; d padded 8 -> 16
 //                                           with zeros: the hf = 1 halves of both operands are zero)
 //   lane = query column, registers = the 16 keys (r&3) + 8(r>>2) + 4hf: the softmax over the keys of a
@@ -555,9 +555,10 @@ __device__ __forceinline__ f32x16 mfma3_32(u32x4 ah, u32x4 al, u32x4 bh, u32x4 b
     return c;
 }
 
-__device__ ERWIN_PHASE void ball_attention_mfma8(int qkv, int ldq, int n, int c, int heads,
-                                                               int ball, int perm, const Img out_) {
-    constexpr int HD = 8;
+template <int HD>  // 8, 16 or 32
+__device__ ERWIN_PHASE void ball_attention_mfma(int qkv, int ldq, int n, int c, int heads,
+                                                int ball, int perm, const Img out_) {
+    constexpr int NS = HD > 16 ? HD / 16 : 1;  // 16-wide k-steps of the score product
     const Img out = UI(out_);
     qkv = U(qkv), ldq = U(ldq), n = U(n), c = U(c), heads = U(heads), ball = U(ball), perm = U(perm);
     const int lane = threadIdx.x & 63, wave = U(threadIdx.x >> 6), hf = lane >> 5, l31 = lane & 31;
@@ -567,24 +568,31 @@ __device__ ERWIN_PHASE void ball_attention_mfma8(int qkv, int ldq, int n, int c,
         const int tile = item / heads, h = item - tile * heads;
         const int t = I(perm + 4 * (tile * 32 + l31));  // my token: key row of St, query column of St
         const int row = qkv + 4 * (t * ldq + h * HD);
-        float kv[8], qv[8];
-#pragma unroll
-        for (int e4 = 0; e4 < 2; ++e4) {  // every lane reads (rows are 16-B aligned: kPad); hf = 1 is
-            const f32x4 k4 = *reinterpret_cast<const f32x4*>(smem + row + 4 * (c + 4 * e4));  // the zero padding
-            const f32x4 q4 = *reinterpret_cast<const f32x4*>(smem + row + 16 * e4);           // of d = 8..15
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                kv[4 * e4 + e] = hf ? 0.f : k4[e];
-                qv[4 * e4 + e] = hf ? 0.f : q4[e] * qscale;
-            }
-        }
-        u32x4 kh, kl, qh, ql;
-        split8v(kv, kh, kl);
-        split8v(qv, qh, ql);
         f32x16 S;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] = 0.f;
-        S = mfma3_32(kh, kl, qh, ql, S);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            // this lane's 8 head-dim elements of the step: d = 16 s + 8 hf .. + 7 (HD = 8: the hf = 1 half is
+            // the zero padding of d = 8..15; every lane still reads -- rows are 16-B aligned: kPad)
+            const int d0 = HD == 8 ? 0 : 16 * s + 8 * hf;
+            const bool pad = HD == 8 && hf;
+            float kv[8], qv[8];
+#pragma unroll
+            for (int e4 = 0; e4 < 2; ++e4) {
+                const f32x4 k4 = *reinterpret_cast<const f32x4*>(smem + row + 4 * (c + d0 + 4 * e4));
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(smem + row + 4 * (d0 + 4 * e4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    kv[4 * e4 + e] = pad ? 0.f : k4[e];
+                    qv[4 * e4 + e] = pad ? 0.f : q4[e] * qscale;
+                }
+            }
+            u32x4 kh, kl, qh, ql;
+            split8v(kv, kh, kl);
+            split8v(qv, qh, ql);
+            S = mfma3_32(kh, kl, qh, ql, S);
+        }
         float m = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -610,7 +618,7 @@ __device__ ERWIN_PHASE void ball_attention_mfma8(int qkv, int ldq, int n, int c,
             for (int j = 0; j < 8; ++j) {
                 const int key = 16 * s + 8 * (j >> 2) + 4 * hf + (j & 3);  // the accumulator's key order
                 const int tk = __shfl(t, key);
-                const float v1 = F(qkv + 4 * (tk * ldq + 2 * c + h * HD + (l31 & 7)));  // unconditional read
+                const float v1 = F(qkv + 4 * (tk * ldq + 2 * c + h * HD + (l31 & (HD - 1))));  // unconditional read
                 vv[j] = l31 < HD ? v1 : 0.f;
                 pv[j] = S[8 * s + j];
             }
@@ -619,17 +627,19 @@ __device__ ERWIN_PHASE void ball_attention_mfma8(int qkv, int ldq, int n, int c,
             split8v(pv, ph, pl);
             O = mfma3_32(vh, vl, ph, pl, O);
         }
+        // lane (q, hf) holds O[q][d] for d = (r & 3) + 8 (r >> 2) + 4 hf, r < HD / 2 (rows d >= HD are zero)
         const float inv = 1.0f / l;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out.put(t, h * HD + 4 * hf + r, O[r] * inv);
+        for (int r = 0; r < HD / 2; ++r) out.put(t, h * HD + (r & 3) + 8 * (r >> 2) + 4 * hf, O[r] * inv);
     }
 }
 
 __device__ ERWIN_PHASE void attention_dispatch(int hd, int qkv, int ldq, int n, int c,
                                                              int heads, int ball, int perm, const Img out) {
-    if (hd == 8 && n % 32 == 0 && ball <= 32 && (ball & (ball - 1)) == 0) {
-        ball_attention_mfma8(qkv, ldq, n, c, heads, ball, perm, out);
-        return;
+    if (n % 32 == 0 && ball <= 32 && (ball & (ball - 1)) == 0) {
+        if (hd == 8) return ball_attention_mfma<8>(qkv, ldq, n, c, heads, ball, perm, out);
+        if (hd == 16) return ball_attention_mfma<16>(qkv, ldq, n, c, heads, ball, perm, out);
+        if (hd == 32) return ball_attention_mfma<32>(qkv, ldq, n, c, heads, ball, perm, out);
     }
     switch (hd) {
         case 1: ball_attention<1>(qkv, ldq, n, c, heads, ball, perm, out); break;
