@@ -313,11 +313,11 @@ __global__ __launch_bounds__(256) void slice_bwd_points_kernel(
 
 // ----------------------------------------------------------------------------- host side
 int slice_shape_ok(int B, int N, int H, int C, int M);  // slice_valu.hip
-// slice_bwd_mfma.hip: the same passes on v_mfma_f32_32x32x2_f32 (C = 32, M in {32, 64, 128}), same records
+// slice_bwd_mfma.hip: the same passes on v_mfma_f32_32x32x2_f32 (C = 32, M in {32, 64, 128}; C = 64, M in {32, 64}), same records
 bool slice_bwd_mfma_ok(int C, int M);
 int slice_bwd_mfma(int mode, const float*, const float*, const float*, const float*, float, float, float,
                    const float*, const float*, const float*, const float*, const float*, const float*, int, int, int,
-                   int, float*, float*, hipStream_t);
+                   int, int, float*, float*, hipStream_t);
 
 static bool use_bwd_mfma(int C, int M) {  // HAET_FORCE_VALU=1 routes every shape through the generic kernels (tests)
     const char* e = getenv("HAET_FORCE_VALU");
@@ -389,7 +389,7 @@ extern "C" int haet_deslice_bwd_tokens(const float* x_lin, const float* Ws, cons
     if (rc != HAET_OK) return rc;
     if (use_bwd_mfma(C, M))
         return slice_bwd_mfma(0, x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, g_out, nullptr, nullptr,
-                              nullptr, B, N, H, M, nullptr, parts, as_stream(stream));
+                              nullptr, B, N, H, C, M, nullptr, parts, as_stream(stream));
     const int chunk = pick_chunk(N);
     dim3 grid((N + chunk - 1) / chunk, B * H);
     HAET_BWD_DISPATCH(launch_tokens, grid, as_stream(stream), x_lin, Ws, bs, wt, bt, base_temp, c0, col_max,
@@ -406,7 +406,7 @@ extern "C" int haet_slice_bwd_points(const float* x_lin, const float* Ws, const 
     int rc = slice_shape_ok(B, N, H, C, M);
     if (rc != HAET_OK) return rc;
     if (use_bwd_mfma(C, M))
-        return slice_bwd_mfma(1, x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, g_out, S2, dS, A, B, N, H, M,
+        return slice_bwd_mfma(1, x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, g_out, S2, dS, A, B, N, H, C, M,
                               dx_lin, param_parts, as_stream(stream));
     const int chunk = pick_chunk(N);
     dim3 grid((N + chunk - 1) / chunk, B * H);

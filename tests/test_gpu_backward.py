@@ -30,13 +30,13 @@ def _passes_fp64(x, Ws, bs, wt, bt, base, c0, S2):
 
 @pytest.mark.parametrize("B,N,H,C,M", [(1, 700, 4, 16, 16), (2, 333, 8, 32, 64), (1, 1, 2, 32, 32), (1, 5000, 8, 32, 64),
                                        (1, 1025, 4, 64, 32), (1, 257, 2, 32, 128), (2, 64, 3, 8, 8), (1, 300, 2, 64, 100),
-                                       (1, 4097, 2, 16, 48)])
+                                       (1, 4097, 2, 16, 48), (2, 700, 2, 64, 64), (1, 33, 4, 64, 32)])
 @pytest.mark.parametrize("path", ["auto", "valu"])
 def test_backward_passes_vs_fp64_autograd(B, N, H, C, M, path, hip_device, monkeypatch):
     from haet_amd import ops
 
     if path == "valu":  # the generic fp32 vector-ALU kernels for every shape (auto: MFMA kernels where they apply)
-        if not (C == 32 and M in (32, 64, 128)):
+        if not ((C == 32 and M in (32, 64, 128)) or (C == 64 and M in (32, 64))):
             pytest.skip("auto already runs the generic kernels for this shape")
         monkeypatch.setenv("HAET_FORCE_VALU", "1")
 
