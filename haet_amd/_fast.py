@@ -145,5 +145,14 @@ def layer_norm(ln: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
     return ln(x)
 
 
+def add_layer_norm(ln: nn.LayerNorm, x: torch.Tensor, res: torch.Tensor):
+    """(x + res, ln(x + res)); one kernel at inference."""
+    if (enabled(x) and res.shape == x.shape and res.dtype == torch.float32 and ln.elementwise_affine
+            and ln.bias is not None and len(ln.normalized_shape) == 1 and ops.layernorm_supported(ln.normalized_shape[0])):
+        return ops.add_layernorm(x, res, ln.weight, ln.bias, ln.eps)
+    s = x + res
+    return s, layer_norm(ln, s)
+
+
 def is_exact_gelu(act: nn.Module) -> bool:
     return isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none"

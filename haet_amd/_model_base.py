@@ -33,11 +33,11 @@ class TransolverErwinBlockBase(nn.Module):
 
     def forward(self, fx):
         if _fast.usable(fx):  # LayerNorms / MLP on the HIP kernels too, both directions (haet_amd/_fast.py)
-            fx = self.Attn(_fast.layer_norm(self.ln_1, fx)) + fx
-            fx = self.mlp(_fast.layer_norm(self.ln_2, fx)) + fx
+            fx, h = _fast.add_layer_norm(self.ln_2, self.Attn(_fast.layer_norm(self.ln_1, fx)), fx)
             if self.last_layer:
-                return _fast.linear(self.mlp2, _fast.layer_norm(self.ln_3, fx))
-            return fx
+                _, h = _fast.add_layer_norm(self.ln_3, self.mlp(h), fx)
+                return _fast.linear(self.mlp2, h)
+            return self.mlp(h) + fx
         fx = self.Attn(self.ln_1(fx)) + fx
         fx = self.mlp(self.ln_2(fx)) + fx
         if self.last_layer:

@@ -18,10 +18,13 @@ __device__ __forceinline__ float gelu_erf(float v) {  // nn.GELU(approximate='no
 
 // One wave per row: D / 4 float4 chunks over the 64 lanes (D <= 1024), two-pass statistics in registers
 // (mean, then the centred sum of squares: torch's numerics), biased variance, eps inside the root.
-template <int CH>  // chunks per lane
+// RES: the row is x + res (the block's residual add, HAETransolver_Irregular_Mesh.py:125-128), written to `sum`
+// on the way -- one pass instead of an add kernel and a LayerNorm kernel.
+template <int CH, bool RES = false>  // chunks per lane
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int rows, int D,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, const float* __restrict__ res = nullptr,
+                                                        float* __restrict__ sum = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const int nch = D >> 2;
@@ -42,6 +45,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         for (int c = 0; c < CH; ++c) {
             const int ch = lane + 64 * c;
             v[c] = ch < nch ? *reinterpret_cast<const f4v*>(xr + 4 * ch) : f4v{0.f, 0.f, 0.f, 0.f};
+            if (RES && ch < nch) {
+                v[c] += *reinterpret_cast<const f4v*>(res + (size_t)r * D + 4 * ch);
+                *reinterpret_cast<f4v*>(sum + (size_t)r * D + 4 * ch) = v[c];
+            }
             s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
         }
         const float mean = wave_sum(s) * inv_d;
@@ -213,12 +220,28 @@ extern "C" int haet_layernorm_fwd(const float* x, const float* gamma, const floa
     const int ch = (D / 4 + 63) / 64;
     hipStream_t st = as_stream(stream);
     switch (ch) {
-        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out); break;
-        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out); break;
-        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out); break;
-        default: hipLaunchKernelGGL(layernorm_kernel<4>, dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out); break;
+        case 1: hipLaunchKernelGGL((layernorm_kernel<1, false>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out, (const float*)nullptr, (float*)nullptr); break;
+        case 2: hipLaunchKernelGGL((layernorm_kernel<2, false>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out, (const float*)nullptr, (float*)nullptr); break;
+        case 3: hipLaunchKernelGGL((layernorm_kernel<3, false>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out, (const float*)nullptr, (float*)nullptr); break;
+        default: hipLaunchKernelGGL((layernorm_kernel<4, false>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out, (const float*)nullptr, (float*)nullptr); break;
     }
     return check_launch("layernorm_kernel");
+}
+
+extern "C" int haet_add_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta,
+                                      float eps, int rows, int D, float* sum, float* out, haet_stream_t stream) {
+    if (!x || !res || !gamma || !beta || !sum || !out || rows < 1) return fail(HAET_E_ARG, "add_layernorm_fwd: bad arguments");
+    if (!haet_layernorm_supported(D)) return fail(HAET_E_ARG, "add_layernorm_fwd: D=%d unsupported (multiple of 4, <= 1024)", D);
+    const int blocks = rows < 4 * 2048 ? (rows + 3) / 4 : 2048;
+    const int ch = (D / 4 + 63) / 64;
+    hipStream_t st = as_stream(stream);
+    switch (ch) {
+        case 1: hipLaunchKernelGGL((layernorm_kernel<1, true>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out, res, sum); break;
+        case 2: hipLaunchKernelGGL((layernorm_kernel<2, true>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out, res, sum); break;
+        case 3: hipLaunchKernelGGL((layernorm_kernel<3, true>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out, res, sum); break;
+        default: hipLaunchKernelGGL((layernorm_kernel<4, true>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out, res, sum); break;
+    }
+    return check_launch("layernorm_kernel<res>");
 }
 
 extern "C" int haet_layernorm_bwd_num_parts(int rows) { return rows < 4 * 1024 ? (rows + 3) / 4 : 1024; }

@@ -256,6 +256,17 @@ def layernorm(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
     return out
 
 
+def add_layernorm(x: Tensor, res: Tensor, weight: Tensor, bias: Tensor, eps: float):
+    """(x + res, LayerNorm(x + res)) in one pass (haet_add_layernorm_fwd)."""
+    lib = _lib.load()
+    x, res = _f32(x, "x"), _f32(res, "res")
+    D = x.shape[-1]
+    s, out = torch.empty_like(x), torch.empty_like(x)
+    check(lib.haet_add_layernorm_fwd(_p(x), _p(res), _p(_f32(weight.detach(), "weight")), _p(_f32(bias.detach(), "bias")),
+                                     float(eps), x.numel() // D, D, _p(s), _p(out), _stream()), "haet_add_layernorm_fwd")
+    return s, out
+
+
 def layernorm_bwd(x: Tensor, weight: Tensor, gy: Tensor, eps: float):
     """(dx, dgamma, dbeta) of nn.LayerNorm over the last dimension (haet_layernorm_bwd + the sum of its partials)."""
     lib = _lib.load()

@@ -272,6 +272,9 @@ int haet_linear_act_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_
 int haet_layernorm_supported(int D);
 int haet_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int rows, int D,
                        float* out, haet_stream_t stream);
+/* sum = x + res and out = LayerNorm(sum) in one pass (the block's residual add feeding its next LayerNorm) */
+int haet_add_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps,
+                           int rows, int D, float* sum, float* out, haet_stream_t stream);
 /* backward of haet_layernorm_fwd: dx [rows, D] and per-workgroup partials parts [P][2 D] = {dgamma, dbeta}
  * (P = haet_layernorm_bwd_num_parts(rows)); the statistics are recomputed from x.                        */
 int haet_layernorm_bwd_num_parts(int rows);

@@ -115,3 +115,16 @@ def test_model_training_step_fast_layers_match_stock(hip_device, monkeypatch):
     for name, gr in g_ref.items():
         err = float((g_fast[name] - gr).norm()) / max(float(gr.norm()), 1e-4 * scale)
         assert err < 2e-3, (name, err)
+
+
+@pytest.mark.parametrize("rows,D", [(1, 256), (4097, 256), (77, 128), (10, 1024)])
+def test_add_layernorm_vs_fp64(rows, D, hip_device):
+    from haet_amd import ops
+
+    g = torch.Generator().manual_seed(rows + D)
+    x, r = torch.randn(rows, D, generator=g), torch.randn(rows, D, generator=g) * 2
+    w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    s, out = ops.add_layernorm(x.to(hip_device), r.to(hip_device), w.to(hip_device), b.to(hip_device), 1e-5)
+    assert torch.equal(s.cpu(), x + r)
+    ref = torch.nn.functional.layer_norm((x + r).double(), (D,), w.double(), b.double(), 1e-5)
+    assert O.rel_l2(out.cpu().double(), ref) < 2e-6
