@@ -36,5 +36,9 @@ class Physics_Attention_Irregular_Mesh(PhysicsAttentionBase):
                 grads[id(lin.bias)] = gb
         return (self._linear_transposed("in_project_x", lin, g_lin) if need_x else None), grads
 
-    def project_split(self, x, sp):
-        return self._project_split_linear("in_project_x", self.in_project_x, x, sp)
+    def project_split(self, x, sp, pre_norm=None):
+        return self._project_split_linear("in_project_x", self.in_project_x, x, sp, pre_norm)
+
+    def fuses_pre_norm(self, x, ln):
+        return (ln.elementwise_affine and ln.bias is not None and tuple(ln.normalized_shape) == (self.in_project_x.in_features,)
+                and self.shard_group is None and self._split_linear_applies(self.in_project_x, x))

@@ -99,10 +99,15 @@ class PhysicsAttentionBase(nn.Module):
     def project(self, x: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
 
-    def project_split(self, x: torch.Tensor, sp):
+    def project_split(self, x: torch.Tensor, sp, pre_norm=None):
         """Projection straight into the streaming passes' operand format (ops.SplitPoints), or None
-        when this variant / shape has no such path (then `project` + the fp32 passes run)."""
+        when this variant / shape has no such path (then `project` + the fp32 passes run).  `pre_norm`:
+        a LayerNorm to apply to x inside the projection (only ever passed when the variant supports it)."""
         return None
+
+    def fuses_pre_norm(self, x: torch.Tensor, ln) -> bool:
+        """Whether `project_split(x, sp, pre_norm=ln)` can take the block's LayerNorm into its loader."""
+        return False
 
     def _conv_project(self, x: torch.Tensor, grid):
         """Conv2d / Conv3d in_project_x as the HIP implicit GEMM over the channels-last points, or None
@@ -147,16 +152,20 @@ class PhysicsAttentionBase(nn.Module):
         lo = plane if prev is not None else 0
         return y[:, lo:lo + n].contiguous()
 
-    def _project_split_linear(self, name: str, lin: nn.Linear, x: torch.Tensor, sp):
+    def _split_linear_applies(self, lin: nn.Linear, x: torch.Tensor) -> bool:
         B, N, _ = x.shape
-        H, C, G = self.heads, self.dim_head, self.slice_num
         if os.environ.get("HAET_NO_SPLIT_FORMAT") or x.dtype != torch.float32:
-            return None
-        if not (ops.project_split_supported(lin.in_features, lin.out_features, B * N)
-                and ops.slice_split_supported(B, N, H, C, G)):
+            return False
+        return (ops.project_split_supported(lin.in_features, lin.out_features, B * N)
+                and ops.slice_split_supported(B, N, self.heads, self.dim_head, self.slice_num)
+                and ops.linear_supported(lin.in_features, lin.out_features))
+
+    def _project_split_linear(self, name: str, lin: nn.Linear, x: torch.Tensor, sp, pre_norm=None):
+        if not self._split_linear_applies(lin, x):
             return None
         w = self._split_linear(name, lin)
-        return None if w is None else ops.project_split(x, w, sp, H, C)
+        ln = None if pre_norm is None else (pre_norm.weight, pre_norm.bias, pre_norm.eps)
+        return None if w is None else ops.project_split(x, w, sp, self.heads, self.dim_head, ln)
 
     def _split_linear(self, name: str, lin: nn.Linear):
         """haet_linear_fwd operand of a Linear (cached per weight version), or None when the shape
@@ -202,7 +211,12 @@ class PhysicsAttentionBase(nn.Module):
         self.__dict__["_grad_check_stale"] = True
         return super()._apply(fn, *args, **kwargs)
 
-    def forward(self, x: torch.Tensor, return_intermediates: bool = False):
+    def forward(self, x: torch.Tensor, return_intermediates: bool = False, pre_norm: Optional[nn.LayerNorm] = None):
+        """`pre_norm` (not in the reference's signature; used by the block's inference fast path): a LayerNorm
+        to apply to x first -- fused into the projection GEMM's loader where the variant supports it."""
+        if pre_norm is not None and not (x.is_cuda and not torch.is_grad_enabled() and not self.training
+                                         and self.fuses_pre_norm(x, pre_norm)):
+            x, pre_norm = pre_norm(x), None
         if not x.is_cuda:
             raise HaetError("Physics_Attention_* (haet_amd) runs on a ROCm device only; move the module "
                             "and its input with .cuda() -- there is no CPU fallback")
@@ -223,7 +237,7 @@ class PhysicsAttentionBase(nn.Module):
                 return _autograd.HipForwardTorchBackward.apply(self, x, *self.parameters())
             y = _autograd.PhysicsAttentionFunction.apply(self, x, *self.parameters())
             return self.to_out[1](y).to(x.dtype)
-        return self._forward_hip(x, return_intermediates)
+        return self._forward_hip(x, return_intermediates, pre_norm)
 
     def project_torch(self, x: torch.Tensor) -> torch.Tensor:
         """The projection as stock torch ops (differentiable path, haet_amd/_autograd.py)."""
@@ -253,7 +267,7 @@ class PhysicsAttentionBase(nn.Module):
             cache[name] = (key, ops.SplitLinear(lin.weight.detach().t().contiguous(), None))
         return ops.linear(g, cache[name][1])
 
-    def _forward_hip(self, x: torch.Tensor, return_intermediates: bool = False):
+    def _forward_hip(self, x: torch.Tensor, return_intermediates: bool = False, pre_norm=None):
         B, N, _ = x.shape
         H, C, G = self.heads, self.dim_head, self.slice_num
         self.__dict__["_event_chain"] = [None] if self.stage_events is not None else None
@@ -261,7 +275,9 @@ class PhysicsAttentionBase(nn.Module):
         sp = self._slice_params()
         xs = None
         with ev("project"):
-            xs = self.project_split(x, sp)                               # fused operand format, or None
+            xs = self.project_split(x, sp, pre_norm)                     # fused operand format, or None
+            if xs is None and pre_norm is not None:
+                x = pre_norm(x)
             x_lin = None if xs is not None else self.project(x).float().contiguous()  # [B, N, H*C]
         with ev("slice"):
             parts = (ops.slice_partials_split(xs, sp, G) if xs is not None

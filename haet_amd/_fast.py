@@ -105,8 +105,20 @@ def _split_of(lin: nn.Linear, shift: torch.Tensor = None) -> ops.SplitLinear:
     return hit[1]
 
 
-def linear(lin: nn.Linear, x: torch.Tensor, gelu: bool = False, shift: torch.Tensor = None) -> torch.Tensor:
+def _ln_fusable(ln, lin: nn.Linear, x: torch.Tensor) -> bool:
+    return (ln is not None and not torch.is_grad_enabled() and ln.elementwise_affine and ln.bias is not None
+            and tuple(ln.normalized_shape) == (lin.in_features,) and ops.linear_supported(lin.in_features, lin.out_features)
+            and ops.linear_ln_supported(lin.in_features, lin.out_features, x.numel() // lin.in_features))
+
+
+def linear(lin: nn.Linear, x: torch.Tensor, gelu: bool = False, shift: torch.Tensor = None,
+           pre_norm: nn.LayerNorm = None) -> torch.Tensor:
+    """`pre_norm`: a LayerNorm applied to x first -- inside the GEMM's loader where the kernel allows."""
     K, O = lin.in_features, lin.out_features
+    if pre_norm is not None:
+        if _ln_fusable(pre_norm, lin, x):
+            return ops.linear(x, _split_of(lin, shift), gelu, ln=(pre_norm.weight, pre_norm.bias, pre_norm.eps))
+        x = layer_norm(pre_norm, x)
     if torch.is_grad_enabled():  # training: autograd node on the kernels, activation / shift by torch
         if ops.linear_supported(K, O) or ops.linear_narrow_supported(K, O):
             y = _HipLinear.apply(x, lin.weight, lin.bias, lin)
@@ -124,12 +136,13 @@ def linear(lin: nn.Linear, x: torch.Tensor, gelu: bool = False, shift: torch.Ten
     return y if shift is None else y.add_(shift)
 
 
-def mlp(m, x: torch.Tensor, shift: torch.Tensor = None):
+def mlp(m, x: torch.Tensor, shift: torch.Tensor = None, pre_norm: nn.LayerNorm = None):
     """components.MLP forward (GELU variant) on the HIP kernels, or None when it does not apply;
-    `shift` is added to the output (folded into the last bias)."""
+    `shift` is added to the output (folded into the last bias), `pre_norm` is applied to x first (in the
+    first GEMM's loader where possible)."""
     if not (usable(x) and is_exact_gelu(m.linear_pre[1])):
         return None
-    x = linear(m.linear_pre[0], x, gelu=True)
+    x = linear(m.linear_pre[0], x, gelu=True, pre_norm=pre_norm)
     for i in range(m.n_layers):
         y = linear(m.linears[i][0], x, gelu=True)
         x = y + x if m.res else y

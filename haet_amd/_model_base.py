@@ -33,11 +33,22 @@ class TransolverErwinBlockBase(nn.Module):
 
     def forward(self, fx):
         if _fast.usable(fx):  # LayerNorms / MLP on the HIP kernels too, both directions (haet_amd/_fast.py)
-            fx, h = _fast.add_layer_norm(self.ln_2, self.Attn(_fast.layer_norm(self.ln_1, fx)), fx)
+            if _fast.enabled(fx):
+                # inference: ln_1 rides in the projection GEMM's loader, ln_2 in the MLP's first GEMM's
+                a = self.Attn(fx, pre_norm=self.ln_1)
+                fx = a.add_(fx)
+                m = _fast.mlp(self.mlp, fx, pre_norm=self.ln_2)
+                if m is None:
+                    m = self.mlp(_fast.layer_norm(self.ln_2, fx))
+                if self.last_layer:
+                    _, h = _fast.add_layer_norm(self.ln_3, m, fx)
+                    return _fast.linear(self.mlp2, h)
+                return m.add_(fx)
+            fx = self.Attn(_fast.layer_norm(self.ln_1, fx)) + fx
+            m = self.mlp(_fast.layer_norm(self.ln_2, fx))
             if self.last_layer:
-                _, h = _fast.add_layer_norm(self.ln_3, self.mlp(h), fx)
-                return _fast.linear(self.mlp2, h)
-            return self.mlp(h) + fx
+                return _fast.linear(self.mlp2, _fast.layer_norm(self.ln_3, m + fx))
+            return m + fx
         fx = self.Attn(self.ln_1(fx)) + fx
         fx = self.mlp(self.ln_2(fx)) + fx
         if self.last_layer:

@@ -346,12 +346,35 @@ constexpr int WS_IMGP = 2 * GIMG + 32;  // {hi, lo} image pair + 8 banks of skew
 // operand format instead of fp32 -- per 4 channels 16 B = {4 x bf16 hi, 4 x bf16 lo}, same row stride as
 // fp32 -- together with s[n][h] = log2(e) / tau(n, h) (Ada-Temp, IrregularMesh.py:168), so the slice
 // and de-slice loaders only copy.  They are bound by vector issue; the GEMM has the slack.
+// Sum over the LPR (64 or 32) consecutive lanes that hold one x row, in every lane, without LDS-crossbar
+// operations (the loader runs inside the counted-wait loop): rotations inside the 16-lane DPP rows, then the four
+// row sums through scalar registers.
+template <int LPR>
+__device__ __forceinline__ float row_lanes_sum(float v, int hf) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));  // row_ror:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false));  // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xF, 0xF, false));  // row_ror:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, false));  // row_ror:1
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    if (LPR == 64) return (r0 + r1) + (r2 + r3);
+    return hf ? r2 + r3 : r0 + r1;
+}
+
 struct SplitArgs {
     const float* wt;  // ada_temp_linear.weight [32]
     float bt, base_temp;
     float* s_out;     // [Nrows][O / 32]
+    // LNORM: nn.LayerNorm(K) applied to every x row in the loader (ln_1 in front of in_project_x, ln_2 in
+    // front of the block MLP: HAETransolver_Irregular_Mesh.py:125-128) -- the row is in one wave instruction
+    // anyway, the normalised activations never exist in HBM
+    const float* ln_g;
+    const float* ln_b;
+    float ln_eps;
 };
-template <int NKT, int S, bool SPLIT = false, int ACT = 0>
+template <int NKT, int S, bool SPLIT = false, int ACT = 0, bool LNORM = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ Whi,
     const unsigned short* __restrict__ Wlo, const float* __restrict__ bias, int Nrows, int O,
@@ -399,7 +422,26 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(
         const int row = 8 * wave + 4 * h + lrow;
         st_off[h] = (row >> 5) * RBSZ + lkt * WS_IMGP + g_off(row & 31, lq >> 1) + ((lq & 1) << 3) - 4 * h * 64;
     }
-    auto stage = [&](int tbuf, int j, const f32x4 v) {
+    f32x4 lng = {1.f, 1.f, 1.f, 1.f}, lnb = {0.f, 0.f, 0.f, 0.f};
+    if (LNORM) {
+        lng = *reinterpret_cast<const f32x4*>(sa.ln_g + 4 * lcol);
+        lnb = *reinterpret_cast<const f32x4*>(sa.ln_b + 4 * lcol);
+    }
+    auto stage = [&](int tbuf, int j, const f32x4 vin) {
+        f32x4 v = vin;
+        if (LNORM) {  // two-pass statistics over the LPR lanes that hold this row (torch's numerics)
+            static_assert(!LNORM || LPR == 64 || LPR == 32, "one or two rows per wave load");
+            const float mean = row_lanes_sum<LPR>((v[0] + v[1]) + (v[2] + v[3]), hf) * (1.0f / K);
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] -= mean;
+                q = fmaf(v[e], v[e], q);
+            }
+            const float rstd = rsqrtf(row_lanes_sum<LPR>(q, hf) * (1.0f / K) + sa.ln_eps);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e] * rstd, lng[e], lnb[e]);
+        }
         const int off = tbuf + st_off[j >= NKT / 2] + RPI * j * 64;
         const unsigned h01 = g_pack(v[0], v[1]), h23 = g_pack(v[2], v[3]);
         const u32x2 hi = {h01, h23};
@@ -600,7 +642,8 @@ extern "C" int haet_linear_supported(int K, int O) {
 }
 
 static int linear_fwd_impl(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias, int Nrows,
-                           int K, int O, int act, float* out, haet_stream_t stream) {
+                           int K, int O, int act, float* out, haet_stream_t stream, const float* ln_g = nullptr,
+                           const float* ln_b = nullptr, float ln_eps = 0.f) {
     if (!x || !W_hi || !W_lo || !out || Nrows < 1 || (act != 0 && act != 1)) return fail(HAET_E_ARG, "linear_fwd: bad arguments");
     if (!haet_linear_supported(K, O))
         return fail(HAET_E_ARG, "linear_fwd: K=%d (multiple of 32) / O=%d (multiple of 128) unsupported", K, O);
@@ -615,12 +658,18 @@ static int linear_fwd_impl(const float* x, const uint16_t* W_hi, const uint16_t*
             if (lds > 64 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi, W_lo, bias, Nrows,
-                               O, tiles, out, SplitArgs{nullptr, 0.f, 0.f, nullptr});
+                               O, tiles, out, SplitArgs{nullptr, 0.f, 0.f, nullptr, ln_g, ln_b, ln_eps});
         };
+        if (ln_g) {
+            if (K == 256) { if (act) go(gemm_ws_kernel<8, 4, false, 1, true>); else go(gemm_ws_kernel<8, 4, false, 0, true>); }
+            else { if (act) go(gemm_ws_kernel<4, 4, false, 1, true>); else go(gemm_ws_kernel<4, 4, false, 0, true>); }
+            return check_launch("gemm_ws_kernel<ln>");
+        }
         if (K == 256) { if (act) go(gemm_ws_kernel<8, 4, false, 1>); else go(gemm_ws_kernel<8, 4>); }
         else { if (act) go(gemm_ws_kernel<4, 4, false, 1>); else go(gemm_ws_kernel<4, 4>); }
         return check_launch("gemm_ws_kernel");
     }
+    if (ln_g) return fail(HAET_E_ARG, "linear_ln_fwd: K=%d O=%d rows=%d outside the W-stationary kernel", K, O, Nrows);
     // 256-row workgroup tiles (W staged once per 256 rows) when there are enough rows to fill the
     // chip, 128-row tiles otherwise; 128-column variant for O % 256 != 0
     const bool big = Nrows >= 256 * 256 && O % 256 == 0;
@@ -664,14 +713,22 @@ extern "C" int haet_linear_act_fwd(const float* x, const uint16_t* W_hi, const u
     return linear_fwd_impl(x, W_hi, W_lo, bias, Nrows, K, O, act, out, stream);
 }
 
+// LayerNorm(K) fused into the loader of the W-stationary kernel (same envelope as haet_project_split_fwd)
+extern "C" int haet_linear_ln_fwd(const float* x, const float* ln_g, const float* ln_b, float ln_eps,
+                                  const uint16_t* W_hi, const uint16_t* W_lo, const float* bias, int Nrows, int K,
+                                  int O, int act, float* out, haet_stream_t stream) {
+    if (!ln_g || !ln_b) return fail(HAET_E_ARG, "linear_ln_fwd: null LayerNorm parameters");
+    return linear_fwd_impl(x, W_hi, W_lo, bias, Nrows, K, O, act, out, stream, ln_g, ln_b, ln_eps);
+}
+
 extern "C" int haet_project_split_supported(int K, int O, int Nrows) {
     return (O % 256 == 0 && (K == 128 || K == 256) && Nrows >= 64) ? 1 : 0;
 }
 
-extern "C" int haet_project_split_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo,
-                                      const float* bias, const float* wt, float bt, float base_temp,
-                                      int Nrows, int K, int O, void* x_split, float* s_out,
-                                      haet_stream_t stream) {
+static int project_split_impl(const float* x, const uint16_t* W_hi, const uint16_t* W_lo,
+                              const float* bias, const float* wt, float bt, float base_temp,
+                              int Nrows, int K, int O, void* x_split, float* s_out,
+                              haet_stream_t stream, const float* ln_g, const float* ln_b, float ln_eps) {
     if (!x || !W_hi || !W_lo || !wt || !x_split || !s_out)
         return fail(HAET_E_ARG, "project_split_fwd: null pointer");
     if (!haet_project_split_supported(K, O, Nrows))
@@ -683,11 +740,33 @@ extern "C" int haet_project_split_fwd(const float* x, const uint16_t* W_hi, cons
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi, W_lo, bias, Nrows, O,
-                           tiles, reinterpret_cast<float*>(x_split), SplitArgs{wt, bt, base_temp, s_out});
+                           tiles, reinterpret_cast<float*>(x_split), SplitArgs{wt, bt, base_temp, s_out, ln_g, ln_b, ln_eps});
     };
+    if (ln_g) {
+        if (K == 256) go(gemm_ws_kernel<8, 4, true, 0, true>);
+        else go(gemm_ws_kernel<4, 4, true, 0, true>);
+        return check_launch("gemm_ws_kernel<split, ln>");
+    }
     if (K == 256) go(gemm_ws_kernel<8, 4, true>);
     else go(gemm_ws_kernel<4, 4, true>);
     return check_launch("gemm_ws_kernel<split>");
+}
+
+extern "C" int haet_project_split_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo,
+                                      const float* bias, const float* wt, float bt, float base_temp,
+                                      int Nrows, int K, int O, void* x_split, float* s_out,
+                                      haet_stream_t stream) {
+    return project_split_impl(x, W_hi, W_lo, bias, wt, bt, base_temp, Nrows, K, O, x_split, s_out, stream, nullptr,
+                              nullptr, 0.f);
+}
+
+extern "C" int haet_project_split_ln_fwd(const float* x, const float* ln_g, const float* ln_b, float ln_eps,
+                                         const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
+                                         const float* wt, float bt, float base_temp, int Nrows, int K, int O,
+                                         void* x_split, float* s_out, haet_stream_t stream) {
+    if (!ln_g || !ln_b) return fail(HAET_E_ARG, "project_split_ln_fwd: null LayerNorm parameters");
+    return project_split_impl(x, W_hi, W_lo, bias, wt, bt, base_temp, Nrows, K, O, x_split, s_out, stream, ln_g, ln_b,
+                              ln_eps);
 }
 
 // Conv2d / Conv3d projection (kernel k, stride 1, padding k/2) over a channels-last grid, as an

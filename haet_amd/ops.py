@@ -224,14 +224,23 @@ def linear_supported(K: int, O: int) -> bool:
     return bool(_lib.load().haet_linear_supported(int(K), int(O)))
 
 
-def linear(x: Tensor, w: SplitLinear, gelu: bool = False) -> Tensor:
+def linear_ln_supported(K: int, O: int, rows: int) -> bool:
+    """LayerNorm fused into the GEMM's loader: the W-stationary kernel's envelope."""
+    return project_split_supported(K, O, rows)
+
+
+def linear(x: Tensor, w: SplitLinear, gelu: bool = False, ln=None) -> Tensor:
     """out[..., O] = x[..., K] @ W^T + b on the matrix cores (split-bf16, fp32-class accuracy), optionally
-    followed by GELU (erf) in the epilogue."""
+    followed by GELU (erf) in the epilogue; `ln` = (weight, bias, eps) applies nn.LayerNorm(K) to x in the loader."""
     lib = _lib.load()
     x = _f32(x, "x")
     rows = x.numel() // w.K
     out = torch.empty(x.shape[:-1] + (w.O,), dtype=torch.float32, device=x.device)
-    if gelu:
+    if ln is not None:
+        check(lib.haet_linear_ln_fwd(_p(x), _p(_f32(ln[0].detach(), "ln.weight")), _p(_f32(ln[1].detach(), "ln.bias")),
+                                     float(ln[2]), _p(w.hi), _p(w.lo), _p(w.bias), rows, w.K, w.O, 1 if gelu else 0,
+                                     _p(out), _stream()), "haet_linear_ln_fwd")
+    elif gelu:
         check(lib.haet_linear_act_fwd(_p(x), _p(w.hi), _p(w.lo), _p(w.bias), rows, w.K, w.O, 1, _p(out), _stream()),
               "haet_linear_act_fwd")
     else:
@@ -343,13 +352,19 @@ def slice_split_supported(B: int, N: int, H: int, C: int, M: int) -> bool:
     return bool(_lib.load().haet_slice_split_supported(B, N, H, C, M))
 
 
-def project_split(x: Tensor, w: SplitLinear, p: SliceParams, H: int, C: int) -> SplitPoints:
-    """in_project_x on the matrix cores, output in the split operand format + s = log2(e)/tau."""
+def project_split(x: Tensor, w: SplitLinear, p: SliceParams, H: int, C: int, ln=None) -> SplitPoints:
+    """in_project_x on the matrix cores, output in the split operand format + s = log2(e)/tau;
+    `ln` = (weight, bias, eps): nn.LayerNorm over x's last dimension fused into the loader."""
     lib = _lib.load()
     x = _f32(x, "x")
     B, N, K = x.shape
     cells = torch.empty((B, N, w.O), dtype=torch.float32, device=x.device)
     s = torch.empty((B, N, H), dtype=torch.float32, device=x.device)
+    if ln is not None:
+        check(lib.haet_project_split_ln_fwd(_p(x), _p(_f32(ln[0].detach(), "ln.weight")), _p(_f32(ln[1].detach(), "ln.bias")),
+                                            float(ln[2]), _p(w.hi), _p(w.lo), _p(w.bias), _p(p.wt), p.bt, p.base_temp,
+                                            B * N, K, w.O, _p(cells), _p(s), _stream()), "haet_project_split_ln_fwd")
+        return SplitPoints(cells, s, H, C)
     check(lib.haet_project_split_fwd(_p(x), _p(w.hi), _p(w.lo), _p(w.bias), _p(p.wt), p.bt, p.base_temp,
                                      B * N, K, w.O, _p(cells), _p(s), _stream()), "haet_project_split_fwd")
     return SplitPoints(cells, s, H, C)

@@ -269,6 +269,15 @@ int haet_linear_wgrad(const float* G, const float* X, int N, int O, int K, float
  *   haet_linear_narrow_fwd: Linear (+ GELU) with K <= 16 inputs (coordinates + fields), fp32 vector ALUs  */
 int haet_linear_act_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
                         int Nrows, int K, int O, int act, float* out, haet_stream_t stream);
+/* nn.LayerNorm(K) fused into the loader of the GEMM (ln_1 in front of in_project_x, ln_2 in front of the block
+ * MLP): the envelope of haet_project_split_supported (K in {128, 256}, O % 256 = 0, >= 64 rows).        */
+int haet_linear_ln_fwd(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                       const uint16_t* W_hi, const uint16_t* W_lo, const float* bias, int Nrows, int K, int O,
+                       int act, float* out, haet_stream_t stream);
+int haet_project_split_ln_fwd(const float* x, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                              const uint16_t* W_hi, const uint16_t* W_lo, const float* bias, const float* wt,
+                              float bt, float base_temp, int Nrows, int K, int O, void* x_split, float* s_out,
+                              haet_stream_t stream);
 int haet_layernorm_supported(int D);
 int haet_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int rows, int D,
                        float* out, haet_stream_t stream);

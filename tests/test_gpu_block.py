@@ -128,3 +128,37 @@ def test_add_layernorm_vs_fp64(rows, D, hip_device):
     assert torch.equal(s.cpu(), x + r)
     ref = torch.nn.functional.layer_norm((x + r).double(), (D,), w.double(), b.double(), 1e-5)
     assert O.rel_l2(out.cpu().double(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("rows,K,Oc,gelu", [(1000, 256, 512, True), (70001, 256, 256, False), (64, 128, 256, True), (4099, 128, 512, False)])
+def test_layernorm_fused_into_the_gemm_loader_vs_fp64(rows, K, Oc, gelu, hip_device):
+    from haet_amd import ops
+
+    g = torch.Generator().manual_seed(rows + K)
+    x = torch.randn(rows, K, generator=g) * 2 + 0.7
+    lw, lb = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    W, b = torch.randn(Oc, K, generator=g) / K ** 0.5, torch.randn(Oc, generator=g)
+    ref = torch.nn.functional.layer_norm(x.double(), (K,), lw.double(), lb.double(), 1e-5) @ W.double().t() + b.double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    assert ops.linear_ln_supported(K, Oc, rows)
+    w = ops.SplitLinear(W.to(hip_device), b.to(hip_device))
+    out = ops.linear(x.to(hip_device), w, gelu=gelu, ln=(lw.to(hip_device), lb.to(hip_device), 1e-5))
+    assert O.rel_l2(out.cpu().double(), ref) < 2e-5
+
+
+def test_pre_norm_in_the_projection_matches_separate_layernorm(hip_device):
+    """Attn(x, pre_norm=ln) (LayerNorm inside the projection GEMM's loader) against Attn(ln(x))."""
+    from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh
+
+    torch.manual_seed(4)
+    mod = Physics_Attention_Irregular_Mesh(dim=256, heads=8, dim_head=32, slice_num=64, rotate=45).eval().to(hip_device)
+    ln = torch.nn.LayerNorm(256).to(hip_device)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.normal_(0, 0.3)
+        x = torch.randn(1, 5000, 256, device=hip_device) * 1.7 + 0.2
+        assert mod.fuses_pre_norm(x, ln)
+        fused = mod(x, pre_norm=ln)
+        ref = mod(ln(x))
+    assert O.rel_l2(fused.cpu(), ref.cpu()) < 2e-5
