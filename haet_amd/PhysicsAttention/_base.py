@@ -211,6 +211,7 @@ class PhysicsAttentionBase(nn.Module):
         self.__dict__["_grad_check_stale"] = True
         return super()._apply(fn, *args, **kwargs)
 
+    @torch.compiler.disable  # torch.compile(model) (the reference's scripts): the HIP path is an opaque eager call
     def forward(self, x: torch.Tensor, return_intermediates: bool = False, pre_norm: Optional[nn.LayerNorm] = None):
         """`pre_norm` (not in the reference's signature; used by the block's inference fast path): a LayerNorm
         to apply to x first -- fused into the projection GEMM's loader where the variant supports it."""

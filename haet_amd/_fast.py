@@ -111,6 +111,7 @@ def _ln_fusable(ln, lin: nn.Linear, x: torch.Tensor) -> bool:
             and ops.linear_ln_supported(lin.in_features, lin.out_features, x.numel() // lin.in_features))
 
 
+@torch.compiler.disable  # opaque to torch.compile: ctypes calls into libhaet_hip.so
 def linear(lin: nn.Linear, x: torch.Tensor, gelu: bool = False, shift: torch.Tensor = None,
            pre_norm: nn.LayerNorm = None) -> torch.Tensor:
     """`pre_norm`: a LayerNorm applied to x first -- inside the GEMM's loader where the kernel allows."""
@@ -136,6 +137,7 @@ def linear(lin: nn.Linear, x: torch.Tensor, gelu: bool = False, shift: torch.Ten
     return y if shift is None else y.add_(shift)
 
 
+@torch.compiler.disable  # opaque to torch.compile: ctypes calls into libhaet_hip.so
 def mlp(m, x: torch.Tensor, shift: torch.Tensor = None, pre_norm: nn.LayerNorm = None):
     """components.MLP forward (GELU variant) on the HIP kernels, or None when it does not apply;
     `shift` is added to the output (folded into the last bias), `pre_norm` is applied to x first (in the
@@ -149,6 +151,7 @@ def mlp(m, x: torch.Tensor, shift: torch.Tensor = None, pre_norm: nn.LayerNorm =
     return linear(m.linear_post, x, shift=shift)
 
 
+@torch.compiler.disable  # opaque to torch.compile: ctypes calls into libhaet_hip.so
 def layer_norm(ln: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
     if (ln.elementwise_affine and ln.bias is not None and len(ln.normalized_shape) == 1
             and ops.layernorm_supported(ln.normalized_shape[0])):
@@ -158,6 +161,7 @@ def layer_norm(ln: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
     return ln(x)
 
 
+@torch.compiler.disable  # opaque to torch.compile: ctypes calls into libhaet_hip.so
 def add_layer_norm(ln: nn.LayerNorm, x: torch.Tensor, res: torch.Tensor):
     """(x + res, ln(x + res)); one kernel at inference."""
     if (enabled(x) and res.shape == x.shape and res.dtype == torch.float32 and ln.elementwise_affine

@@ -162,3 +162,46 @@ def test_pre_norm_in_the_projection_matches_separate_layernorm(hip_device):
         fused = mod(x, pre_norm=ln)
         ref = mod(ln(x))
     assert O.rel_l2(fused.cpu(), ref.cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("mode", ["reduce-overhead", "max-autotune-no-cudagraphs"])
+def test_model_under_torch_compile(mode, hip_device):
+    """The reference's scripts wrap the model in torch.compile: the HIP path stays an opaque eager call inside
+    whatever the compiler does with the rest, same numbers as the eager model."""
+    import haet_amd
+
+    torch.manual_seed(3)
+    model = haet_amd.HAETransolver_Irregular_Mesh(space_dim=3, fun_dim=4, n_hidden=256, n_layers=2, n_head=8,
+                                                  mlp_ratio=2, out_dim=4, slice_num=64).eval().to(hip_device)
+    x = torch.randn(1, 3000, 7, device=hip_device)
+    with torch.no_grad():
+        ref = model(x, None)
+        compiled = torch.compile(model, mode=mode)
+        out = compiled(x, None)
+        out2 = compiled(x, None)
+    assert O.rel_l2(out.cpu(), ref.cpu()) < 1e-5 and O.rel_l2(out2.cpu(), ref.cpu()) < 1e-5
+
+
+def test_training_step_under_torch_compile(hip_device):
+    import haet_amd
+
+    torch.manual_seed(5)
+    model = haet_amd.HAETransolver_Irregular_Mesh(space_dim=3, fun_dim=4, n_hidden=256, n_layers=1, n_head=8,
+                                                  mlp_ratio=2, out_dim=4, slice_num=64).to(hip_device).train()
+    x = torch.randn(1, 2000, 7, device=hip_device)
+    y = torch.randn(1, 2000, 4, device=hip_device)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def step(m):
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.mse_loss(m(x, None), y)
+        loss.backward()
+        return float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    loss_ref, g_ref = step(model)
+    loss_c, g_c = step(torch.compile(model))
+    assert abs(loss_c - loss_ref) < 1e-5 * max(1.0, abs(loss_ref))
+    scale = max(float(g.norm()) for g in g_ref.values())
+    for name, gr in g_ref.items():
+        assert float((g_c[name] - gr).norm()) / max(float(gr.norm()), 1e-4 * scale) < 2e-3, name
