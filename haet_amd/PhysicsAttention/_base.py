@@ -229,9 +229,6 @@ class PhysicsAttentionBase(nn.Module):
 
             if return_intermediates:
                 raise NotImplementedError("return_intermediates is a no-grad / eval facility")
-            if self.shard_group is not None and not isinstance(self.in_project_x, nn.Linear):
-                raise NotImplementedError("gradients on the slab-sharded structured meshes (halo exchange in the "
-                                          "convolution's backward) are not available yet")
             if os.environ.get("HAET_TORCH_BACKWARD") and self.shard_group is None:  # the interim path, for A/B runs
                 if self.training:
                     return _autograd.attention_forward(self, x)
@@ -250,12 +247,53 @@ class PhysicsAttentionBase(nn.Module):
         params = [p for p in self.in_project_x.parameters() if id(p) in wanted]
         if not need_x and not params:
             return None, {}
+        if self.shard_group is not None:
+            return self._conv_backward_sharded(x, g_lin, need_x, params)
         with torch.enable_grad():
             xr = x.detach().requires_grad_(bool(need_x))
             y = self.project_torch(xr)
         got = torch.autograd.grad(y, ([xr] if need_x else []) + params, g_lin.to(y.dtype), allow_unused=True)
         gx = got[0] if need_x else None
         return gx, {id(p): g for p, g in zip(params, got[1 if need_x else 0:])}
+
+    def _conv_backward_sharded(self, x: torch.Tensor, g_lin: torch.Tensor, need_x: bool, params):
+        """Backward of the slab-sharded convolution projection (`_conv_project` with halos): the convolution's
+        backward (MIOpen) on the slab extended by the neighbours' halo planes, then the REVERSE halo exchange --
+        the gradient that landed on a neighbour's plane goes home and is added there.  The weight / bias
+        gradients are this rank's additive shares (sums over its own output points)."""
+        from ..sharding import exchange_halo_planes, exchange_planes
+
+        conv = self.in_project_x
+        grid = self.grid_shape()
+        plane = 1
+        for g in grid[1:]:
+            plane *= g
+        B, n, Cin = x.shape
+        prev, nxt = exchange_halo_planes(x, plane, self.shard_group)
+        x_ext = torch.cat([t for t in (prev, x, nxt) if t is not None], dim=1)
+        lo = plane if prev is not None else 0
+        ext = x_ext.shape[1] // plane
+        nd = len(grid)
+        with torch.enable_grad(), torch.autocast("cuda", enabled=False):
+            xe = x_ext.detach().float().requires_grad_(True)
+            xg = xe.view((B, ext) + tuple(grid[1:]) + (Cin,)).permute(0, nd + 1, *range(1, nd + 1))
+            y = conv(xg).permute(0, *range(2, nd + 2), 1).reshape(B, ext * plane, -1)[:, lo:lo + n]
+        got = torch.autograd.grad(y, [xe] + list(params), g_lin.to(y.dtype), allow_unused=True)
+        gxe = got[0]
+        from_prev, from_next = exchange_planes(gxe[:, :plane] if prev is not None else None,
+                                               gxe[:, lo + n:] if nxt is not None else None, self.shard_group)
+        gx = None
+        if need_x:
+            gx = gxe[:, lo:lo + n].clone()
+            if from_prev is not None:
+                gx[:, :plane] += from_prev
+            if from_next is not None:
+                gx[:, n - plane:] += from_next
+        return gx, {id(p): g for p, g in zip(params, got[1:])}
+
+    def grid_shape(self):
+        """(H, W[, D]) of a structured variant (the first axis is the sharded one)."""
+        raise NotImplementedError
 
     def _linear_transposed(self, name: str, lin: nn.Linear, g: torch.Tensor) -> torch.Tensor:
         """g [..., O] @ W [O, K] -> [..., K]: the input gradient of a Linear, on the same MFMA GEMM."""

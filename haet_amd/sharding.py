@@ -61,30 +61,40 @@ def shard_bounds(n_points: int, rank: int, world: int):
     return start, start + base + (1 if rank < extra else 0)
 
 
-def exchange_halo_planes(x: torch.Tensor, plane: int, group=None):
-    """Slab sharding of a structured grid along its first axis (SURVEY.md 8e): x [B, n_planes*plane, C]
-    is this rank's slab; returns (prev, next) = the neighbour ranks' boundary planes [B, plane, C]
-    (None at the global faces, where the convolution's zero padding applies).  One point-to-point
-    exchange per side -- ncclSend/Recv over xGMI on the GPU node."""
+def exchange_planes(send_prev, send_next, group=None):
+    """Point-to-point exchange with the two neighbour ranks of a slab decomposition: `send_prev` goes to rank - 1,
+    `send_next` to rank + 1 (either may be None at the global faces); returns (what rank - 1 sent as its
+    `send_next`, what rank + 1 sent as its `send_prev`), None at the faces.  ncclSend/Recv over xGMI on the GPU node."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    B, n, C = x.shape
-    first, last = x[:, :plane].contiguous(), x[:, n - plane:].contiguous()
-    via_host = x.is_cuda and dist.get_backend(group) == "gloo"  # test configuration (see allgather_records)
-    buf = (lambda: torch.empty((B, plane, C), dtype=x.dtype, device="cpu" if via_host else x.device))
+    ref = send_prev if send_prev is not None else send_next
+    if ref is None:
+        return None, None
+    via_host = ref.is_cuda and dist.get_backend(group) == "gloo"  # test configuration (see allgather_records)
+    buf = (lambda: torch.empty(ref.shape, dtype=ref.dtype, device="cpu" if via_host else ref.device))
     prev = buf() if rank > 0 else None
     nxt = buf() if rank < world - 1 else None
     ops = []
     peer = (lambda r: dist.get_global_rank(group, r) if group is not None else r)
+    out = (lambda t: t.contiguous().cpu() if via_host else t.contiguous())
     if rank > 0:
-        ops += [dist.P2POp(dist.isend, first.cpu() if via_host else first, peer(rank - 1), group),
+        ops += [dist.P2POp(dist.isend, out(send_prev), peer(rank - 1), group),
                 dist.P2POp(dist.irecv, prev, peer(rank - 1), group)]
     if rank < world - 1:
-        ops += [dist.P2POp(dist.isend, last.cpu() if via_host else last, peer(rank + 1), group),
+        ops += [dist.P2POp(dist.isend, out(send_next), peer(rank + 1), group),
                 dist.P2POp(dist.irecv, nxt, peer(rank + 1), group)]
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     if via_host:
-        prev = None if prev is None else prev.to(x.device)
-        nxt = None if nxt is None else nxt.to(x.device)
+        prev = None if prev is None else prev.to(ref.device)
+        nxt = None if nxt is None else nxt.to(ref.device)
     return prev, nxt
+
+
+def exchange_halo_planes(x: torch.Tensor, plane: int, group=None):
+    """Slab sharding of a structured grid along its first axis (SURVEY.md 8e): x [B, n_planes*plane, C]
+    is this rank's slab; returns (prev, next) = the neighbour ranks' boundary planes [B, plane, C]
+    (None at the global faces, where the convolution's zero padding applies).  One point-to-point
+    exchange per side."""
+    n = x.shape[1]
+    return exchange_planes(x[:, :plane], x[:, n - plane:], group)
