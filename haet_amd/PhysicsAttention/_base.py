@@ -249,12 +249,36 @@ class PhysicsAttentionBase(nn.Module):
             return None, {}
         if self.shard_group is not None:
             return self._conv_backward_sharded(x, g_lin, need_x, params)
-        with torch.enable_grad():
-            xr = x.detach().requires_grad_(bool(need_x))
-            y = self.project_torch(xr)
-        got = torch.autograd.grad(y, ([xr] if need_x else []) + params, g_lin.to(y.dtype), allow_unused=True)
-        gx = got[0] if need_x else None
-        return gx, {id(p): g for p, g in zip(params, got[1 if need_x else 0:])}
+        gx = self._conv_input_grad(g_lin) if need_x else None  # HIP implicit GEMM with the transposed, flipped kernel
+        via_torch = need_x and gx is None
+        if via_torch or params:
+            with torch.enable_grad():
+                xr = x.detach().requires_grad_(bool(via_torch))
+                y = self.project_torch(xr)
+            got = torch.autograd.grad(y, ([xr] if via_torch else []) + params, g_lin.to(y.dtype), allow_unused=True)
+            if via_torch:
+                gx = got[0]
+            return gx, {id(p): g for p, g in zip(params, got[1 if via_torch else 0:])}
+        return gx, {}
+
+    def _conv_input_grad(self, g_lin: torch.Tensor):
+        """dL/dx of the same-padded stride-1 convolution projection = the convolution of dL/dy with the kernel
+        transposed (in <-> out channels) and flipped: the same implicit-GEMM kernel as the forward.  None when the
+        channel counts are outside its envelope (then MIOpen's backward-data runs)."""
+        conv = self.in_project_x
+        if not isinstance(conv, (nn.Conv2d, nn.Conv3d)) or os.environ.get("HAET_NO_HIP_CONV") or g_lin.dtype != torch.float32:
+            return None
+        if (not ops.conv_project_supported(conv.out_channels, conv.in_channels)
+                or any(s != 1 for s in conv.stride) or any(d != 1 for d in conv.dilation) or conv.groups != 1
+                or any(k % 2 == 0 or p != k // 2 for k, p in zip(conv.kernel_size, conv.padding))
+                or conv.padding_mode != "zeros"):
+            return None
+        cache = self.__dict__.setdefault("_split_cache", {})
+        key = (conv.weight.data_ptr(), conv.weight._version)
+        if "in_project_x.T" not in cache or cache["in_project_x.T"][0] != key:
+            wt = conv.weight.detach().transpose(0, 1).flip(tuple(range(2, conv.weight.dim()))).contiguous()
+            cache["in_project_x.T"] = (key, ops.SplitConv(wt, None))
+        return ops.conv_project(g_lin, cache["in_project_x.T"][1], self.grid_shape())
 
     def _conv_backward_sharded(self, x: torch.Tensor, g_lin: torch.Tensor, need_x: bool, params):
         """Backward of the slab-sharded convolution projection (`_conv_project` with halos): the convolution's

@@ -90,7 +90,7 @@ def test_backward_passes_vs_fp64_autograd(B, N, H, C, M, path, hip_device, monke
         assert abs(float(dbt) - float(gbt)) < 5 * tol * max(1.0, abs(float(gbt)), float(gwt.norm()))
 
 
-@pytest.mark.parametrize("kind", ["irregular_c3", "structured2d", "structured3d"])
+@pytest.mark.parametrize("kind", ["irregular_c3", "structured2d", "structured3d", "structured2d_wide", "structured3d_wide"])
 @pytest.mark.parametrize("train", [False, True])
 def test_module_gradients_vs_device_restatement(kind, train, hip_device):
     """All parameter gradients and the input gradient of the three variants: the HIP autograd node
@@ -105,14 +105,22 @@ def test_module_gradients_vs_device_restatement(kind, train, hip_device):
     elif kind == "structured2d":
         mod, N, dim = Physics_Attention_Structured_Mesh_2D(dim=64, heads=4, dim_head=32, slice_num=16, H=20, W=12,
                                                            rotate=45), 240, 64
-    else:
+    elif kind == "structured3d":
         mod, N, dim = Physics_Attention_Structured_Mesh_3D(dim=32, heads=4, dim_head=32, slice_num=32, H=6, W=8, D=5,
                                                            rotate=45), 240, 32
+    elif kind == "structured2d_wide":  # channel counts inside the HIP convolution's envelope in both directions
+        mod, N, dim = Physics_Attention_Structured_Mesh_2D(dim=128, heads=4, dim_head=32, slice_num=16, H=20, W=12,
+                                                           rotate=45), 240, 128
+    else:
+        mod, N, dim = Physics_Attention_Structured_Mesh_3D(dim=128, heads=4, dim_head=32, slice_num=32, H=6, W=8, D=5,
+                                                           rotate=45), 240, 128
     with torch.no_grad():
         for name, p in mod.erwin.named_parameters():
             if p.dim() >= 2:
                 p.mul_(3.0)  # make the Erwin stage matter in the output
     mod = mod.to(hip_device).train(train)
+    if kind.endswith("_wide"):  # the input gradient of the projection runs on the HIP convolution here
+        assert mod._conv_input_grad(torch.zeros(1, N, mod.in_project_x.out_channels, device=hip_device)) is not None
     x = torch.randn(2, N, dim, device=hip_device)
     gout = torch.randn(2, N, dim, device=hip_device)
 
