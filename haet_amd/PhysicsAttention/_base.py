@@ -261,7 +261,7 @@ class PhysicsAttentionBase(nn.Module):
             return gx, {id(p): g for p, g in zip(params, got[1 if via_torch else 0:])}
         return gx, {}
 
-    def _conv_input_grad(self, g_lin: torch.Tensor):
+    def _conv_input_grad(self, g_lin: torch.Tensor, grid=None):
         """dL/dx of the same-padded stride-1 convolution projection = the convolution of dL/dy with the kernel
         transposed (in <-> out channels) and flipped: the same implicit-GEMM kernel as the forward.  None when the
         channel counts are outside its envelope (then MIOpen's backward-data runs)."""
@@ -278,7 +278,7 @@ class PhysicsAttentionBase(nn.Module):
         if "in_project_x.T" not in cache or cache["in_project_x.T"][0] != key:
             wt = conv.weight.detach().transpose(0, 1).flip(tuple(range(2, conv.weight.dim()))).contiguous()
             cache["in_project_x.T"] = (key, ops.SplitConv(wt, None))
-        return ops.conv_project(g_lin, cache["in_project_x.T"][1], self.grid_shape())
+        return ops.conv_project(g_lin, cache["in_project_x.T"][1], self.grid_shape() if grid is None else grid)
 
     def _conv_backward_sharded(self, x: torch.Tensor, g_lin: torch.Tensor, need_x: bool, params):
         """Backward of the slab-sharded convolution projection (`_conv_project` with halos): the convolution's
@@ -298,22 +298,33 @@ class PhysicsAttentionBase(nn.Module):
         lo = plane if prev is not None else 0
         ext = x_ext.shape[1] // plane
         nd = len(grid)
-        with torch.enable_grad(), torch.autocast("cuda", enabled=False):
-            xe = x_ext.detach().float().requires_grad_(True)
-            xg = xe.view((B, ext) + tuple(grid[1:]) + (Cin,)).permute(0, nd + 1, *range(1, nd + 1))
-            y = conv(xg).permute(0, *range(2, nd + 2), 1).reshape(B, ext * plane, -1)[:, lo:lo + n]
-        got = torch.autograd.grad(y, [xe] + list(params), g_lin.to(y.dtype), allow_unused=True)
-        gxe = got[0]
+        # input gradient over the extended slab: the HIP implicit GEMM where the channel counts allow (dL/dy is
+        # zero on the halo planes, whose outputs belong to the neighbours), else MIOpen through autograd
+        gxe = None
+        if need_x:
+            zeros = (lambda t: None if t is None else torch.zeros((B, plane, g_lin.shape[-1]), dtype=g_lin.dtype, device=g_lin.device))
+            g_ext = torch.cat([t for t in (zeros(prev), g_lin, zeros(nxt)) if t is not None], dim=1)
+            gxe = self._conv_input_grad(g_ext, (ext,) + tuple(grid[1:]))
+        via_torch = need_x and gxe is None
+        got = ()
+        if via_torch or params:
+            with torch.enable_grad(), torch.autocast("cuda", enabled=False):
+                xe = x_ext.detach().float().requires_grad_(bool(via_torch))
+                xg = xe.view((B, ext) + tuple(grid[1:]) + (Cin,)).permute(0, nd + 1, *range(1, nd + 1))
+                y = conv(xg).permute(0, *range(2, nd + 2), 1).reshape(B, ext * plane, -1)[:, lo:lo + n]
+            got = torch.autograd.grad(y, ([xe] if via_torch else []) + list(params), g_lin.to(y.dtype), allow_unused=True)
+            if via_torch:
+                gxe, got = got[0], got[1:]
+        if not need_x:
+            return None, {id(p): g for p, g in zip(params, got)}
         from_prev, from_next = exchange_planes(gxe[:, :plane] if prev is not None else None,
                                                gxe[:, lo + n:] if nxt is not None else None, self.shard_group)
-        gx = None
-        if need_x:
-            gx = gxe[:, lo:lo + n].clone()
-            if from_prev is not None:
-                gx[:, :plane] += from_prev
-            if from_next is not None:
-                gx[:, n - plane:] += from_next
-        return gx, {id(p): g for p, g in zip(params, got[1:])}
+        gx = gxe[:, lo:lo + n].clone()
+        if from_prev is not None:
+            gx[:, :plane] += from_prev
+        if from_next is not None:
+            gx[:, n - plane:] += from_next
+        return gx, {id(p): g for p, g in zip(params, got)}
 
     def grid_shape(self):
         """(H, W[, D]) of a structured variant (the first axis is the sharded one)."""

@@ -173,9 +173,9 @@ def _structured_grad_worker(rank, world, port, tmp):
     for kind, grid in (("structured2d", (12, 10)), ("structured3d", (6, 5, 4))):
         torch.manual_seed(17)
         if kind == "structured2d":
-            mod = Physics_Attention_Structured_Mesh_2D(64, heads=4, dim_head=32, slice_num=32, H=grid[0], W=grid[1], rotate=45)
+            mod = Physics_Attention_Structured_Mesh_2D(128, heads=4, dim_head=32, slice_num=32, H=grid[0], W=grid[1], rotate=45)
         else:
-            mod = Physics_Attention_Structured_Mesh_3D(64, heads=4, dim_head=32, slice_num=32, H=grid[0], W=grid[1],
+            mod = Physics_Attention_Structured_Mesh_3D(128, heads=4, dim_head=32, slice_num=32, H=grid[0], W=grid[1],
                                                        D=grid[2], rotate=45)
         with torch.no_grad():
             for name, p in mod.erwin.named_parameters():
@@ -186,8 +186,8 @@ def _structured_grad_worker(rank, world, port, tmp):
         for g in grid:
             N *= g
         plane = N // grid[0]
-        x = torch.randn(2, N, 64).to(dev)
-        gout = torch.randn(2, N, 64).to(dev)
+        x = torch.randn(2, N, 128).to(dev)
+        gout = torch.randn(2, N, 128).to(dev)
         xr = x.clone().requires_grad_(True)
         (_autograd.attention_forward(mod, xr) * gout).sum().backward()   # unsharded reference on this rank
         ref = {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}
