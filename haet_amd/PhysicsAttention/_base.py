@@ -251,6 +251,9 @@ class PhysicsAttentionBase(nn.Module):
             return self._conv_backward_sharded(x, g_lin, need_x, params)
         gx = self._conv_input_grad(g_lin) if need_x else None  # HIP implicit GEMM with the transposed, flipped kernel
         via_torch = need_x and gx is None
+        hip_w = self._conv_weight_grad(g_lin, x, self.grid_shape()) if params and not via_torch else None
+        if hip_w is not None:
+            return gx, {id(p): g for p, g in zip(params, hip_w(params))}
         if via_torch or params:
             with torch.enable_grad():
                 xr = x.detach().requires_grad_(bool(via_torch))
@@ -260,6 +263,20 @@ class PhysicsAttentionBase(nn.Module):
                 gx = got[0]
             return gx, {id(p): g for p, g in zip(params, got[1 if via_torch else 0:])}
         return gx, {}
+
+    def _conv_weight_grad(self, g_lin: torch.Tensor, x: torch.Tensor, grid):
+        """Weight / bias gradient of the convolution projection as one shifted row-contraction per kernel tap on the
+        f32 matrix cores (ops.conv_wgrad), or None outside its envelope (then MIOpen).  Returns a function mapping
+        the wanted parameter list to their gradients."""
+        conv = self.in_project_x
+        if (not isinstance(conv, (nn.Conv2d, nn.Conv3d)) or os.environ.get("HAET_NO_HIP_CONV") or g_lin.dtype != torch.float32
+                or not ops.conv_wgrad_supported(conv.in_channels, conv.out_channels)
+                or any(s != 1 for s in conv.stride) or any(d != 1 for d in conv.dilation) or conv.groups != 1
+                or any(k % 2 == 0 or p != k // 2 for k, p in zip(conv.kernel_size, conv.padding))
+                or conv.padding_mode != "zeros"):
+            return None
+        dW, db = ops.conv_wgrad(g_lin, x, grid, conv.kernel_size)
+        return lambda params: [dW if p is conv.weight else db for p in params]
 
     def _conv_input_grad(self, g_lin: torch.Tensor, grid=None):
         """dL/dx of the same-padded stride-1 convolution projection = the convolution of dL/dy with the kernel
@@ -307,7 +324,17 @@ class PhysicsAttentionBase(nn.Module):
             gxe = self._conv_input_grad(g_ext, (ext,) + tuple(grid[1:]))
         via_torch = need_x and gxe is None
         got = ()
-        if via_torch or params:
+        if params and not via_torch:
+            zeros = (lambda t: None if t is None else torch.zeros((B, plane, g_lin.shape[-1]), dtype=g_lin.dtype, device=g_lin.device))
+            g_ext = torch.cat([t for t in (zeros(prev), g_lin, zeros(nxt)) if t is not None], dim=1)
+            hip_w = self._conv_weight_grad(g_ext, x_ext, (ext,) + tuple(grid[1:]))
+            if hip_w is not None:
+                got, params_done = tuple(hip_w(params)), True
+            else:
+                params_done = False
+        else:
+            params_done = False
+        if via_torch or (params and not params_done):
             with torch.enable_grad(), torch.autocast("cuda", enabled=False):
                 xe = x_ext.detach().float().requires_grad_(bool(via_torch))
                 xg = xe.view((B, ext) + tuple(grid[1:]) + (Cin,)).permute(0, nd + 1, *range(1, nd + 1))

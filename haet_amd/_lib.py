@@ -77,6 +77,7 @@ SIGNATURES = {
     "haet_linear_wgrad_supported": (c_int, [c_int, c_int]),
     "haet_linear_wgrad_num_parts": (c_int, [c_int]),
     "haet_linear_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
+    "haet_conv_wgrad_tap": (c_int, [_P, _P] + [c_int] * 9 + [_P, _P]),
     "haet_linear_act_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "haet_linear_ln_fwd": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "haet_project_split_ln_fwd": (c_int, [_P, _P, _P, c_float, _P, _P, _P, _P, c_float, c_float, c_int, c_int, c_int,

@@ -27,9 +27,17 @@ int wgrad_chunk(int N) {  // rows per workgroup: ~256 workgroups, whole 32-row t
 // LDS: two buffers of one 32-row tile of both operands, [G 32 x 256 | X 32 x 256] floats = 64 KB each.
 constexpr int kTileFloats = 2 * kRowsTile * 256;
 
+// TAP: the X row of output row n is row n + (dh gW + dw) gD + dd of the channels-last grid [B][gH][gW][gD], zero
+// where that neighbour lies outside the grid -- one tap of a convolution's weight gradient
+// (dW[o][c][tap] = sum_n g[n][o] x[n + off(tap)][c], StructuredMesh2D.py:109 / StructuredMesh3D.py:113).
+struct TapGeom {
+    int gH, gW, gD, dh, dw, dd;
+};
+
+template <bool TAP>
 __global__ __launch_bounds__(512) void gemm_tn_f32_kernel(const float* __restrict__ G, const float* __restrict__ X,
                                                           int N, int O, int K, int chunk,
-                                                          float* __restrict__ parts) {
+                                                          float* __restrict__ parts, TapGeom tg) {
     typedef float f4v __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -58,10 +66,18 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_kernel(const float* __restric
             const int n = nb + sr + 8 * i;
             const bool ok = n < n1;
             const size_t r = ok ? (size_t)n : (size_t)n0;  // unconditional loads: the waits stay counted
+            size_t rx = r;
+            bool okx = ok;
+            if (TAP) {
+                const int d = (int)(r % tg.gD), w = (int)((r / tg.gD) % tg.gW), hh = (int)((r / ((size_t)tg.gD * tg.gW)) % tg.gH);
+                okx = ok && (unsigned)(hh + tg.dh) < (unsigned)tg.gH && (unsigned)(w + tg.dw) < (unsigned)tg.gW &&
+                      (unsigned)(d + tg.dd) < (unsigned)tg.gD;
+                if (okx) rx = (size_t)((long long)r + ((long long)tg.dh * tg.gW + tg.dw) * tg.gD + tg.dd);
+            }
             const f4v g4 = *reinterpret_cast<const f4v*>(G + r * O + ob0 + sc);
-            const f4v x4 = *reinterpret_cast<const f4v*>(X + r * K + kb0 + sc);
+            const f4v x4 = *reinterpret_cast<const f4v*>(X + rx * K + kb0 + sc);
             sg[i] = ok ? g4 : zero4;
-            sx[i] = ok ? x4 : zero4;
+            sx[i] = okx ? x4 : zero4;
         }
     };
     auto stash = [&](float* buf) {
@@ -137,11 +153,35 @@ extern "C" int haet_linear_wgrad(const float* G, const float* X, int N, int O, i
     const size_t lds = 2 * (size_t)kTileFloats * sizeof(float);  // 128 KB
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f32_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f32_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(HAET_E_LAUNCH, "linear_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_tn_f32_kernel, grid, dim3(512), lds, as_stream(stream), G, X, N, O, K, chunk, parts);
+    hipLaunchKernelGGL(gemm_tn_f32_kernel<false>, grid, dim3(512), lds, as_stream(stream), G, X, N, O, K, chunk, parts,
+                       TapGeom{});
     return check_launch("gemm_tn_f32_kernel");
+}
+
+// One tap (dh, dw, dd) of the weight gradient of a same-padded stride-1 convolution over the channels-last grid
+// x [B, gH*gW*gD, Cin], g = dL/d output [B, gH*gW*gD, O]: records as haet_linear_wgrad (K = Cin).
+extern "C" int haet_conv_wgrad_tap(const float* G, const float* X, int B, int gH, int gW, int gD, int O, int Cin,
+                                   int dh, int dw, int dd, float* parts, haet_stream_t stream) {
+    if (!G || !X || !parts) return fail(HAET_E_ARG, "conv_wgrad_tap: null pointer");
+    const long long rows = (long long)B * gH * gW * gD;
+    if (B < 1 || gH < 1 || gW < 1 || gD < 1 || rows > 0x7fffffffLL || !haet_linear_wgrad_supported(O, Cin))
+        return fail(HAET_E_ARG, "conv_wgrad_tap: bad grid or O=%d / C_in=%d not multiples of 256", O, Cin);
+    const int N = (int)rows, chunk = wgrad_chunk(N);
+    dim3 grid((N + chunk - 1) / chunk, (O / 256) * (Cin / 256));
+    const size_t lds = 2 * (size_t)kTileFloats * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f32_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(HAET_E_LAUNCH, "conv_wgrad_tap: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_f32_kernel<true>, grid, dim3(512), lds, as_stream(stream), G, X, N, O, Cin, chunk, parts,
+                       TapGeom{gH, gW, gD, dh, dw, dd});
+    return check_launch("gemm_tn_f32_kernel<tap>");
 }

@@ -329,6 +329,39 @@ def linear_wgrad(g: Tensor, x: Tensor):
     return dW, db
 
 
+def conv_wgrad_supported(Cin: int, O: int) -> bool:
+    return bool(_lib.load().haet_linear_wgrad_supported(int(O), int(Cin)))
+
+
+def conv_wgrad(g: Tensor, x: Tensor, grid: Tuple[int, ...], kernel: Tuple[int, ...]):
+    """(dW [O, C_in, *kernel], db [O]) of a same-padded stride-1 Conv2d / Conv3d over the channels-last grid:
+    x [B, N, C_in], g = dL/d output [B, N, O]; one haet_conv_wgrad_tap launch per kernel tap."""
+    lib = _lib.load()
+    g, x = _f32(g, "g"), _f32(x, "x")
+    B, N, O = g.shape
+    Cin = x.shape[-1]
+    gH, gW = grid[0], grid[1]
+    gD = grid[2] if len(grid) > 2 else 1
+    ks = tuple(kernel) + (1,) * (3 - len(kernel))
+    if gH * gW * gD != N or x.shape[1] != N:
+        raise HaetError("conv_wgrad: tensors do not match the grid")
+    P = lib.haet_linear_wgrad_num_parts(B * N)
+    ob, kb = O // 256, Cin // 256
+    parts = torch.empty((P, ob * kb, 256 * 256 + 256), dtype=torch.float32, device=g.device)
+    dW = torch.empty((O, Cin) + ks, dtype=torch.float32, device=g.device)
+    db = None
+    for a in range(ks[0]):
+        for b in range(ks[1]):
+            for c in range(ks[2]):
+                check(lib.haet_conv_wgrad_tap(_p(g), _p(x), B, gH, gW, gD, O, Cin, a - ks[0] // 2, b - ks[1] // 2,
+                                              c - ks[2] // 2, _p(parts), _stream()), "haet_conv_wgrad_tap")
+                s = parts.sum(dim=0)
+                dW[:, :, a, b, c] = s[:, :256 * 256].view(ob, kb, 256, 256).permute(0, 2, 1, 3).reshape(O, Cin)
+                if db is None:
+                    db = s[:, 256 * 256:].view(ob, kb, 256)[:, 0].reshape(O).clone()
+    return dW.reshape((O, Cin) + tuple(kernel)), db
+
+
 # --------------------------------------------------------------------------- fused operand format
 class SplitPoints:
     """x_lin in the streaming passes' operand format (haet_project_split_fwd): `cells` [B, N, H*C]

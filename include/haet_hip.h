@@ -258,6 +258,12 @@ int haet_slice_bwd_points(const float* x_lin, const float* Ws, const float* bs, 
 int haet_linear_wgrad_supported(int O, int K);
 int haet_linear_wgrad_num_parts(int N);
 int haet_linear_wgrad(const float* G, const float* X, int N, int O, int K, float* parts, haet_stream_t stream);
+/* One tap (dh, dw, dd) of the weight gradient of the structured variants' convolution projection
+ * (nn.Conv2d / nn.Conv3d, same padding, stride 1; 2-D: gD = 1, dd = 0):
+ *   dW[o][c][tap] = sum_n g[n][o] x[n + (dh gW + dw) gD + dd][c]   (zero where the neighbour is outside the grid)
+ * over the channels-last grid; parts as haet_linear_wgrad with K = C_in (its db entries are sum_n g, tap-independent). */
+int haet_conv_wgrad_tap(const float* G, const float* X, int B, int gH, int gW, int gD, int O, int Cin,
+                        int dh, int dw, int dd, float* parts, haet_stream_t stream);
 
 /* ------------------------------------------------------------------ the block around the path
  * Point-wise callers either side of Physics_Attention inside a Transolver block

@@ -90,7 +90,8 @@ def test_backward_passes_vs_fp64_autograd(B, N, H, C, M, path, hip_device, monke
         assert abs(float(dbt) - float(gbt)) < 5 * tol * max(1.0, abs(float(gbt)), float(gwt.norm()))
 
 
-@pytest.mark.parametrize("kind", ["irregular_c3", "structured2d", "structured3d", "structured2d_wide", "structured3d_wide"])
+@pytest.mark.parametrize("kind", ["irregular_c3", "structured2d", "structured3d", "structured2d_wide", "structured3d_wide",
+                                  "structured3d_c5like"])
 @pytest.mark.parametrize("train", [False, True])
 def test_module_gradients_vs_device_restatement(kind, train, hip_device):
     """All parameter gradients and the input gradient of the three variants: the HIP autograd node
@@ -111,15 +112,18 @@ def test_module_gradients_vs_device_restatement(kind, train, hip_device):
     elif kind == "structured2d_wide":  # channel counts inside the HIP convolution's envelope in both directions
         mod, N, dim = Physics_Attention_Structured_Mesh_2D(dim=128, heads=4, dim_head=32, slice_num=16, H=20, W=12,
                                                            rotate=45), 240, 128
-    else:
+    elif kind == "structured3d_wide":
         mod, N, dim = Physics_Attention_Structured_Mesh_3D(dim=128, heads=4, dim_head=32, slice_num=32, H=6, W=8, D=5,
                                                            rotate=45), 240, 128
+    else:  # C5's widths (256 -> 8 x 32): input AND weight gradient of the convolution on the HIP kernels
+        mod, N, dim = Physics_Attention_Structured_Mesh_3D(dim=256, heads=8, dim_head=32, slice_num=32, H=4, W=6, D=5,
+                                                           rotate=45), 120, 256
     with torch.no_grad():
         for name, p in mod.erwin.named_parameters():
             if p.dim() >= 2:
                 p.mul_(3.0)  # make the Erwin stage matter in the output
     mod = mod.to(hip_device).train(train)
-    if kind.endswith("_wide"):  # the input gradient of the projection runs on the HIP convolution here
+    if kind.endswith("_wide") or kind.endswith("c5like"):  # the input gradient of the projection runs on the HIP convolution here
         assert mod._conv_input_grad(torch.zeros(1, N, mod.in_project_x.out_channels, device=hip_device)) is not None
     x = torch.randn(2, N, dim, device=hip_device)
     gout = torch.randn(2, N, dim, device=hip_device)
@@ -182,3 +186,25 @@ def test_linear_weight_gradient_vs_fp64(rows, O, K, hip_device):
     ref = G.double().t() @ X.double()
     assert float((dW.cpu().double() - ref).norm() / ref.norm()) < 2e-6
     assert float((db.cpu().double() - G.double().sum(0)).norm() / G.double().sum(0).norm()) < 2e-6
+
+
+@pytest.mark.parametrize("B,grid,k", [(2, (5, 6, 7), 3), (1, (9, 7), 3), (1, (4, 4, 4), 1), (1, (6, 5), 5)])
+def test_convolution_weight_gradient_vs_fp64(B, grid, k, hip_device):
+    """ops.conv_wgrad (one shifted row-contraction per tap on the f32 MFMA) against fp64 autograd of the convolution."""
+    from haet_amd import ops
+
+    nd = len(grid)
+    N = 1
+    for g_ in grid:
+        N *= g_
+    gen = torch.Generator().manual_seed(N + k)
+    x = torch.randn(B, N, 256, generator=gen)
+    g = torch.randn(B, N, 256, generator=gen)
+    conv = (torch.nn.Conv2d if nd == 2 else torch.nn.Conv3d)(256, 256, k, 1, k // 2).double()
+    xg = x.double().view((B,) + grid + (256,)).permute(0, nd + 1, *range(1, nd + 1))
+    y = conv(xg).permute(0, *range(2, nd + 2), 1).reshape(B, N, 256)
+    gW, gb = torch.autograd.grad(y, [conv.weight, conv.bias], g.double())
+    dW, db = ops.conv_wgrad(g.to(hip_device), x.to(hip_device), grid, (k,) * nd)
+    assert dW.shape == gW.shape
+    assert float((dW.cpu().double() - gW).norm() / gW.norm()) < 2e-6
+    assert float((db.cpu().double() - gb).norm() / gb.norm()) < 2e-6
