@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ..._lib import ErwinDesc, HaetError
+from ..._lib import HaetError
 
 
 class SwiGLU(nn.Module):

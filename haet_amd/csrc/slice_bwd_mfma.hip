@@ -377,8 +377,6 @@ bool slice_bwd_mfma_ok(int C, int M) {
     return (C == 32 && (M == 32 || M == 64 || M == 128)) || (C == 64 && (M == 32 || M == 64));
 }
 
-int slice_bwd_mfma_chunk(int N) { return pick_chunk(N); }
-
 // go / S2 / dS / A / dx as in haet_slice_bwd_points; mode 0 ignores S2, dS, A, dx
 int slice_bwd_mfma(int mode, const float* x, const float* Ws, const float* bs, const float* wt, float bt,
                    float base_temp, float c0, const float* cm, const float* cs, const float* go, const float* S2,
