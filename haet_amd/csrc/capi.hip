@@ -43,7 +43,7 @@ int deslice_mfma_fwd(const float*, const float*, const float*, const float*, flo
 
 // slice_f32_mfma.hip: the two passes on the f32 matrix cores (C in {32, 64}, M in {32, 64, 128})
 bool slice_f32_ok(int C, int M);
-int slice_f32_num_parts(int N);
+int slice_f32_num_parts(int N, int BH);
 int slice_f32_fwd(const float*, const float*, const float*, const float*, float, float, float, int, int, int, int,
                   int, float*, hipStream_t);
 int deslice_f32_fwd(const float*, const float*, const float*, const float*, float, float, float, const float*,
@@ -73,7 +73,7 @@ extern "C" int haet_slice_num_parts(int B, int N, int H, int C, int M) {
     if (slice_shape_ok(B, N, H, C, M) != HAET_OK) return HAET_E_ARG;
     MfmaPlan p;
     if (use_mfma(B, N, H, C, M, &p)) return p.parts;
-    if (use_f32_mfma(C, M)) return slice_f32_num_parts(N);
+    if (use_f32_mfma(C, M)) return slice_f32_num_parts(N, B * H);
     return slice_valu_num_parts(N);
 }
 

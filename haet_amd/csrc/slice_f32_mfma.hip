@@ -41,9 +41,12 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-int pick_chunk(int N) {  // ~256 chunks of whole 32-point tiles
-    int c = (N + 255) / 256;
-    c = ((c + 255) / 256) * 256;
+int pick_chunk(int N, int BH) {  // ~512 workgroups at small N (each builds its operand images and merges its waves once)
+    int P = 512 / (BH > 0 ? BH : 1);
+    if (P < 1) P = 1;
+    int c = (N + P - 1) / P;
+    c = ((c + 255) / 256) * 256;  // whole 32-point tiles for all 8 waves
+    if (c > 4096) c = 4096;       // and at most 16 tiles per wave: short f32 accumulation chains, the merge adds the rest
     return c < 256 ? 256 : c;
 }
 
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(NW * 64) void deslice_f32_kernel(
 
 // ----------------------------------------------------------------------------- host side
 bool slice_f32_ok(int C, int M) { return (C == 32 || C == 64) && (M == 32 || M == 64 || M == 128); }
-int slice_f32_num_parts(int N) { return (N + pick_chunk(N) - 1) / pick_chunk(N); }
+int slice_f32_num_parts(int N, int BH) { return (N + pick_chunk(N, BH) - 1) / pick_chunk(N, BH); }
 
 template <int CB, int MB, int NW>
 static int launch_slice(dim3 grid, hipStream_t st, const float* x, const float* Ws, const float* bs, const float* wt,
@@ -385,7 +388,7 @@ static int launch_deslice(dim3 grid, hipStream_t st, const float* x, const float
 
 int slice_f32_fwd(const float* x, const float* Ws, const float* bs, const float* wt, float bt, float base_temp,
                   float c0, int B, int N, int H, int C, int M, float* parts, hipStream_t st) {
-    const int chunk = pick_chunk(N);
+    const int chunk = pick_chunk(N, B * H);
     dim3 grid((N + chunk - 1) / chunk, B * H);
     HAET_F32_DISPATCH(launch_slice, grid, st, x, Ws, bs, wt, bt, base_temp, c0, N, H, chunk, parts)
 }
@@ -393,7 +396,7 @@ int slice_f32_fwd(const float* x, const float* Ws, const float* bs, const float*
 int deslice_f32_fwd(const float* x, const float* Ws, const float* bs, const float* wt, float bt, float base_temp,
                     float c0, const float* cm, const float* cs, const float* S2, int B, int N, int H, int C, int M,
                     float* out, hipStream_t st) {
-    const int chunk = pick_chunk(N);
+    const int chunk = pick_chunk(N, B * H);
     dim3 grid((N + chunk - 1) / chunk, B * H);
     HAET_F32_DISPATCH(launch_deslice, grid, st, x, Ws, bs, wt, bt, base_temp, c0, cm, cs, S2, N, H, chunk, out)
 }
