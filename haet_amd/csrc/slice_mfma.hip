@@ -286,7 +286,9 @@ template <int LI, int IPW, int MB, int NWV = NW, bool SPLIT = false, bool PRIV =
 __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ Ws, const float* __restrict__ bs,
     const float* __restrict__ wt, float bt, float base_temp, float c0, int N, int H,
-    int tiles_per_chunk, float* __restrict__ parts, const float* __restrict__ s_in) {
+    int tiles_per_chunk, float* __restrict__ parts, const float* __restrict__ s_in, int M_rec, int g_off) {
+    // M_rec / g_off: the records are laid out for M_rec slice columns and this launch fills columns g_off .. g_off + M
+    // (M = 128 runs as two launches of the M = 64 kernel: its four-items-per-wave variant spills)
     constexpr int M = 32 * MB;
     constexpr int IPH = (IPW < MB) ? IPW : MB;  // items of one head handled by this wave
     constexpr int HPW = IPW / IPH;              // heads per wave
@@ -448,16 +450,16 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
 #pragma unroll
         for (int k = 0; k < IPW; ++k) {
             const int id = item0 + k, h = id / MB, gb = id % MB;
-            float* rec = parts + ((size_t)blockIdx.x * BH + b * H + h) * (size_t)M * (kC + 2);
+            float* rec = parts + ((size_t)blockIdx.x * BH + b * H + h) * (size_t)M_rec * (kC + 2);
             const float l = lsum[k] + __shfl_xor(lsum[k], 32);
             if (hf == 0) {
-                rec[32 * gb + l31] = m2[k] * kLn2;
-                rec[M + 32 * gb + l31] = l;
+                rec[g_off + 32 * gb + l31] = m2[k] * kLn2;
+                rec[M_rec + g_off + 32 * gb + l31] = l;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int g = 32 * gb + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                rec[2 * M + g * kC + l31] = Z[k][r];
+                const int g = g_off + 32 * gb + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                rec[2 * M_rec + g * kC + l31] = Z[k][r];
             }
         }
     }
@@ -634,7 +636,7 @@ static int set_lds(K kernel, size_t bytes) {
         auto kern = slice_mfma_kernel<LI_, IPW_, MB_, NW_, SP_>;                                      \
         if (int rc = set_lds(kern, p.lds_slice)) return rc;                                          \
         hipLaunchKernelGGL(kern, grid, dim3(NW_ * 64), p.lds_slice, st, x, Ws, bs, wt, bt, base_temp, \
-                           c0, N, H, p.tiles_per_chunk, parts, s_in);                                \
+                           c0, N, H, p.tiles_per_chunk, parts, s_in, M_rec, g_off);                  \
         return check_launch("slice_mfma_kernel");                                                    \
     }
 #define SLICE_LAUNCH_P(LI_, IPW_, MB_, NW_)                                                        \
@@ -642,7 +644,7 @@ static int set_lds(K kernel, size_t bytes) {
         auto kern = slice_mfma_kernel<LI_, IPW_, MB_, NW_, true, true>;                               \
         if (int rc = set_lds(kern, p.lds_slice)) return rc;                                          \
         hipLaunchKernelGGL(kern, grid, dim3(NW_ * 64), p.lds_slice, st, x, Ws, bs, wt, bt, base_temp, \
-                           c0, N, H, p.tiles_per_chunk, parts, s_in);                                \
+                           c0, N, H, p.tiles_per_chunk, parts, s_in, M_rec, g_off);                  \
         return check_launch("slice_mfma_kernel");                                                    \
     }
 #define SLICE_CASE(LI_, IPW_, MB_, NW_)                                                            \
@@ -657,9 +659,30 @@ static int set_lds(K kernel, size_t bytes) {
         SLICE_LAUNCH(LI_, IPW_, MB_, NW_, false)                                                      \
     }
 
+static int slice_mfma_launch(const float* x, const float* Ws, const float* bs, const float* wt, float bt,
+                             float base_temp, float c0, int B, int N, int H, int C, int M, float* parts,
+                             hipStream_t st, const float* s_in, int M_rec, int g_off);
+
 int slice_mfma_fwd(const float* x, const float* Ws, const float* bs, const float* wt, float bt,
                    float base_temp, float c0, int B, int N, int H, int C, int M, float* parts,
                    hipStream_t st, const float* s_in) {
+    static const bool one_launch = getenv("HAET_SLICE_M128_ONE") != nullptr;  // A/B: the four-items-per-wave kernel
+    if (M == 128 && !one_launch && mfma_plan(B, N, H, C, 64, nullptr)) {
+        // two launches of the M = 64 kernel, each reading x once: 2 x 0.30 ms per 1M points against 1.4 ms for
+        // the M = 128 variant (64 accumulator + 64 logit registers per wave: spills)
+        for (int half = 0; half < 2; ++half) {
+            int rc = slice_mfma_launch(x, Ws + (size_t)64 * half * kC, bs + 64 * half, wt, bt, base_temp, c0, B, N, H, C,
+                                       64, parts, st, s_in, 128, 64 * half);
+            if (rc != HAET_OK) return rc;
+        }
+        return HAET_OK;
+    }
+    return slice_mfma_launch(x, Ws, bs, wt, bt, base_temp, c0, B, N, H, C, M, parts, st, s_in, M, 0);
+}
+
+static int slice_mfma_launch(const float* x, const float* Ws, const float* bs, const float* wt, float bt,
+                             float base_temp, float c0, int B, int N, int H, int C, int M, float* parts,
+                             hipStream_t st, const float* s_in, int M_rec, int g_off) {
     MfmaPlan p;
     if (!mfma_plan(B, N, H, C, M, &p)) return fail(HAET_E_ARG, "slice_mfma: unsupported shape");
     dim3 grid(p.parts, B);
