@@ -282,7 +282,11 @@ int slice_valu_fwd(const float* x, const float* Ws, const float* bs, const float
 int deslice_valu_fwd(const float* x, const float* Ws, const float* bs, const float* wt, float bt,
                      float base_temp, float c0, const float* cm, const float* cs, const float* S2,
                      int B, int N, int H, int C, int M, float* out, hipStream_t st) {
-    const int chunk = 1024, NG = (M + 63) / 64;
+    // 1024 points per workgroup at large N; at small N enough workgroups to fill the chip (~512 in all)
+    int chunk = (N + (512 / (B * H > 512 ? 512 : B * H)) - 1) / (512 / (B * H > 512 ? 512 : B * H));
+    chunk = ((chunk + 63) / 64) * 64;
+    chunk = chunk < 64 ? 64 : (chunk > 1024 ? 1024 : chunk);
+    const int NG = (M + 63) / 64;
     dim3 grid((N + chunk - 1) / chunk, B * H);
     const size_t lds = ((size_t)M * C + 4 * (64 / C) * M) * sizeof(float);
     switch (C) {
