@@ -6,6 +6,8 @@
 // (8 waves, 2 x 4) keeps a 256 x 256 block of dW in its accumulators over its chunk of rows, stages 32-row
 // tiles of both operands through a double-buffered LDS copy (each element leaves HBM / L2 once per workgroup)
 // and writes one partial record; the caller sums the records.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace haet {
@@ -13,6 +15,24 @@ namespace haet {
 namespace {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__device__ __forceinline__ unsigned tn_pack(float a, float b) {  // v_cvt_pk_bf16_f32 (RNE)
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void tn_split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned h = tn_pack(v[2 * i], v[2 * i + 1]);
+        hi[i] = h;
+        lo[i] = tn_pack(v[2 * i] - __uint_as_float(h << 16), v[2 * i + 1] - __uint_as_float(h & 0xffff0000u));
+    }
+}
 
 constexpr int kRowsTile = 32;
 
@@ -34,7 +54,9 @@ struct TapGeom {
     int gH, gW, gD, dh, dw, dd;
 };
 
-template <bool TAP>
+// X3: split-bf16 products (hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_bf16, each wave splitting the fragments it
+// reads) instead of exact f32 MFMA products: 1/5 of the matrix-core cycles, which leaves the kernel HBM-bound.
+template <bool TAP, bool X3>
 __global__ __launch_bounds__(512) void gemm_tn_f32_kernel(const float* __restrict__ G, const float* __restrict__ X,
                                                           int N, int O, int K, int chunk,
                                                           float* __restrict__ parts, TapGeom tg) {
@@ -95,9 +117,41 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_kernel(const float* __restric
         fetch(nb + kRowsTile);  // in flight under this tile's 128 MFMAs
         const float* gs = lds + cur * kTileFloats + ol + l31;
         const float* xs = lds + cur * kTileFloats + kRowsTile * 256 + kl + l31;
+        if (X3) {
+            // k-step s of the 32x32x16 instruction: this lane's 8 k-elements = rows 16 s + 8 half + j of the tile
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = gs[(16 * ks + 8 * half + j) * 256 + 32 * ob];
+                    dbl[ob] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                    tn_split8(v, ah[ob], al[ob]);
+                }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = xs[(16 * ks + 8 * half + j) * 256 + 32 * kb];
+                    tn_split8(v, bh[kb], bl[kb]);
+                }
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        const bf16x8 a0 = __builtin_bit_cast(bf16x8, ah[ob]), a1 = __builtin_bit_cast(bf16x8, al[ob]);
+                        const bf16x8 b0 = __builtin_bit_cast(bf16x8, bh[kb]), b1 = __builtin_bit_cast(bf16x8, bl[kb]);
+                        acc[ob][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[ob][kb], 0, 0, 0);
+                        acc[ob][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[ob][kb], 0, 0, 0);
+                        acc[ob][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[ob][kb], 0, 0, 0);
+                    }
+            }
+        }
         // k-pair kk of the instruction = rows kk (lanes 0-31) and kk + 16 (lanes 32-63) of the tile, both operands
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
+        for (int kk = 0; kk < (X3 ? 0 : 16); ++kk) {
             float a[4], b[2];
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) a[ob] = gs[(kk + 16 * half) * 256 + 32 * ob];
@@ -131,6 +185,11 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_kernel(const float* __restric
     }
 }
 
+static bool wgrad_exact_f32() {  // HAET_WGRAD_F32=1: exact f32 MFMA products (A/B runs, reference for the tests)
+    static const bool on = getenv("HAET_WGRAD_F32") != nullptr;
+    return on;
+}
+
 }  // namespace haet
 
 using namespace haet;
@@ -153,13 +212,19 @@ extern "C" int haet_linear_wgrad(const float* G, const float* X, int N, int O, i
     const size_t lds = 2 * (size_t)kTileFloats * sizeof(float);  // 128 KB
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f32_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(HAET_E_LAUNCH, "linear_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        for (const void* k : {reinterpret_cast<const void*>(gemm_tn_f32_kernel<false, false>),
+                              reinterpret_cast<const void*>(gemm_tn_f32_kernel<false, true>)}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail(HAET_E_LAUNCH, "linear_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_tn_f32_kernel<false>, grid, dim3(512), lds, as_stream(stream), G, X, N, O, K, chunk, parts,
-                       TapGeom{});
+    if (wgrad_exact_f32())
+        hipLaunchKernelGGL((gemm_tn_f32_kernel<false, false>), grid, dim3(512), lds, as_stream(stream), G, X, N, O, K,
+                           chunk, parts, TapGeom{});
+    else
+        hipLaunchKernelGGL((gemm_tn_f32_kernel<false, true>), grid, dim3(512), lds, as_stream(stream), G, X, N, O, K,
+                           chunk, parts, TapGeom{});
     return check_launch("gemm_tn_f32_kernel");
 }
 
@@ -176,12 +241,18 @@ extern "C" int haet_conv_wgrad_tap(const float* G, const float* X, int B, int gH
     const size_t lds = 2 * (size_t)kTileFloats * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f32_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(HAET_E_LAUNCH, "conv_wgrad_tap: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        for (const void* k : {reinterpret_cast<const void*>(gemm_tn_f32_kernel<true, false>),
+                              reinterpret_cast<const void*>(gemm_tn_f32_kernel<true, true>)}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail(HAET_E_LAUNCH, "conv_wgrad_tap: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_tn_f32_kernel<true>, grid, dim3(512), lds, as_stream(stream), G, X, N, O, Cin, chunk, parts,
-                       TapGeom{gH, gW, gD, dh, dw, dd});
+    if (wgrad_exact_f32())
+        hipLaunchKernelGGL((gemm_tn_f32_kernel<true, false>), grid, dim3(512), lds, as_stream(stream), G, X, N, O, Cin,
+                           chunk, parts, TapGeom{gH, gW, gD, dh, dw, dd});
+    else
+        hipLaunchKernelGGL((gemm_tn_f32_kernel<true, true>), grid, dim3(512), lds, as_stream(stream), G, X, N, O, Cin,
+                           chunk, parts, TapGeom{gH, gW, gD, dh, dw, dd});
     return check_launch("gemm_tn_f32_kernel<tap>");
 }

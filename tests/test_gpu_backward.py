@@ -174,7 +174,7 @@ def test_backward_never_materialises_the_slice_weights(hip_device):
 @pytest.mark.parametrize("rows,O,K", [(1, 256, 256), (31, 256, 256), (1000, 256, 256), (70001, 256, 256), (300, 512, 256),
                                       (257, 256, 768), (500, 64, 128)])
 def test_linear_weight_gradient_vs_fp64(rows, O, K, hip_device):
-    """haet_linear_wgrad (f32 MFMA, contraction over the points) against an fp64 product; shapes outside its
+    """haet_linear_wgrad (split-bf16 MFMA, contraction over the points) against an fp64 product; shapes outside its
     envelope take the library GEMM."""
     from haet_amd import ops
 
@@ -184,7 +184,7 @@ def test_linear_weight_gradient_vs_fp64(rows, O, K, hip_device):
     dW, db = ops.linear_wgrad(G.to(hip_device), X.to(hip_device))
     assert dW.shape == (O, K) and db.shape == (O,)
     ref = G.double().t() @ X.double()
-    assert float((dW.cpu().double() - ref).norm() / ref.norm()) < 2e-6
+    assert float((dW.cpu().double() - ref).norm() / ref.norm()) < 2e-5  # split-bf16 products (HAET_WGRAD_F32=1: exact f32)
     assert float((db.cpu().double() - G.double().sum(0)).norm() / G.double().sum(0).norm()) < 2e-6
 
 
@@ -206,5 +206,5 @@ def test_convolution_weight_gradient_vs_fp64(B, grid, k, hip_device):
     gW, gb = torch.autograd.grad(y, [conv.weight, conv.bias], g.double())
     dW, db = ops.conv_wgrad(g.to(hip_device), x.to(hip_device), grid, (k,) * nd)
     assert dW.shape == gW.shape
-    assert float((dW.cpu().double() - gW).norm() / gW.norm()) < 2e-6
+    assert float((dW.cpu().double() - gW).norm() / gW.norm()) < 2e-5
     assert float((db.cpu().double() - gb).norm() / gb.norm()) < 2e-6
