@@ -111,3 +111,40 @@ def test_halo_plane_exchange_three_ranks(tmp_path):
     mp.spawn(_halo_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
     for r in range(3):
         assert torch.load(os.path.join(tmp_path, f"h{r}.pt"))["ok"]
+
+
+def _grad_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from haet_amd.sharding import allreduce_gradients, exchange_planes, shard_bounds
+
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.GELU(), torch.nn.Linear(5, 3))
+    x = torch.randn(40, 6)
+    ref = [torch.autograd.grad(model(x).square().sum(), list(model.parameters()))][0]   # the whole batch on one rank
+    a, b = shard_bounds(40, rank, world)
+    model(x[a:b]).square().sum().backward()                                             # this rank's rows only
+    allreduce_gradients(model)
+    ok = all(torch.allclose(p.grad, g, atol=1e-5) for p, g in zip(model.parameters(), ref))
+    # the reverse halo exchange of the sharded convolution's backward: what I send "up" arrives as my neighbour's "from below"
+    up, down = torch.full((1, 2, 3), float(rank)), torch.full((1, 2, 3), 10.0 + rank)
+    got_prev, got_next = exchange_planes(up if rank > 0 else None, down if rank < world - 1 else None, None)
+    ok &= (got_prev is None) == (rank == 0) and (got_next is None) == (rank == world - 1)
+    if got_prev is not None:
+        ok &= bool((got_prev == 10.0 + rank - 1).all())
+    if got_next is not None:
+        ok &= bool((got_next == float(rank + 1)).all())
+    torch.save({"ok": bool(ok)}, os.path.join(tmp, f"g{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_and_reverse_exchange_three_ranks(tmp_path):
+    """The trainer-side SUM all-reduce of sharded training (every rank ends with the full-batch gradient) and the
+    neighbour exchange in the direction the convolution's backward uses it."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_grad_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    for r in range(3):
+        assert torch.load(os.path.join(tmp_path, f"g{r}.pt"))["ok"]
