@@ -1,5 +1,5 @@
 // Weight gradient of a Linear over the points: dW[O][K] = sum_n G[n][o] X[n][k], db[o] = sum_n G[n][o]
-// (to_out and in_project_x of the Physics_Attention modules; the reference gets them from torch autograd,
+// (to_out and in_project_x of the Physics_Attention modules, the block's MLPs, the convolution's taps; the reference gets them from torch autograd,
 // exp_airfoil.py:249-255).  N is ~1e6, O = K = 256: an output-stationary GEMM whose contraction runs
 // over the ROW index of both operands, so the f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32 products)
 // takes both operands as plain row-major tiles, the output column in the lane: no transposes.  A workgroup
@@ -185,9 +185,174 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same contraction with the split done ONCE per element: the staging threads convert each 32-row tile of G and X
+// to {hi, lo} bf16 images [32 rows][32 columns] (64-B rows, 16-B chunks XOR-swizzled: the layout of slice_mfma.hip),
+// and every wave takes its A / B fragments -- 8 consecutive ROWS of one column, i.e. the contraction index in the
+// k slot -- with the transposed LDS read ds_read_b64_tr_b16.  No per-wave split (each element was split by up to
+// four waves above), a quarter of the LDS read instructions.
+constexpr int kImg = 2048 + 32;                 // bytes per image plane
+constexpr int kTileImgBytes = 2 * 8 * 2 * kImg;  // G and X: 8 column blocks each, {hi, lo}
+
+__device__ __forceinline__ int tn_img_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+typedef __attribute__((ext_vector_type(4))) short tn_s16x4;
+typedef __attribute__((ext_vector_type(2))) unsigned tn_u32x2;
+
+// fragment of k-step s (rows 16 s .. 16 s + 15 of the tile) for column lane % 32 of the image at byte offset img
+__device__ __forceinline__ void tn_read_cols(const char* smem, int img, int s, int lane, u32x4& hi, u32x4& lo) {
+    const int i = lane & 15, cb = (lane >> 4) & 1, hf = lane >> 5;
+    const int chunk = 2 * cb + ((i & 3) >> 1), sub = (i & 1) << 3;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const int base = img + part * kImg;
+        const int r0 = 16 * s + 4 * hf + (i >> 2), r1 = r0 + 8;
+        const tn_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) tn_s16x4*)(smem + base + tn_img_off(r0, chunk) + sub));
+        const tn_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) tn_s16x4*)(smem + base + tn_img_off(r1, chunk) + sub));
+        const tn_u32x2 a2 = __builtin_bit_cast(tn_u32x2, a), b2 = __builtin_bit_cast(tn_u32x2, b);
+        const u32x4 v = {a2[0], a2[1], b2[0], b2[1]};
+        if (part == 0) hi = v;
+        else lo = v;
+    }
+}
+
+template <bool TAP>
+__global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const float* __restrict__ G, const float* __restrict__ X,
+                                                         int N, int O, int K, int chunk,
+                                                         float* __restrict__ parts, TapGeom tg) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char tsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int kblocks = K / 256;
+    const int ob0 = (blockIdx.y / kblocks) * 256, kb0 = (blockIdx.y % kblocks) * 256;
+    const int wo = wave >> 2, wk = wave & 3;  // this wave's 128 x 64 part of the 256 x 256 block
+    const int n0 = blockIdx.x * chunk, n1 = min(N, n0 + chunk);
+
+    f16v acc[4][2];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[ob][kb][v] = 0.f;
+
+    // staging: thread t = float4 column t % 64 of rows t / 64 + 8 i (i < 4) of both operands
+    const int sr = tid >> 6, sc = (tid & 63) * 4, q8 = tid & 7, blk = (tid & 63) >> 3;
+    const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    f4v sg[4], sx[4], dbs = zero4;  // dbs: this thread's 4 columns of sum_n G over its rows (the bias gradient)
+    auto fetch = [&](int nb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = nb + sr + 8 * i;
+            const bool ok = n < n1;
+            const size_t r = ok ? (size_t)n : (size_t)n0;  // unconditional loads: the waits stay counted
+            size_t rx = r;
+            bool okx = ok;
+            if (TAP) {
+                const int d = (int)(r % tg.gD), w = (int)((r / tg.gD) % tg.gW), hh = (int)((r / ((size_t)tg.gD * tg.gW)) % tg.gH);
+                okx = ok && (unsigned)(hh + tg.dh) < (unsigned)tg.gH && (unsigned)(w + tg.dw) < (unsigned)tg.gW &&
+                      (unsigned)(d + tg.dd) < (unsigned)tg.gD;
+                if (okx) rx = (size_t)((long long)r + ((long long)tg.dh * tg.gW + tg.dw) * tg.gD + tg.dd);
+            }
+            const f4v g4 = *reinterpret_cast<const f4v*>(G + r * O + ob0 + sc);
+            const f4v x4 = *reinterpret_cast<const f4v*>(X + rx * K + kb0 + sc);
+            sg[i] = ok ? g4 : zero4;
+            sx[i] = okx ? x4 : zero4;
+        }
+    };
+    auto put = [&](int base, int row, const f4v v) {  // 4 consecutive columns of one row -> the 8-B {hi} and {lo} pieces
+        const unsigned h01 = tn_pack(v[0], v[1]), h23 = tn_pack(v[2], v[3]);
+        const tn_u32x2 hi = {h01, h23};
+        const tn_u32x2 lo = {tn_pack(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u)),
+                             tn_pack(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u))};
+        const int off = base + tn_img_off(row, q8 >> 1) + ((q8 & 1) << 3);
+        *reinterpret_cast<tn_u32x2*>(tsm + off) = hi;
+        *reinterpret_cast<tn_u32x2*>(tsm + off + kImg) = lo;
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dbs += sg[i];
+            put(buf + blk * (2 * kImg), sr + 8 * i, sg[i]);
+            put(buf + (8 + blk) * (2 * kImg), sr + 8 * i, sx[i]);
+        }
+    };
+    fetch(n0);
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (int nb = n0; nb < n1; nb += kRowsTile) {
+        fetch(nb + kRowsTile);  // in flight under this tile's MFMAs
+        const int gimg = cur * kTileImgBytes + (4 * wo) * (2 * kImg);
+        const int ximg = cur * kTileImgBytes + (8 + 2 * wk) * (2 * kImg);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) tn_read_cols(tsm, gimg + ob * (2 * kImg), ks, lane, ah[ob], al[ob]);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) tn_read_cols(tsm, ximg + kb * (2 * kImg), ks, lane, bh[kb], bl[kb]);
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const bf16x8 a0 = __builtin_bit_cast(bf16x8, ah[ob]), a1 = __builtin_bit_cast(bf16x8, al[ob]);
+                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, bh[kb]), b1 = __builtin_bit_cast(bf16x8, bl[kb]);
+                    acc[ob][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[ob][kb], 0, 0, 0);
+                    acc[ob][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[ob][kb], 0, 0, 0);
+                    acc[ob][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[ob][kb], 0, 0, 0);
+                }
+        }
+        cur ^= 1;
+        stash(cur * kTileImgBytes);  // last read as tile nb - 32, before the barrier that ended that iteration
+        __syncthreads();
+    }
+    // (the last stash staged an all-zero tile past the chunk and added zeros to dbs)
+
+    float* rec = parts + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (size_t)(256 * 256 + 256);
+    const int ol = 128 * wo, kl = 64 * wk;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int o = ol + 32 * ob + 8 * (v >> 2) + 4 * half + (v & 3);
+                rec[o * 256 + kl + 32 * kb + l31] = acc[ob][kb][v];
+            }
+    // bias gradient: wave w holds the sums over rows = w (mod 8) of all 256 columns (lane l: columns 4l .. 4l+3)
+    float* red = reinterpret_cast<float*>(tsm);
+    *reinterpret_cast<f4v*>(red + wave * 256 + 4 * lane) = dbs;
+    __syncthreads();
+    if (tid < 256) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) sum += red[w * 256 + tid];
+        rec[256 * 256 + tid] = sum;
+    }
+}
+
 static bool wgrad_exact_f32() {  // HAET_WGRAD_F32=1: exact f32 MFMA products (A/B runs, reference for the tests)
     static const bool on = getenv("HAET_WGRAD_F32") != nullptr;
     return on;
+}
+static bool wgrad_wave_split() {  // HAET_WGRAD_WAVE_SPLIT=1: the split-bf16 variant that splits per wave (A/B runs)
+    static const bool on = getenv("HAET_WGRAD_WAVE_SPLIT") != nullptr;
+    return on;
+}
+static int x3_attr() {
+    static bool done = false;
+    if (!done) {
+        for (const void* k : {reinterpret_cast<const void*>(gemm_tn_x3_kernel<false>),
+                              reinterpret_cast<const void*>(gemm_tn_x3_kernel<true>)}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileImgBytes);
+            if (e != hipSuccess) return fail(HAET_E_LAUNCH, "linear_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        done = true;
+    }
+    return HAET_OK;
 }
 
 }  // namespace haet
@@ -222,10 +387,15 @@ extern "C" int haet_linear_wgrad(const float* G, const float* X, int N, int O, i
     if (wgrad_exact_f32())
         hipLaunchKernelGGL((gemm_tn_f32_kernel<false, false>), grid, dim3(512), lds, as_stream(stream), G, X, N, O, K,
                            chunk, parts, TapGeom{});
-    else
+    else if (wgrad_wave_split())
         hipLaunchKernelGGL((gemm_tn_f32_kernel<false, true>), grid, dim3(512), lds, as_stream(stream), G, X, N, O, K,
                            chunk, parts, TapGeom{});
-    return check_launch("gemm_tn_f32_kernel");
+    else {
+        if (int rc = x3_attr()) return rc;
+        hipLaunchKernelGGL((gemm_tn_x3_kernel<false>), grid, dim3(512), 2 * kTileImgBytes, as_stream(stream), G, X, N, O,
+                           K, chunk, parts, TapGeom{});
+    }
+    return check_launch("gemm_tn kernel");
 }
 
 // One tap (dh, dw, dd) of the weight gradient of a same-padded stride-1 convolution over the channels-last grid
@@ -251,8 +421,13 @@ extern "C" int haet_conv_wgrad_tap(const float* G, const float* X, int B, int gH
     if (wgrad_exact_f32())
         hipLaunchKernelGGL((gemm_tn_f32_kernel<true, false>), grid, dim3(512), lds, as_stream(stream), G, X, N, O, Cin,
                            chunk, parts, TapGeom{gH, gW, gD, dh, dw, dd});
-    else
+    else if (wgrad_wave_split())
         hipLaunchKernelGGL((gemm_tn_f32_kernel<true, true>), grid, dim3(512), lds, as_stream(stream), G, X, N, O, Cin,
                            chunk, parts, TapGeom{gH, gW, gD, dh, dw, dd});
+    else {
+        if (int rc = x3_attr()) return rc;
+        hipLaunchKernelGGL((gemm_tn_x3_kernel<true>), grid, dim3(512), 2 * kTileImgBytes, as_stream(stream), G, X, N, O,
+                           Cin, chunk, parts, TapGeom{gH, gW, gD, dh, dw, dd});
+    }
     return check_launch("gemm_tn_f32_kernel<tap>");
 }
