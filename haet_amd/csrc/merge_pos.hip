@@ -20,12 +20,34 @@ __global__ __launch_bounds__(256) void slice_merge_kernel(
     const int lane = tid & 63, wave = tid >> 6;
     const size_t rstride = (size_t)BH * M * (C + 2);
     const size_t base = (size_t)bh * M * (C + 2);
+    // All three kinds of loads (m, l, St) are issued before anything is computed on them: the kernel is a chain of
+    // dependent round trips to L2 / HBM otherwise (~17 us for 256 records; it runs twice per forward on the
+    // point-sharded path).  St: this thread's records r = grp, grp + ngrp, ... in blocks of kPre.
+    constexpr int kPre = 32;
+    const int ngrp = 256 / C, c = tid % C, grp = tid / C;
+    const float* sp = rec + base + 2 * M + (size_t)g * C + c;
+    float pre[kPre];
+    if (grp < ngrp) {
+#pragma unroll
+        for (int i = 0; i < kPre; ++i) {
+            const int r = grp + i * ngrp;
+            pre[i] = r < R ? sp[r * rstride] : 0.f;
+        }
+    }
     float mx = -INFINITY;
     for (int r = tid; r < R; r += 256) {
         const float mr = rec[r * rstride + base + g];
+        red[tid] = rec[r * rstride + base + M + g];  // l_r, parked until the weights exist (R <= 256: one per thread)
         aw[r] = mr;
         mx = fmaxf(mx, mr);
+        if (R > 256) break;  // (larger R: the second loop below re-reads l)
     }
+    if (R > 256)
+        for (int r = tid + 256; r < R; r += 256) {
+            const float mr = rec[r * rstride + base + g];
+            aw[r] = mr;
+            mx = fmaxf(mx, mr);
+        }
     mx = wave_max(mx);
     if (lane == 0) wred[wave] = mx;
     __syncthreads();
@@ -35,19 +57,24 @@ __global__ __launch_bounds__(256) void slice_merge_kernel(
         const float mr = aw[r];
         const float a = (mr == -INFINITY) ? 0.f : __expf(mr - mx);
         aw[r] = a;
-        lsum = fmaf(rec[r * rstride + base + M + g], a, lsum);
+        const float lr = (R <= 256) ? red[tid] : rec[r * rstride + base + M + g];
+        lsum = fmaf(lr, a, lsum);
     }
     lsum = wave_sum(lsum);
     if (lane == 0) wred[4 + wave] = lsum;
     __syncthreads();
     lsum = (wred[4] + wred[5]) + (wred[6] + wred[7]);
     // phase 2
-    const int ngrp = 256 / C, c = tid % C, grp = tid / C;
     float s = 0.f;
     if (grp < ngrp) {
-        const float* sp = rec + base + 2 * M + (size_t)g * C + c;
-        for (int r = grp; r < R; r += ngrp) s = fmaf(sp[r * rstride], aw[r], s);
+#pragma unroll
+        for (int i = 0; i < kPre; ++i) {
+            const int r = grp + i * ngrp;
+            if (r < R) s = fmaf(pre[i], aw[r], s);
+        }
+        for (int r = grp + kPre * ngrp; r < R; r += ngrp) s = fmaf(sp[r * rstride], aw[r], s);
     }
+    __syncthreads();  // red[] held the l values until here
     red[tid] = s;
     __syncthreads();
     if (tid < C) {
