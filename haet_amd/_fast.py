@@ -9,7 +9,7 @@ With gradients enabled (training scripts: loss.backward(), exp_airfoil.py:249-25
 autograd nodes on the same kernels -- Linear: forward GEMM, input gradient = the GEMM with the transposed
 weight planes, weight / bias gradient = haet_linear_wgrad; LayerNorm: haet_layernorm_fwd / _bwd -- with the
 activation left to torch (it keeps the pre-activation for its own backward).  One-layer model, 1M points:
-inference 15.1 -> 7.6 ms, training step 58.4 -> 31.1 ms.
+inference 15.1 -> 6.8 ms, training step 58.4 -> 30.6 ms.
 
 fp32 tensors on the device only; anything else (autocast dtypes, shapes outside the kernels' envelopes,
 HAET_NO_BLOCK_FAST=1) runs the stock modules unchanged.
