@@ -9,7 +9,7 @@ With gradients enabled (training scripts: loss.backward(), exp_airfoil.py:249-25
 autograd nodes on the same kernels -- Linear: forward GEMM, input gradient = the GEMM with the transposed
 weight planes, weight / bias gradient = haet_linear_wgrad; LayerNorm: haet_layernorm_fwd / _bwd -- with the
 activation left to torch (it keeps the pre-activation for its own backward).  One-layer model, 1M points:
-inference 15.1 -> 6.8 ms, training step 58.4 -> 30.6 ms.
+inference 15.1 -> 6.2 ms, training step 58.4 -> 30.6 ms.
 
 fp32 tensors on the device only; anything else (autocast dtypes, shapes outside the kernels' envelopes,
 HAET_NO_BLOCK_FAST=1) runs the stock modules unchanged.
@@ -169,6 +169,17 @@ def add_layer_norm(ln: nn.LayerNorm, x: torch.Tensor, res: torch.Tensor):
         return ops.add_layernorm(x, res, ln.weight, ln.bias, ln.eps)
     s = x + res
     return s, layer_norm(ln, s)
+
+
+@torch.compiler.disable  # opaque to torch.compile: ctypes calls into libhaet_hip.so
+def add_layer_norm_linear(ln: nn.LayerNorm, lin: nn.Linear, x: torch.Tensor, res: torch.Tensor) -> torch.Tensor:
+    """lin(ln(x + res)) -- the model's last layer; one kernel at inference when the output is narrow."""
+    if (enabled(x) and res.shape == x.shape and res.dtype == torch.float32 and ln.elementwise_affine and ln.bias is not None
+            and tuple(ln.normalized_shape) == (lin.in_features,)
+            and ops.ln_linear_small_supported(lin.in_features, lin.out_features)):
+        return ops.ln_linear_small(x, res, ln.weight, ln.bias, ln.eps, lin.weight, lin.bias)
+    _, h = add_layer_norm(ln, x, res)
+    return linear(lin, h)
 
 
 def is_exact_gelu(act: nn.Module) -> bool:

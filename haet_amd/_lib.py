@@ -85,6 +85,8 @@ SIGNATURES = {
     "haet_layernorm_supported": (c_int, [c_int]),
     "haet_layernorm_fwd": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P]),
     "haet_add_layernorm_fwd": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P]),
+    "haet_ln_linear_small_supported": (c_int, [c_int, c_int]),
+    "haet_ln_linear_small_fwd": (c_int, [_P, _P, _P, _P, c_float, _P, _P, c_int, c_int, c_int, _P, _P]),
     "haet_layernorm_bwd_num_parts": (c_int, [c_int]),
     "haet_layernorm_bwd": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P, _P]),
     "haet_linear_narrow_supported": (c_int, [c_int, c_int]),

@@ -41,8 +41,7 @@ class TransolverErwinBlockBase(nn.Module):
                 if m is None:
                     m = self.mlp(_fast.layer_norm(self.ln_2, fx))
                 if self.last_layer:
-                    _, h = _fast.add_layer_norm(self.ln_3, m, fx)
-                    return _fast.linear(self.mlp2, h)
+                    return _fast.add_layer_norm_linear(self.ln_3, self.mlp2, m, fx)
                 return m.add_(fx)
             fx = self.Attn(_fast.layer_norm(self.ln_1, fx)) + fx
             m = self.mlp(_fast.layer_norm(self.ln_2, fx))

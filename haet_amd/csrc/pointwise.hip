@@ -216,6 +216,51 @@ __global__ __launch_bounds__(256) void linear_narrow_kernel(const float* __restr
     }
 }
 
+// Last layer of the model (HAETransolver_Irregular_Mesh.py:129-132): out = mlp2(ln_3(x + res)) with a narrow output
+// (out_dim <= 16).  One wave per row like the LayerNorm kernel; neither the sum nor the normalised row is written --
+// nothing after the last block reads them -- only the OD outputs: dots of the lane's 4 normalised channels with its
+// 4 columns of W, reduced over the wave.  D = 256 (64 lanes x 4 channels).
+template <int OD, bool RES>
+__global__ __launch_bounds__(256) void ln_linear_small_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float eps, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, int rows, int od,
+                                                              float* __restrict__ out) {
+    constexpr int D = 256;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const f4v g = *reinterpret_cast<const f4v*>(gamma + 4 * lane), b = *reinterpret_cast<const f4v*>(beta + 4 * lane);
+    f4v w[OD];
+#pragma unroll
+    for (int j = 0; j < OD; ++j) w[j] = j < od ? *reinterpret_cast<const f4v*>(W + (size_t)j * D + 4 * lane) : f4v{0.f, 0.f, 0.f, 0.f};
+    const float bl = (bias && lane < od) ? bias[lane] : 0.f;
+    for (int r = wave; r < rows; r += nwaves) {
+        f4v v = *reinterpret_cast<const f4v*>(x + (size_t)r * D + 4 * lane);
+        if (RES) v += *reinterpret_cast<const f4v*>(res + (size_t)r * D + 4 * lane);
+        const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] -= mean;
+            q = fmaf(v[j], v[j], q);
+        }
+        const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j] * rstd, g[j], b[j]);
+        float mine = 0.f;  // lane j < od ends up with output j
+#pragma unroll
+        for (int j = 0; j < OD; ++j) {
+            float d = v[0] * w[j][0];
+            d = fmaf(v[1], w[j][1], d);
+            d = fmaf(v[2], w[j][2], d);
+            d = fmaf(v[3], w[j][3], d);
+            d = wave_sum(d);
+            mine = lane == j ? d : mine;
+        }
+        if (lane < od) out[(size_t)r * od + lane] = mine + bl;
+    }
+}
+
 // The same Linear when O / 4 is a multiple of 64 (every wave's 64 lanes = 256 consecutive outputs of ONE row): the
 // lane keeps its 4 weight columns in registers for the whole kernel, the row's K inputs are wave-uniform (scalar
 // loads), and the kernel is a pure output stream -- the generic kernel above spends its time on 7 wave-wide loads of
@@ -292,6 +337,27 @@ extern "C" int haet_add_layernorm_fwd(const float* x, const float* res, const fl
         default: hipLaunchKernelGGL((layernorm_kernel<4, true>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, eps, rows, D, out, res, sum); break;
     }
     return check_launch("layernorm_kernel<res>");
+}
+
+extern "C" int haet_ln_linear_small_supported(int D, int OD) { return (D == 256 && OD >= 1 && OD <= 16) ? 1 : 0; }
+
+extern "C" int haet_ln_linear_small_fwd(const float* x, const float* res /*or NULL*/, const float* gamma,
+                                        const float* beta, float eps, const float* W /*[OD, D]*/, const float* bias,
+                                        int rows, int D, int OD, float* out, haet_stream_t stream) {
+    if (!x || !gamma || !beta || !W || !out || rows < 1) return fail(HAET_E_ARG, "ln_linear_small_fwd: bad arguments");
+    if (!haet_ln_linear_small_supported(D, OD)) return fail(HAET_E_ARG, "ln_linear_small_fwd: D=%d (256) / OD=%d (<= 16) unsupported", D, OD);
+    const int blocks = rows < 4 * 2048 ? (rows + 3) / 4 : 2048;
+    hipStream_t st = as_stream(stream);
+#define HAET_LNL(ODT)                                                                                                   \
+    do {                                                                                                                \
+        if (res) hipLaunchKernelGGL((ln_linear_small_kernel<ODT, true>), dim3(blocks), dim3(256), 0, st, x, res, gamma, beta, eps, W, bias, rows, OD, out); \
+        else hipLaunchKernelGGL((ln_linear_small_kernel<ODT, false>), dim3(blocks), dim3(256), 0, st, x, res, gamma, beta, eps, W, bias, rows, OD, out);    \
+    } while (0)
+    if (OD <= 4) HAET_LNL(4);
+    else if (OD <= 8) HAET_LNL(8);
+    else HAET_LNL(16);
+#undef HAET_LNL
+    return check_launch("ln_linear_small_kernel");
 }
 
 extern "C" int haet_layernorm_bwd_num_parts(int rows) { return rows < 4 * 1024 ? (rows + 3) / 4 : 1024; }

@@ -276,6 +276,26 @@ def add_layernorm(x: Tensor, res: Tensor, weight: Tensor, bias: Tensor, eps: flo
     return s, out
 
 
+def ln_linear_small_supported(D: int, OD: int) -> bool:
+    return bool(_lib.load().haet_ln_linear_small_supported(int(D), int(OD)))
+
+
+def ln_linear_small(x: Tensor, res: Optional[Tensor], ln_weight: Tensor, ln_bias: Tensor, eps: float,
+                    weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """Linear(LayerNorm(x (+ res))) with at most 16 outputs, one pass (haet_ln_linear_small_fwd)."""
+    lib = _lib.load()
+    x = _f32(x, "x")
+    D = x.shape[-1]
+    OD = weight.shape[0]
+    out = torch.empty(x.shape[:-1] + (OD,), dtype=torch.float32, device=x.device)
+    check(lib.haet_ln_linear_small_fwd(_p(x), _p(None if res is None else _f32(res, "res")),
+                                       _p(_f32(ln_weight.detach(), "ln.weight")), _p(_f32(ln_bias.detach(), "ln.bias")),
+                                       float(eps), _p(_f32(weight.detach(), "weight")),
+                                       _p(None if bias is None else _f32(bias.detach(), "bias")), x.numel() // D, D, OD,
+                                       _p(out), _stream()), "haet_ln_linear_small_fwd")
+    return out
+
+
 def layernorm_bwd(x: Tensor, weight: Tensor, gy: Tensor, eps: float):
     """(dx, dgamma, dbeta) of nn.LayerNorm over the last dimension (haet_layernorm_bwd + the sum of its partials)."""
     lib = _lib.load()

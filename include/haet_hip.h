@@ -290,6 +290,12 @@ int haet_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 /* sum = x + res and out = LayerNorm(sum) in one pass (the block's residual add feeding its next LayerNorm) */
 int haet_add_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps,
                            int rows, int D, float* sum, float* out, haet_stream_t stream);
+/* out [rows, OD] = Linear(LayerNorm(x (+ res))) with a narrow output (OD <= 16, D = 256): the model's last layer,
+ * mlp2(ln_3(.)) (HAETransolver_Irregular_Mesh.py:129-132); neither the sum nor the normalised rows are written. */
+int haet_ln_linear_small_supported(int D, int OD);
+int haet_ln_linear_small_fwd(const float* x, const float* res /*or NULL*/, const float* gamma, const float* beta,
+                             float eps, const float* W /*[OD, D]*/, const float* bias, int rows, int D, int OD,
+                             float* out, haet_stream_t stream);
 /* backward of haet_layernorm_fwd: dx [rows, D] and per-workgroup partials parts [P][2 D] = {dgamma, dbeta}
  * (P = haet_layernorm_bwd_num_parts(rows)); the statistics are recomputed from x.                        */
 int haet_layernorm_bwd_num_parts(int rows);

@@ -205,3 +205,19 @@ def test_training_step_under_torch_compile(hip_device):
     scale = max(float(g.norm()) for g in g_ref.values())
     for name, gr in g_ref.items():
         assert float((g_c[name] - gr).norm()) / max(float(gr.norm()), 1e-4 * scale) < 2e-3, name
+
+
+@pytest.mark.parametrize("rows,od,with_res", [(1, 4, True), (5000, 4, True), (777, 1, False), (300, 16, True), (64, 7, False)])
+def test_layernorm_narrow_linear_vs_fp64(rows, od, with_res, hip_device):
+    from haet_amd import ops
+
+    g = torch.Generator().manual_seed(rows + od)
+    x, r = torch.randn(rows, 256, generator=g) * 1.5, torch.randn(rows, 256, generator=g)
+    lw, lb = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    W, b = torch.randn(od, 256, generator=g) / 16, torch.randn(od, generator=g)
+    s = x.double() + (r.double() if with_res else 0)
+    ref = torch.nn.functional.layer_norm(s, (256,), lw.double(), lb.double(), 1e-5) @ W.double().t() + b.double()
+    out = ops.ln_linear_small(x.to(hip_device), r.to(hip_device) if with_res else None, lw.to(hip_device), lb.to(hip_device),
+                              1e-5, W.to(hip_device), b.to(hip_device))
+    assert out.shape == (rows, od)
+    assert O.rel_l2(out.cpu().double(), ref) < 2e-6
