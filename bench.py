@@ -60,19 +60,27 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python3 bench.py --gpus N`: become the launcher -- N children under torch.distributed.run, started
+        # BEFORE anything here touches the GPU (no exec from a process that holds the device), exit with their code
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    dev = torch.device("cuda", local)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    n_dev = torch.cuda.device_count()
+    rehearsal = world > n_dev  # several ranks per GPU (HAET_BENCH_REHEARSE, see self_launch): gloo moves the records
+    dev = torch.device("cuda", local % max(n_dev, 1))
     torch.cuda.set_device(dev)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from haet_amd import _lib
     from haet_amd.sharding import shard_bounds, shard_points
@@ -133,7 +141,7 @@ def main():
     mod.stage_events = None
     mod.event_pool = None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -148,6 +156,7 @@ def main():
         dom = max(BYTES_PER_POINT, key=lambda k: stage_ms[k])
         n_local = b - a
         gbs = n_local * BYTES_PER_POINT[dom](256) / (stage_ms[dom] * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic_bytes(KERNEL_OF_STAGE[dom], N) if world == 1 else (None, None)
         res = {
             "metric": "forward points/sec + L2 vs ref, 1M-pt irregular mesh, M=64 slices",
             "value": N * args.steps / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps,
@@ -159,10 +168,15 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": KERNEL_OF_STAGE[dom], "stage": dom, "achieved": gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_bytes(KERNEL_OF_STAGE[dom], N) if world == 1 else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         # the whole forward against SURVEY.md 8d's fused floor of 3*D*4 B/point (x read once per
+                         # pass, the output written once) at the HBM peak
+                         "path_frac": N * 3 * 256 * 4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "all_kernels_frac": {k: round(n_local * BYTES_PER_POINT[k](256) / (stage_ms[k] * 1e-3)
                                                        / 1e9 / HBM_PEAK_GBS, 4) for k in BYTES_PER_POINT}},
         }
+        if rehearsal:
+            res["rehearsal"] = f"{world} ranks on {n_dev} GPU(s), records over gloo: functional run, not a measurement"
         if world == 1 and not args.no_cpu_baseline:
             res.update(cpu_leg(mod, x_full, out))
         if world == 1:
@@ -171,6 +185,27 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(args):
+    """Run this script as N ranks on this node and return their exit code."""
+    import socket
+    import subprocess
+
+    n_dev = torch.cuda.device_count()  # (does not initialise the GPU on this image)
+    env = dict(os.environ)
+    if n_dev < args.gpus:
+        if not os.environ.get("HAET_BENCH_REHEARSE") or n_dev < 1 or args.gpus > 6:
+            print(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, this node shows {n_dev} "
+                  "(HAET_BENCH_REHEARSE=1 runs up to 6 ranks on the GPUs there are, over gloo: a functional "
+                  "rehearsal, not a measurement)", file=sys.stderr)
+            return 3
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def train_leg(mod, x, steps=5):
@@ -206,19 +241,31 @@ def train_leg(mod, x, steps=5):
         return {"train_step": {"error": repr(exc)}}
 
 
+def kernel_source_id():
+    """Identifies the build the numbers belong to: a hash over the kernel sources (haet_amd/csrc)."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "haet_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "haet_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic_bytes(kernel, n_points):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*pmc_traffic.json:
-    FETCH_SIZE corrected x2 for gfx950 + WRITE_SIZE), or None if they were taken at another size."""
+    """(HBM bytes per launch of `kernel`, source file) from the committed PMC pass of THIS build
+    (profiles/*pmc_traffic.json whose `source_id` matches the kernel sources; FETCH_SIZE corrected x2 for
+    gfx950 + WRITE_SIZE, MI355X_MICROARCH.md HBM section) -- (None, None) when no pass of this build and this
+    size is committed: a byte count of another build is not this run's traffic."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-    if not files:
-        return None
-    d = json.load(open(files[-1]))
-    k = d.get("kernels", {}).get(kernel)
-    if not k or d.get("points") != n_points:
-        return None
-    return (2.0 * k["fetch_kb_raw"] + k["write_kb"]) * 1024.0
+    sid = kernel_source_id()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), key=os.path.getmtime, reverse=True):
+        d = json.load(open(f))
+        k = d.get("kernels", {}).get(kernel)
+        if k and d.get("points") == n_points and d.get("source_id") == sid:
+            return (2.0 * k["fetch_kb_raw"] + k["write_kb"]) * 1024.0, os.path.basename(f)
+    return None, None
 
 
 def host_cores():

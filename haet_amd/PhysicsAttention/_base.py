@@ -23,6 +23,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from .. import _lib as _lib_mod
 from .. import ops
 from ..components import ErwinFlashTransformer as ErwinTransformer
 from .._lib import HaetError
@@ -94,6 +95,7 @@ class PhysicsAttentionBase(nn.Module):
         self.stage_events = None  # set to [] to collect (stage, start, end) HIP events (bench.py)
         self.event_pool = None    # optional list of pre-recorded timing events the stage timer draws from
         self._slice_cache = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_caches())
 
     # -- per-variant projection to [B, N, H*C] -------------------------------------------
     def project(self, x: torch.Tensor) -> torch.Tensor:
@@ -198,10 +200,10 @@ class PhysicsAttentionBase(nn.Module):
     def _any_requires_grad(self) -> bool:
         d = self.__dict__
         ps = d.get("_grad_check_params")
-        d["_grad_check_age"] = d.get("_grad_check_age", 0) + 1
-        if ps is None or d.get("_grad_check_stale", True) or d["_grad_check_age"] >= 256:
+        gen = _lib_mod.cache_generation()
+        if ps is None or d.get("_grad_check_stale", True) or d.get("_grad_check_gen") != gen:
             ps = list(self.parameters())  # ~50 us: cached, see ErwinTransformer._pack_key
-            d["_grad_check_params"], d["_grad_check_stale"], d["_grad_check_age"] = ps, False, 0
+            d["_grad_check_params"], d["_grad_check_stale"], d["_grad_check_gen"] = ps, False, gen
         for p in ps:
             if p.requires_grad:
                 return True
@@ -210,6 +212,17 @@ class PhysicsAttentionBase(nn.Module):
     def _apply(self, fn, *args, **kwargs):  # .to() / .cuda(): parameter objects may be replaced
         self.__dict__["_grad_check_stale"] = True
         return super()._apply(fn, *args, **kwargs)
+
+    def invalidate_caches(self):
+        """Drop every weight-derived operand this module caches (bf16 planes of the projections, the slice
+        parameters, the packed Erwin blob); they are re-derived at the next forward.  The caches are keyed on
+        each parameter's (storage pointer, `_version`), which ordinary updates (optimizer steps, `copy_`,
+        load_state_dict) change -- but in-place writes through `.data` (an EMA swap `p.data.copy_(shadow)`,
+        `p.data.clamp_()`) change neither: call this after such writes."""
+        self.__dict__["_split_cache"] = {}
+        self._slice_cache = None
+        self.__dict__["_grad_check_stale"] = True
+        self.erwin.invalidate_caches()
 
     @torch.compiler.disable  # torch.compile(model) (the reference's scripts): the HIP path is an opaque eager call
     def forward(self, x: torch.Tensor, return_intermediates: bool = False, pre_norm: Optional[nn.LayerNorm] = None):

@@ -86,6 +86,8 @@ def erwin_forward(er, feat, pos, n_clouds):
         x = _run_blocks(layer, x, p, rots[i])
         stack.append((x, p, rots[i]))
         st = layer.pool.stride  # components/pooling.py:25-40
+        if st == 1:  # "no pooling" (pooling.py:26-27): the node passes through, no projection / BatchNorm
+            continue
         centers = p.view(-1, st, d).mean(dim=1)
         rel = (p.view(-1, st, d) - centers[:, None]).reshape(-1, st * d)
         x = layer.pool.norm(layer.pool.proj(torch.cat([x.reshape(-1, st * x.shape[1]), rel], dim=1)))
@@ -116,7 +118,7 @@ def attention_forward(mod, x):
     flat = S.reshape(B * H * G, C)
     d = mod.dimensionality
     lo, hi = flat[:, :d].min(dim=0)[0], flat[:, :d].max(dim=0)[0]
-    pos = (flat[:, :d] - lo) / (hi - lo + 1e-8)
+    pos = ((flat[:, :d] - lo) / (hi - lo + 1e-8)).detach()  # no gradient through positions (see _tokens_through_erwin)
     S2 = erwin_forward(mod.erwin, flat, pos, B * H).reshape(B, H, G, C)
     out_x = torch.einsum("bhgc,bhng->bhnc", S2, w).permute(0, 2, 1, 3).reshape(B, N, H * C)
     return mod.to_out(out_x).to(x.dtype)
@@ -154,7 +156,9 @@ def _tokens_through_erwin(mod, S, n_clouds):
     """Token positions (IrregularMesh.py:196-209) + Erwin on the slice tokens S [T, C], differentiable."""
     d = mod.dimensionality
     lo, hi = S[:, :d].min(dim=0)[0], S[:, :d].max(dim=0)[0]
-    pos = (S[:, :d] - lo) / (hi - lo + 1e-8)
+    # The reference uses positions only under no_grad (attention.py:35 `compute_rel_pos`, pooling.py:29,59,
+    # the tree build erwin_flash.py:149): nothing flows S -> pos -> pe_proj / pool / unpool.
+    pos = ((S[:, :d] - lo) / (hi - lo + 1e-8)).detach()
     return erwin_forward(mod.erwin, S, pos, n_clouds)
 
 

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import _lib, ops
 
 _split = weakref.WeakKeyDictionary()  # nn.Linear -> (weight / bias version key, ops.SplitLinear)
 
@@ -40,7 +40,7 @@ _split_t = weakref.WeakKeyDictionary()  # nn.Linear -> (weight version key, Spli
 
 
 def _split_t_of(lin: nn.Linear) -> ops.SplitLinear:
-    key = (lin.weight.data_ptr(), lin.weight._version)
+    key = (lin.weight.data_ptr(), lin.weight._version, _lib.invalidate_epoch())
     hit = _split_t.get(lin)
     if hit is None or hit[0] != key:
         hit = (key, ops.SplitLinear(lin.weight.detach().t().contiguous(), None))
@@ -94,7 +94,7 @@ def _split_of(lin: nn.Linear, shift: torch.Tensor = None) -> ops.SplitLinear:
     added to every output row, e.g. the models' `placeholder`)."""
     b = lin.bias
     key = (lin.weight.data_ptr(), lin.weight._version, None if b is None else (b.data_ptr(), b._version),
-           None if shift is None else (shift.data_ptr(), shift._version))
+           None if shift is None else (shift.data_ptr(), shift._version), _lib.invalidate_epoch())
     hit = _split.get(lin)
     if hit is None or hit[0] != key:
         bias = b

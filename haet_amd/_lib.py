@@ -99,6 +99,48 @@ SIGNATURES = {
 
 _lib = None
 
+# --------------------------------------------------------------------------- cache generations
+# The modules cache weight-derived operands (bf16 planes, the packed Erwin blob) keyed on
+# (data_ptr, _version) of their parameters, and the LIST of those parameter objects to avoid walking the
+# module tree per forward.  A parameter or buffer OBJECT re-assigned by hand on any submodule goes through
+# nn.Module.register_parameter / __setattr__, which fire torch's global registration hooks: every such
+# event bumps this generation and the cached lists are re-walked at the next forward -- immediately, not
+# after N calls.  (In-place writes through `.data` bump neither `_version` nor this: call
+# `module.invalidate_caches()` after EMA swaps / manual clipping done that way.)
+_generation = [0]
+
+
+def _bump_generation(*_args):
+    _generation[0] += 1
+    return None
+
+
+def cache_generation() -> int:
+    return _generation[0]
+
+
+def invalidate_all_caches() -> None:
+    """Force every haet_amd module to re-derive its cached operands at its next forward."""
+    _generation[0] += 1
+    _invalidate_epoch[0] += 1
+
+
+_invalidate_epoch = [0]
+
+
+def invalidate_epoch() -> int:
+    return _invalidate_epoch[0]
+
+
+def _install_registration_hooks():
+    import torch.nn.modules.module as _m
+
+    _m.register_module_parameter_registration_hook(_bump_generation)
+    _m.register_module_buffer_registration_hook(_bump_generation)
+
+
+_install_registration_hooks()
+
 
 def load():
     """Load libhaet_hip.so (raises HaetError if it has not been built)."""

@@ -79,6 +79,16 @@ class ModelBase(nn.Module):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
 
+    def invalidate_caches(self):
+        """Re-derive every cached weight operand of the model (attention modules and the point-wise fast path) at
+        the next forward -- for in-place parameter writes through `.data` (see PhysicsAttentionBase.invalidate_caches)."""
+        from . import _lib
+
+        _lib.invalidate_all_caches()
+        for m in self.modules():
+            if m is not self and hasattr(m, "invalidate_caches"):
+                m.invalidate_caches()
+
     def unified_positions(self, x):
         raise NotImplementedError
 

@@ -16,7 +16,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from ... import ops
+from ... import _lib, ops
 from ..._lib import HaetError
 
 
@@ -143,18 +143,25 @@ class ErwinTransformer(nn.Module):
     def _pack_key(self):
         # Walking nn.Module.parameters()/buffers() costs ~0.1 ms per forward, so the tensor list is
         # cached.  The tensor OBJECTS only change through .to()/.cuda() (-> _apply), load_state_dict
-        # with assign=True (-> post hook, which also fires for an ancestor's load) or a parameter
-        # re-assigned by hand on a submodule (-> caught by the periodic re-walk).
+        # with assign=True (-> post hook, which also fires for an ancestor's load) or a parameter / buffer
+        # re-assigned by hand on a submodule (-> torch's global registration hooks bump
+        # _lib.cache_generation(), seen here at the very next forward).
         d = self.__dict__
         ts = d.get("_pack_tensors")
-        d["_pack_age"] = d.get("_pack_age", 0) + 1
-        if ts is None or d.get("_pack_stale", True) or d["_pack_age"] >= 256:
+        gen = _lib.cache_generation()
+        if ts is None or d.get("_pack_stale", True) or d.get("_pack_gen") != gen:
             ts = list(self.parameters()) + list(self.buffers())
-            d["_pack_tensors"], d["_pack_stale"], d["_pack_age"] = ts, False, 0
-        return tuple([(t.data_ptr(), t._version) for t in ts])
+            d["_pack_tensors"], d["_pack_stale"], d["_pack_gen"] = ts, False, gen
+        return tuple([(t.data_ptr(), t._version) for t in ts] + [(-1, _lib.invalidate_epoch())])
 
     def _mark_stale(self, *_):
         self.__dict__["_pack_stale"] = True
+
+    def invalidate_caches(self):
+        """Drop the packed weight blob (rebuilt at the next forward): needed after in-place writes through
+        `.data` (EMA swap, manual clipping), which change neither `_version` nor the storage pointer."""
+        self._packed = None
+        self._mark_stale()
 
     def _apply(self, fn, *args, **kwargs):
         self._mark_stale()

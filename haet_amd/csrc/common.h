@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 
@@ -22,6 +23,20 @@ inline int check_launch(const char* what) {
 }
 
 inline hipStream_t as_stream(haet_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is PER DEVICE: a process-wide "already set" flag skips the
+// call on a second device and the > 64 KiB launch fails there.  One bit per device ordinal, set atomically
+// (several host threads may launch at once).
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+    static int bit() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return d & 63;
+    }
+    bool done() const { return (mask.load(std::memory_order_acquire) >> bit()) & 1ull; }
+    void set() { mask.fetch_or(1ull << bit(), std::memory_order_release); }
+};
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

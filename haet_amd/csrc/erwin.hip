@@ -1015,12 +1015,13 @@ extern "C" int haet_erwin_fwd(const float* tokens, const float* pos, const int32
     const size_t bytes = (size_t)erwin_layout(*desc, Mp, &a, &w) * sizeof(float);
     if (bytes > 160 * 1024)
         return fail(HAET_E_RESOURCE, "erwin: one cloud needs %zu B of LDS (> 160 KiB)", bytes);
-    static thread_local size_t attr_set = 0;
-    if (bytes > 64 * 1024 && bytes > attr_set) {
+    static std::atomic<size_t> attr_set[64];  // per device ordinal (the attribute is per device)
+    std::atomic<size_t>& attr_dev = attr_set[PerDeviceOnce::bit()];
+    if (bytes > 64 * 1024 && bytes > attr_dev.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(erwin_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return fail(HAET_E_LAUNCH, "erwin: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = bytes;
+        attr_dev.store(bytes, std::memory_order_release);
     }
     ErwinDir dir;
     erwin_directory(*desc, Mp, &dir);

@@ -343,14 +343,14 @@ static bool wgrad_wave_split() {  // HAET_WGRAD_WAVE_SPLIT=1: the split-bf16 var
     return on;
 }
 static int x3_attr() {
-    static bool done = false;
-    if (!done) {
+    static PerDeviceOnce done;
+    if (!done.done()) {
         for (const void* k : {reinterpret_cast<const void*>(gemm_tn_x3_kernel<false>),
                               reinterpret_cast<const void*>(gemm_tn_x3_kernel<true>)}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileImgBytes);
             if (e != hipSuccess) return fail(HAET_E_LAUNCH, "linear_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
-        done = true;
+        done.set();
     }
     return HAET_OK;
 }
@@ -375,14 +375,14 @@ extern "C" int haet_linear_wgrad(const float* G, const float* X, int N, int O, i
     const int chunk = wgrad_chunk(N);
     dim3 grid((N + chunk - 1) / chunk, (O / 256) * (K / 256));
     const size_t lds = 2 * (size_t)kTileFloats * sizeof(float);  // 128 KB
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (!attr_set.done()) {
         for (const void* k : {reinterpret_cast<const void*>(gemm_tn_f32_kernel<false, false>),
                               reinterpret_cast<const void*>(gemm_tn_f32_kernel<false, true>)}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return fail(HAET_E_LAUNCH, "linear_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
-        attr_set = true;
+        attr_set.set();
     }
     if (wgrad_exact_f32())
         hipLaunchKernelGGL((gemm_tn_f32_kernel<false, false>), grid, dim3(512), lds, as_stream(stream), G, X, N, O, K,
@@ -409,14 +409,14 @@ extern "C" int haet_conv_wgrad_tap(const float* G, const float* X, int B, int gH
     const int N = (int)rows, chunk = wgrad_chunk(N);
     dim3 grid((N + chunk - 1) / chunk, (O / 256) * (Cin / 256));
     const size_t lds = 2 * (size_t)kTileFloats * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (!attr_set.done()) {
         for (const void* k : {reinterpret_cast<const void*>(gemm_tn_f32_kernel<true, false>),
                               reinterpret_cast<const void*>(gemm_tn_f32_kernel<true, true>)}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return fail(HAET_E_LAUNCH, "conv_wgrad_tap: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
-        attr_set = true;
+        attr_set.set();
     }
     if (wgrad_exact_f32())
         hipLaunchKernelGGL((gemm_tn_f32_kernel<true, false>), grid, dim3(512), lds, as_stream(stream), G, X, N, O, Cin,

@@ -216,7 +216,10 @@ def run_blocks(x, pos, rot, sd, pre, depth, heads, ball, rotate_on, trace, tag):
 
 
 def ball_pool(x, pos, sd, pre, stride, training):
-    """EF/components/pooling.py:25-40."""
+    """EF/components/pooling.py:25-40.  stride == 1: the node passes through unchanged
+    (no projection, no BatchNorm: pooling.py:26-27)."""
+    if stride == 1:
+        return x, pos
     d = pos.shape[1]
     centers = pos.view(-1, stride, d).mean(dim=1)
     rel = (pos.view(-1, stride, d) - centers[:, None]).reshape(-1, stride * d)
@@ -321,7 +324,10 @@ def physics_attention_forward(x: Tensor, sd: Dict[str, Tensor], cfg: AttnCfg,
     S = torch.einsum("bhnc,bhng->bhgc", x_proj, w)
     S = S / (norm + 1e-5)[:, :, :, None].repeat(1, 1, 1, C)
     flat = S.reshape(B * H * G, C)
-    pos = token_positions(flat, cfg.erwin.dimensionality)
+    # Positions carry no gradient: every use of them in the reference is under no_grad
+    # (attention.py:35 compute_rel_pos is @torch.no_grad; pooling.py:29,59 centres / rel_pos under
+    # torch.no_grad(); the tree build is no_grad too, erwin_flash.py:149).
+    pos = token_positions(flat, cfg.erwin.dimensionality).detach()
     batch_idx = torch.arange(B * H).repeat_interleave(G)
     etrace = {} if trace is not None else None
     flat2 = erwin_forward(flat, pos, batch_idx, sd, cfg.erwin, "erwin.", training, etrace)

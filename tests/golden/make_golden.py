@@ -195,10 +195,25 @@ ATTN_CASES = [
     ("irr_nonpow2_amp", "irregular", dict(dim=64, heads=4, dim_head=16, slice_num=12, rotate=45, ball_sizes=[16, 8]), 333, "amp", False),
     ("s2d_c1like_amp", "structured2d", dict(dim=64, heads=4, dim_head=16, slice_num=8, H=16, W=16, rotate=45), (16, 16), "amp", False),
     ("s3d_c5like_amp", "structured3d", dict(dim=64, heads=4, dim_head=16, slice_num=16, H=8, W=8, D=8, rotate=45), (8, 8, 8), "amp", False),
+    # round 2 -- stride-1 "no pooling" level (pooling.py:26-27): the pooled node IS the node, widths must agree
+    ("irr_stride1_amp", "irregular", dict(dim=64, heads=4, dim_head=16, slice_num=16, rotate=45, strides=[1],
+                                          c_hidden=[16, 16], ball_sizes=[16, 8]), 500, "amp", False),
+    ("irr_stride1_amp_train", "irregular", dict(dim=64, heads=4, dim_head=16, slice_num=16, rotate=45, strides=[1],
+                                                c_hidden=[16, 16], ball_sizes=[16, 8]), 450, "amp", True),
+    ("irr_b2_amp_train", "irregular", dict(dim=64, heads=4, dim_head=16, slice_num=16, rotate=45), 350, "amp", True),
+    ("irr_c3like_amp_train", "irregular", dict(dim=256, heads=8, dim_head=32, slice_num=64, rotate=45), 900, "amp", True),
+]
+
+# BASELINE configs C1 and C5 at their REAL widths (dim 256 -> 8 heads x 32: inside the HIP convolution's envelope),
+# C1 at its real grid, C5 on a grid the CPU can check.  "big" fixtures: inputs and the convolution weight are
+# int8 * 2^-k (exact in fp32, 1 byte per value in the file), per-point outputs are kept for a row sample only.
+BIG_CASES = [
+    ("c1_real", "structured2d", dict(dim=256, heads=8, dim_head=32, slice_num=8, H=64, W=64, rotate=45), (64, 64), 4096.0),
+    ("c5_real", "structured3d", dict(dim=256, heads=8, dim_head=32, slice_num=128, H=8, W=16, D=16, rotate=45), (8, 16, 16), 8192.0),
 ]
 
 
-def gen_attention_fixtures(models, tree_store):
+def gen_attention_fixtures(models, tree_store, only=None):
     from models.PhysicsAttention import (Physics_Attention_Irregular_Mesh,
                                          Physics_Attention_Structured_Mesh_2D,
                                          Physics_Attention_Structured_Mesh_3D)
@@ -207,6 +222,8 @@ def gen_attention_fixtures(models, tree_store):
             "structured2d": Physics_Attention_Structured_Mesh_2D,
             "structured3d": Physics_Attention_Structured_Mesh_3D}
     for ci, (name, kind, kw, n, weights, train) in enumerate(ATTN_CASES):
+        if only and ("attn_" + name) not in only:
+            continue
         torch.manual_seed(100 + ci)
         gen = torch.Generator().manual_seed(1000 + ci)
         mod = ctor[kind](**kw)
@@ -237,6 +254,84 @@ def gen_attention_fixtures(models, tree_store):
         path = os.path.join(HERE, f"attn_{name}.npz")
         np.savez_compressed(path, **arrays)
         print(f"{path}: {os.path.getsize(path)/1e6:.2f} MB  out_norm={cap['out'].norm():.4f}")
+
+
+def gen_big_fixtures(models, tree_store, only=None):
+    from models.PhysicsAttention import Physics_Attention_Structured_Mesh_2D, Physics_Attention_Structured_Mesh_3D
+
+    ctor = {"structured2d": Physics_Attention_Structured_Mesh_2D, "structured3d": Physics_Attention_Structured_Mesh_3D}
+    for ci, (name, kind, kw, grid, wscale) in enumerate(BIG_CASES):
+        if only and ("big_" + name) not in only:
+            continue
+        torch.manual_seed(300 + ci)
+        gen = torch.Generator().manual_seed(3000 + ci)
+        mod = ctor[kind](**kw)
+        amplify(mod, gen)
+        N = int(np.prod(grid))
+        xq = torch.clamp(torch.round(torch.randn(1, N, kw["dim"], generator=gen) * 32.0), -127, 127).to(torch.int8)
+        x = xq.float() / 32.0
+        with torch.no_grad():  # the convolution weight on an int8 grid (its bias and everything else stay fp32)
+            wq = torch.clamp(torch.round(mod.in_project_x.weight * wscale), -127, 127).to(torch.int8)
+            mod.in_project_x.weight.copy_(wq.float() / wscale)
+        mod.eval()
+        sd = {k: v.clone() for k, v in mod.state_dict().items()}
+        with torch.no_grad():
+            cap = run_attention(mod, x, tree_store)
+        meta = dict(kind=kind, kw=kw, grid=grid, train=False, B=1, N=N)
+        rows = torch.linspace(0, N - 1, 384).long()
+        arrays = {"x_i8": xq.numpy(), "x_scale": np.float32(32.0), "w_i8": wq.numpy(), "w_scale": np.float32(wscale),
+                  "rows": rows.numpy()}
+        arrays.update({"sd/" + k: v for k, v in to_np(sd).items() if k != "in_project_x.weight"})
+        arrays["exp/x_lin_rows"] = _xlin_rows(cap["x_lin_raw"], kind, 1, N).index_select(1, rows).numpy()
+        arrays["exp/out_rows"] = cap["out"].index_select(1, rows).numpy()
+        arrays["exp/out_norm"] = np.float64(cap["out"].double().norm())
+        for k, v in cap.items():
+            if k in ("x_lin_raw", "out"):
+                continue
+            arrays["exp/" + k] = v.numpy()
+        arrays["meta"] = np.frombuffer(repr(meta).encode(), dtype=np.uint8)
+        path = os.path.join(HERE, f"big_{name}.npz")
+        np.savez_compressed(path, **arrays)
+        print(f"{path}: {os.path.getsize(path)/1e6:.2f} MB  out_norm={cap['out'].norm():.4f}")
+
+
+GRAD_CASES = ["irr_small_amp", "irr_small_amp_train", "irr_b2_amp", "irr_b2_amp_train", "irr_norot_amp",
+              "s2d_c1like_amp", "s3d_c5like_amp", "irr_stride1_amp", "irr_stride1_amp_train", "irr_nonpow2_amp"]
+
+
+def gen_grad_fixtures(models, only=None):
+    """Gradients of the REFERENCE module (its own autograd) w.r.t. the input and every parameter for
+    loss = <out, gout>, on the inputs / weights of an existing attention fixture (read back from its .npz)."""
+    import ast
+
+    from models.PhysicsAttention import (Physics_Attention_Irregular_Mesh, Physics_Attention_Structured_Mesh_2D,
+                                         Physics_Attention_Structured_Mesh_3D)
+
+    ctor = {"irregular": Physics_Attention_Irregular_Mesh, "structured2d": Physics_Attention_Structured_Mesh_2D,
+            "structured3d": Physics_Attention_Structured_Mesh_3D}
+    for ci, name in enumerate(GRAD_CASES):
+        if only and ("grad_" + name) not in only:
+            continue
+        z = np.load(os.path.join(HERE, f"attn_{name}.npz"))
+        meta = ast.literal_eval(bytes(z["meta"]).decode())
+        mod = ctor[meta["kind"]](**meta["kw"])
+        mod.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")})
+        mod.train(meta["train"])
+        x = torch.from_numpy(z["x"].astype(np.float32)).requires_grad_(True)
+        gen = torch.Generator().manual_seed(4000 + ci)
+        gout = torch.randn(x.shape[0], x.shape[1], meta["kw"]["dim"], generator=gen).half().float()
+        out = mod(x)
+        assert np.allclose(out.detach().numpy(), z["exp/out"], rtol=0, atol=1e-5 * float(np.abs(z["exp/out"]).max()))
+        (out * gout).sum().backward()
+        arrays = {"gout": gout.half().numpy(), "gx": x.grad.numpy()}
+        for pn, p in mod.named_parameters():
+            if p.grad is not None:
+                arrays["g/" + pn] = p.grad.numpy()
+            else:
+                arrays["nograd/" + pn] = np.zeros(0, dtype=np.float32)
+        path = os.path.join(HERE, f"grad_{name}.npz")
+        np.savez_compressed(path, **arrays)
+        print(f"{path}: {os.path.getsize(path)/1e6:.2f} MB  |gx|={x.grad.norm():.4f}")
 
 
 def _xlin_rows(raw, kind, B, N):
@@ -322,9 +417,16 @@ def gen_tree_fixtures():
 
 
 if __name__ == "__main__":
+    # no arguments: regenerate everything; otherwise only the named fixture files (without .npz), e.g.
+    #   make_golden.py attn_irr_stride1_amp big_c1_real grad_irr_small_amp
+    # (an .npz is a zip: rewriting an unchanged fixture changes its bytes through the member timestamps)
+    only = set(sys.argv[1:])
     torch.set_num_threads(8)
     models = import_reference()
     store = capture_tree(models)
-    gen_tree_fixtures()
-    gen_attention_fixtures(models, store)
-    gen_model_fixtures(models)
+    if not only:
+        gen_tree_fixtures()
+        gen_model_fixtures(models)
+    gen_attention_fixtures(models, store, only)
+    gen_big_fixtures(models, store, only)
+    gen_grad_fixtures(models, only)

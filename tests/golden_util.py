@@ -18,6 +18,35 @@ def model_fixture_names():
     return sorted(os.path.basename(p)[6:-4] for p in glob.glob(os.path.join(GOLDEN, "model_*.npz")))
 
 
+def big_fixture_names():
+    return sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(GOLDEN, "big_*.npz")))
+
+
+def grad_fixture_names():
+    return sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN, "grad_*.npz")))
+
+
+def load_big(name):
+    """BASELINE configs C1 / C5 at their real widths: x and the convolution weight are int8 * 2^-k (exact in
+    fp32); per-point expectations (`x_lin_rows`, `out_rows`) cover the sampled `rows` only."""
+    z = np.load(os.path.join(GOLDEN, f"big_{name}.npz"))
+    meta = _meta(z)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    sd["in_project_x.weight"] = torch.from_numpy(z["w_i8"].astype(np.float32) / float(z["w_scale"]))
+    exp = {k[4:]: torch.from_numpy(np.asarray(z[k])) for k in z.files if k.startswith("exp/")}
+    x = torch.from_numpy(z["x_i8"].astype(np.float32) / float(z["x_scale"]))
+    return x, sd, meta, exp, torch.from_numpy(z["rows"])
+
+
+def load_grad(name):
+    """Gradients of the reference module for loss = <out, gout> on the inputs of attn_<name>.npz:
+    (gout, gx, {param: grad}, [params the reference gives no gradient])."""
+    z = np.load(os.path.join(GOLDEN, f"grad_{name}.npz"))
+    grads = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g/")}
+    nograd = [k[7:] for k in z.files if k.startswith("nograd/")]
+    return torch.from_numpy(z["gout"].astype(np.float32)), torch.from_numpy(z["gx"]), grads, nograd
+
+
 def _meta(z):
     return ast.literal_eval(bytes(z["meta"]).decode())
 

@@ -115,16 +115,21 @@ def test_weight_version_key_sees_every_kind_of_update():
     k3 = er._pack_key()
     assert k3 != k2
     m.float()
-    # a parameter re-assigned by hand on a submodule is caught by the periodic re-walk at the latest
+    # a parameter (or buffer) re-assigned by hand on a SUBMODULE is seen at the very next call: torch's global
+    # registration hooks bump the cache generation (haet_amd/_lib.py)
     er._pack_key()
     er.encoder[0].blocks[0].norm1.weight = torch.nn.Parameter(torch.ones(16))
     new_ptr = er.encoder[0].blocks[0].norm1.weight.data_ptr()
-    seen = False
-    for _ in range(300):
-        if any(p == new_ptr for p, _ in er._pack_key()):
-            seen = True
-            break
-    assert seen
+    assert any(p == new_ptr for p, _ in er._pack_key())
+    er.encoder[0].pool.norm.running_mean = torch.zeros(32) + 0.25
+    new_ptr = er.encoder[0].pool.norm.running_mean.data_ptr()
+    assert any(p == new_ptr for p, _ in er._pack_key())
+    # in-place writes through .data change neither _version nor the pointer: invalidate_caches() is the documented way
+    k4 = er._pack_key()
+    er.encoder[0].blocks[0].norm2.weight.data.mul_(2.0)
+    assert er._pack_key() == k4
+    m.invalidate_caches()
+    assert er._packed is None and m._slice_cache is None
 
 
 def test_grad_check_cache_follows_requires_grad():

@@ -95,3 +95,44 @@ def test_model_oracle_matches_reference(name):
     with torch.no_grad():
         out = O.model_forward(x, fx, sd, cfg, kw.get("n_layers", 5))
     assert O.rel_l2(out, ref_out) < 5 * TOL
+
+
+@pytest.mark.parametrize("name", G.big_fixture_names())
+def test_big_config_oracle_matches_reference(name):
+    """BASELINE configs C1 (2-D 64 x 64, M = 8) and C5's widths (3-D, M = 128) at dim 256 / 8 heads x 32."""
+    x, sd, meta, exp, rows = G.load_big(name)
+    cfg = G.oracle_cfg_from_meta(meta)
+    trace = {}
+    with torch.no_grad():
+        out = O.physics_attention_forward(x, sd, cfg, trace=trace)
+    for k in ("tree_idx", "tree_mask", "rot0", "rot1"):
+        assert torch.equal(trace["erwin." + k], exp["erwin." + k]), k
+    assert O.rel_l2(trace["x_lin"].index_select(1, rows), exp["x_lin_rows"]) < TOL
+    assert O.rel_l2(trace["eidetic"].reshape(exp["eidetic_flat"].shape), exp["eidetic_flat"]) < TOL
+    assert O.rel_l2(trace["processed"].reshape(exp["processed_flat"].shape), exp["processed_flat"]) < 5 * TOL
+    assert O.rel_l2(out.index_select(1, rows), exp["out_rows"]) < 5 * TOL
+    assert abs(float(out.double().norm()) / float(exp["out_norm"]) - 1.0) < 5 * TOL
+
+
+@pytest.mark.parametrize("name", G.grad_fixture_names())
+def test_oracle_gradients_match_reference_autograd(name):
+    """Autograd through the oracle against the REFERENCE module's own autograd (tests/golden/grad_*.npz): input
+    and every parameter.  Pins, among the rest, that token positions carry no gradient (attention.py:35,
+    pooling.py:29,59 are no_grad in the reference) and which parameters get none at all (sigma_att)."""
+    x, sd, meta, exp, rows = G.load_attn(name)
+    gout, gx_ref, g_ref, nograd = G.load_grad(name)
+    cfg = G.oracle_cfg_from_meta(meta)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+    full = dict(sd)
+    full.update(leaves)
+    xr = x.clone().requires_grad_(True)
+    out = O.physics_attention_forward(xr, full, cfg, training=meta["train"])
+    names = [k for k in leaves if k in g_ref]
+    got = torch.autograd.grad((out * gout).sum(), [xr] + [leaves[k] for k in names], allow_unused=True)
+    assert O.rel_l2(got[0], gx_ref) < 2e-4
+    scale = max(float(g.norm()) for g in g_ref.values())
+    for k, g in zip(names, got[1:]):
+        assert g is not None, k
+        err = float((g - g_ref[k]).norm()) / max(float(g_ref[k].norm()), 1e-4 * scale)
+        assert err < 5e-4, (k, err)
+    assert set(nograd) == {k for k in leaves if k not in g_ref}, nograd
