@@ -724,6 +724,16 @@ __device__ ERWIN_PHASE void erwin_pool(int l, const haet_erwin_desc& D,
     const int X0 = T(T_X + l), ld0 = T(T_LD + l), P0 = T(T_P + l), P1 = T(T_P + l + 1);
     const Img rows = {T(T_WIDE), img_stride(K), n2 * img_stride(K)};
     const Img none = {0, 0, 0};
+    if (st == 1) {  // "no pooling" (pooling.py:26-27): the node passes through, no projection, no BatchNorm
+        const int X1 = T(T_X + l + 1), ld1 = T(T_LD + l + 1);
+        for (int i = threadIdx.x; i < n2 * c; i += kErwinThreads) {
+            const int p = i / c, k = i % c;
+            F(X1 + 4 * (p * ld1 + k)) = F(X0 + 4 * (p * ld0 + k));
+        }
+        for (int i = threadIdx.x; i < n2 * d; i += kErwinThreads) F(P1 + 4 * i) = F(P0 + 4 * i);
+        __syncthreads();
+        return;
+    }
     stage_params(T(T_PAR), W + R.small_off, R.small_len);
     for (int i = threadIdx.x; i < n2 * d; i += kErwinThreads) {
         const int p = i / d, j = i % d;
@@ -975,6 +985,8 @@ static int erwin_validate(const haet_erwin_desc* D, int Mp) {
             const int st = D->pool[l].stride;
             if (st < 1 || n % st || D->unpool[l].stride != st)
                 return fail(HAET_E_ARG, "erwin: stride %d", st);
+            if (st == 1 && D->enc[l + 1].c != D->enc[l].c)  // the reference would fail in the next layer's Linear
+                return fail(HAET_E_ARG, "erwin: stride 1 (no pooling) needs equal widths %d / %d", D->enc[l].c, D->enc[l + 1].c);
             n /= st;
         }
     }

@@ -208,3 +208,32 @@ def test_convolution_weight_gradient_vs_fp64(B, grid, k, hip_device):
     assert dW.shape == gW.shape
     assert float((dW.cpu().double() - gW).norm() / gW.norm()) < 2e-5
     assert float((db.cpu().double() - gb).norm() / gb.norm()) < 2e-6
+
+
+@pytest.mark.parametrize("name", __import__("tests.golden_util", fromlist=["x"]).grad_fixture_names())
+def test_module_gradients_vs_reference_fixture(name, hip_device):
+    """The HIP autograd node against the REFERENCE module's own autograd (tests/golden/grad_*.npz, made by
+    make_golden.py from the imported reference): input gradient and every parameter gradient, eval and train mode,
+    rotated / unrotated / stride-1 / non-power-of-two trees, 2-D and 3-D.  In particular no gradient flows through the
+    token positions (attention.py:35, pooling.py:29,59 are no_grad in the reference)."""
+    from tests import golden_util as G
+    from tests.test_modules_cpu import CTOR
+
+    x, sd, meta, exp, rows = G.load_attn(name)
+    gout, gx_ref, g_ref, nograd = G.load_grad(name)
+    mod = CTOR[meta["kind"]](**meta["kw"])
+    mod.load_state_dict(sd)
+    mod = mod.to(hip_device).train(meta["train"])
+    xr = x.to(hip_device).requires_grad_(True)
+    out = mod(xr)
+    assert O.rel_l2(out.detach().cpu(), exp["out"]) < 1e-4
+    (out * gout.to(hip_device)).sum().backward()
+    assert O.rel_l2(xr.grad.cpu(), gx_ref) < 2e-3
+    scale = max(float(g.norm()) for g in g_ref.values())
+    for pn, p in mod.named_parameters():
+        if pn in g_ref:
+            assert p.grad is not None, pn
+            err = float((p.grad.cpu() - g_ref[pn]).norm()) / max(float(g_ref[pn].norm()), 1e-3 * scale)
+            assert err < 5e-3, (pn, err)
+        else:
+            assert pn in nograd and (p.grad is None or float(p.grad.abs().max()) == 0.0), pn

@@ -650,3 +650,147 @@ def test_reduced_precision_inputs_under_autocast(dtype, hip_device):
     assert y.dtype == dtype
     assert O.rel_l2(y.float().cpu(), y32.cpu()) < 1e-2       # only the final rounding to `dtype`
     assert O.rel_l2(y32.cpu(), ref.cpu()) < 5e-2              # input rounding
+
+
+# --------------------------------------------------------------------------- BASELINE configs C1 / C5 at their real widths
+@pytest.mark.parametrize("name", G.big_fixture_names())
+def test_big_config_end_to_end(name, hip_device):
+    """C1 (Physics_Attention_Structured_Mesh_2D, 64 x 64 grid, dim 256 -> 8 x 32, M = 8: the generic slice kernels)
+    and C5's widths (Structured_Mesh_3D, dim 256 -> 8 x 32, M = 128, on an 8 x 16 x 16 grid the CPU can check)
+    end to end against the REFERENCE's outputs.  The channel counts are inside the HIP convolution's envelope, so
+    haet_conv_project_fwd is what runs (asserted), not MIOpen."""
+    from haet_amd import ops
+
+    x, sd, meta, exp, rows = G.load_big(name)
+    cfg = G.oracle_cfg_from_meta(meta)
+    mod = _hip_module(meta, sd, hip_device)
+    conv = mod.in_project_x
+    assert ops.conv_project_supported(conv.in_channels, conv.out_channels)
+    calls = []
+    orig = ops.conv_project
+    ops.conv_project = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            out, inter = mod(x.to(hip_device), return_intermediates=True)
+    finally:
+        ops.conv_project = orig
+    assert calls, "the HIP implicit-GEMM convolution did not run"
+    assert O.rel_l2(inter["x_lin"].cpu().index_select(1, rows), exp["x_lin_rows"]) < FP32_TOL
+    assert O.rel_l2(inter["eidetic"].cpu(), exp["eidetic_flat"]) < FP32_TOL
+    assert torch.allclose(inter["pos"].cpu(), exp["pos"], atol=1e-4)
+    assert O.rel_l2(inter["processed"].cpu(), exp["processed_flat"]) < 10 * FP32_TOL
+    err = O.rel_l2(out.cpu().index_select(1, rows), exp["out_rows"])
+    assert err < NORTH_STAR_TOL and err < 10 * FP32_TOL, err
+    assert abs(float(out.double().norm()) / float(exp["out_norm"]) - 1.0) < 10 * FP32_TOL
+
+
+def _conv_rows_fp64(x, weight, bias, grid, rows):
+    """Rows `rows` of the same-padded stride-1 convolution over the channels-last grid, gathered tap by tap in fp64."""
+    nd = len(grid)
+    k = weight.shape[2]
+    w = weight.double()
+    out = bias.double()[None, :].repeat(len(rows), 1)
+    strides = [1] * nd
+    for i in range(nd - 2, -1, -1):
+        strides[i] = strides[i + 1] * grid[i + 1]
+    coords = []
+    r = rows.clone()
+    for i in range(nd):
+        coords.append(r // strides[i])
+        r = r % strides[i]
+    import itertools
+
+    for tap in itertools.product(range(k), repeat=nd):
+        nb = [coords[i] + tap[i] - k // 2 for i in range(nd)]
+        ok = torch.ones(len(rows), dtype=torch.bool)
+        idx = torch.zeros(len(rows), dtype=torch.long)
+        for i in range(nd):
+            ok &= (nb[i] >= 0) & (nb[i] < grid[i])
+            idx += nb[i].clamp(0, grid[i] - 1) * strides[i]
+        xv = x[0].index_select(0, idx.to(x.device)).cpu().double() * ok[:, None]
+        wt = w[(slice(None), slice(None)) + tap]  # [O, Cin]
+        out += xv @ wt.t()
+    return out
+
+
+def test_c5_slab_full_size_properties(hip_device):
+    """BASELINE config C5, ONE rank's share at full size: a 32 x 256 x 256 slab (2 097 152 points), dim 256 -> 8 x 32,
+    M = 128.  Size-independent checks: the convolution against an fp64 tap-by-tap gather at sampled points (faces,
+    edges, interior), sum_n w[n, g] = 1 through the de-slice of an all-ones S', the module's output rows against
+    their own intermediates in fp64."""
+    from haet_amd import ops
+    from haet_amd.PhysicsAttention import Physics_Attention_Structured_Mesh_3D
+
+    torch.manual_seed(5)
+    grid = (32, 256, 256)
+    N = grid[0] * grid[1] * grid[2]
+    mod = Physics_Attention_Structured_Mesh_3D(dim=256, heads=8, dim_head=32, slice_num=128, H=grid[0], W=grid[1],
+                                               D=grid[2], rotate=45).eval().to(hip_device)
+    x = torch.randn(1, N, 256, device=hip_device)
+    with torch.no_grad():
+        out, inter = mod(x, return_intermediates=True)
+    assert torch.isfinite(out).all()
+    g = torch.Generator().manual_seed(0)
+    rows = torch.cat([torch.tensor([0, 255, 256 * 256 - 1, N - 1, N - 256, 31 * 65536, 17 * 65536 + 255 * 256]),
+                      torch.randint(0, N, (57,), generator=g)])
+    conv = mod.in_project_x
+    ref = _conv_rows_fp64(x, conv.weight.detach().cpu(), conv.bias.detach().cpu(), grid, rows)
+    assert O.rel_l2(inter["x_lin"][0].index_select(0, rows.to(hip_device)).cpu(), ref) < FP32_TOL
+    # rows of out_x and out from the intermediates, fp64
+    H, C, M = 8, 32, 128
+    sd = {k: v.detach().cpu().double() for k, v in mod.state_dict().items()}
+    xl = inter["x_lin"][0].index_select(0, rows.to(hip_device)).cpu().double().reshape(-1, H, C)
+    tau = 0.5 + (xl @ sd["ada_temp_linear.weight"][0] + sd["ada_temp_linear.bias"]).clamp(-0.4, 0.4)
+    c0 = float(torch.log(-torch.log(torch.tensor(1e-6))))
+    z = (xl @ sd["in_project_slice.weight"].t() + sd["in_project_slice.bias"] - c0) / tau[..., None]   # [r, H, M]
+    w = torch.exp(z - inter["col_max"].cpu().double().reshape(1, H, M)) / inter["col_sum"].cpu().double().reshape(1, H, M)
+    ox = torch.einsum("rhg,hgc->rhc", w, inter["processed"].cpu().double().reshape(H, M, C)).reshape(-1, H * C)
+    assert O.rel_l2(inter["out_x"][0].index_select(0, rows.to(hip_device)).cpu(), ox) < 5 * FP32_TOL
+    o = ox @ sd["to_out.0.weight"].t() + sd["to_out.0.bias"]
+    assert O.rel_l2(out[0].index_select(0, rows.to(hip_device)).cpu(), o) < 5 * FP32_TOL
+    # sum over the points of every slice weight = 1
+    sp = mod._slice_params()
+    ones = torch.ones(H * M, C, device=hip_device)
+    out1 = ops.deslice(inter["x_lin"], sp, inter["col_max"], inter["col_sum"], ones, H, C, M)
+    assert torch.allclose(out1.double().sum(dim=1), torch.full((1, H * C), float(M), dtype=torch.float64, device=hip_device), rtol=2e-4)
+
+
+def test_more_than_2_31_elements_per_tensor(hip_device):
+    """Every per-point tensor of this run has more than 2^31 elements (8.6M points x 256 channels = 2.2e9; C5 on ONE
+    GPU would be 4.3e9): rows beyond the 2^31-element offset are checked against fp64 restatements of each stage
+    from the module's own intermediates, and the slice weights must still sum to one over all points."""
+    from haet_amd import ops
+    from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh
+
+    torch.manual_seed(9)
+    N, H, C, M = 8_600_000, 8, 32, 64
+    assert N * H * C > 2 ** 31
+    mod = Physics_Attention_Irregular_Mesh(dim=256, heads=H, dim_head=C, slice_num=M, rotate=45).eval().to(hip_device)
+    x = torch.randn(1, N, 256, device=hip_device)
+    with torch.no_grad():
+        out, inter = mod(x, return_intermediates=True)
+    g = torch.Generator().manual_seed(1)
+    rows = torch.cat([torch.tensor([0, N - 1, 2 ** 31 // 256 - 1, 2 ** 31 // 256, 2 ** 31 // 256 + 1]),
+                      torch.randint(2 ** 31 // 256, N, (40,), generator=g), torch.randint(0, N, (19,), generator=g)])
+    rd = rows.to(hip_device)
+    sd = {k: v.detach().cpu().double() for k, v in mod.state_dict().items()}
+    xr = x[0].index_select(0, rd).cpu().double()
+    xl_ref = xr @ sd["in_project_x.weight"].t() + sd["in_project_x.bias"]
+    assert O.rel_l2(inter["x_lin"][0].index_select(0, rd).cpu(), xl_ref) < FP32_TOL
+    xl = xl_ref.reshape(-1, H, C)
+    tau = 0.5 + (xl @ sd["ada_temp_linear.weight"][0] + sd["ada_temp_linear.bias"]).clamp(-0.4, 0.4)
+    c0 = float(torch.log(-torch.log(torch.tensor(1e-6))))
+    z = (xl @ sd["in_project_slice.weight"].t() + sd["in_project_slice.bias"] - c0) / tau[..., None]
+    w = torch.exp(z - inter["col_max"].cpu().double().reshape(1, H, M)) / inter["col_sum"].cpu().double().reshape(1, H, M)
+    ox = torch.einsum("rhg,hgc->rhc", w, inter["processed"].cpu().double().reshape(H, M, C)).reshape(-1, H * C)
+    assert O.rel_l2(inter["out_x"][0].index_select(0, rd).cpu(), ox) < 5 * FP32_TOL
+    o = ox @ sd["to_out.0.weight"].t() + sd["to_out.0.bias"]
+    assert O.rel_l2(out[0].index_select(0, rd).cpu(), o) < 5 * FP32_TOL
+    del out, x
+    sp = mod._slice_params()
+    ones = torch.ones(H * M, C, device=hip_device)
+    out1 = ops.deslice(inter["x_lin"], sp, inter["col_max"], inter["col_sum"], ones, H, C, M)
+    tot = torch.zeros(1, H * C, dtype=torch.float64, device=hip_device)
+    for a in range(0, N, 1_000_000):  # chunked: a float64 copy of the whole tensor is 17 GB
+        tot += out1[:, a:a + 1_000_000].double().sum(dim=1)
+    assert torch.allclose(tot, torch.full_like(tot, float(M)), rtol=2e-4)
