@@ -235,7 +235,7 @@ class PhysicsAttentionBase(nn.Module):
             raise HaetError("Physics_Attention_* (haet_amd) runs on a ROCm device only; move the module "
                             "and its input with .cuda() -- there is no CPU fallback")
         wants_grad = torch.is_grad_enabled() and (x.requires_grad or self._any_requires_grad())
-        if self.training or wants_grad:
+        if wants_grad:
             # One autograd node whose N-scaled work is on the HIP kernels in both directions; only the
             # Erwin stage (B*H*M tokens) differentiates through a torch restatement -- haet_amd/_autograd.py.
             from .. import _autograd
@@ -248,6 +248,8 @@ class PhysicsAttentionBase(nn.Module):
                 return _autograd.HipForwardTorchBackward.apply(self, x, *self.parameters())
             y = _autograd.PhysicsAttentionFunction.apply(self, x, *self.parameters())
             return self.to_out[1](y).to(x.dtype)
+        # no gradient wanted (inference; validation passes under no_grad, also in .train() mode: the Erwin kernel
+        # then runs BatchNorm on batch statistics and updates the running ones, like the reference)
         return self._forward_hip(x, return_intermediates, pre_norm)
 
     def project_torch(self, x: torch.Tensor) -> torch.Tensor:

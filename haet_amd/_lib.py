@@ -34,13 +34,21 @@ class ErwinLayer(ctypes.Structure):
 
 class ErwinResample(ctypes.Structure):
     _fields_ = [("stride", c_int32), ("w", c_int32), ("b", c_int32),
-                ("bn_scale", c_int32), ("bn_shift", c_int32), ("small_off", c_int32), ("small_len", c_int32)]
+                ("bn_scale", c_int32), ("bn_shift", c_int32), ("small_off", c_int32), ("small_len", c_int32),
+                ("bn_eps", c_float), ("bn_momentum", c_float)]
 
 
 class ErwinDesc(ctypes.Structure):
     _fields_ = [("n_levels", c_int32), ("d", c_int32), ("rotate", c_int32), ("decode", c_int32),
-                ("enc", ErwinLayer * MAX_LEVELS), ("dec", ErwinLayer * MAX_LEVELS),
+                ("bn_train", c_int32), ("enc", ErwinLayer * MAX_LEVELS), ("dec", ErwinLayer * MAX_LEVELS),
                 ("pool", ErwinResample * MAX_LEVELS), ("unpool", ErwinResample * MAX_LEVELS)]
+
+
+class ErwinTrain(ctypes.Structure):
+    """haet_erwin_train (include/haet_hip.h): device pointers of the train-mode BatchNorm state."""
+    _fields_ = [("running_mean", c_void_p * (2 * MAX_LEVELS)), ("running_var", c_void_p * (2 * MAX_LEVELS)),
+                ("num_batches_tracked", c_void_p * (2 * MAX_LEVELS)), ("batch_stats", c_void_p),
+                ("workspace", c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/haet_hip.h declares
@@ -92,7 +100,11 @@ SIGNATURES = {
     "haet_linear_narrow_supported": (c_int, [c_int, c_int]),
     "haet_linear_narrow_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "haet_erwin_lds_bytes": (c_size_t, [POINTER(ErwinDesc), c_int]),
-    "haet_erwin_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, POINTER(ErwinDesc), c_int, c_int, _P, _P]),
+    "haet_erwin_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, POINTER(ErwinDesc), POINTER(ErwinTrain), c_int, c_int, _P, _P]),
+    "haet_erwin_train_workspace_bytes": (c_size_t, [POINTER(ErwinDesc), c_int]),
+    "haet_token_stage_supported": (c_int, [POINTER(ErwinDesc), c_int, c_int]),
+    "haet_token_stage_fwd": (c_int, [_P, c_int, c_int, c_float, _P, c_size_t, POINTER(ErwinDesc), POINTER(ErwinTrain),
+                                     _P, _P, _P, _P, _P, _P]),
     "haet_deslice_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P]
                          + [c_int] * 5 + [_P, _P]),
 }
@@ -155,8 +167,8 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
             fn.restype, fn.argtypes = res, args
-        if lib.haet_abi_version() != 3:
-            raise HaetError(f"libhaet_hip.so ABI {lib.haet_abi_version()} != 3")
+        if lib.haet_abi_version() != 4:
+            raise HaetError(f"libhaet_hip.so ABI {lib.haet_abi_version()} != 4")
         _lib = lib
     return _lib
 

@@ -11,6 +11,7 @@ uses is supported (embed=False, mp_steps=0, decode=True).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -186,10 +187,6 @@ class ErwinTransformer(nn.Module):
         tokens (IrregularMesh.py:204-209), computed inside the tree launch; kept in `last_positions`."""
         if not self.decode:
             raise NotImplementedError("decode=False is outside the PhysicsAttention hot path")
-        if self.training:
-            raise NotImplementedError(
-                "train-mode BatchNorm (batch statistics over all clouds) is not implemented in the "
-                "HIP Erwin kernel yet; call .eval()")
         T = node_features.shape[0]
         if n_clouds is None:
             if batch_idx is None:
@@ -199,6 +196,14 @@ class ErwinTransformer(nn.Module):
             raise HaetError("the HIP Erwin stage needs equally sized clouds")
         M = T // n_clouds
         blob, desc = self.packed()
+        train = None
+        if self.training:  # BatchNorm batch statistics over all clouds + running-stat update, inside the kernel
+            train = self._train_state(desc, n_clouds, node_features.device)
+        if node_positions is None and not os.environ.get("HAET_NO_TOKEN_STAGE") and ops.token_stage_supported(desc, n_clouds, M):
+            out, node_positions = ops.token_stage(node_features, blob, desc, n_clouds, M, self.dimensionality,
+                                                  self.strides, float(self.rotate), train)
+            self.__dict__["last_positions"] = node_positions
+            return out
         if node_positions is None:
             tree_idx, tree_mask, rot, _, node_positions = ops.balltree_build(
                 None, n_clouds, M, self.strides, self.ball_sizes, float(self.rotate),
@@ -207,4 +212,14 @@ class ErwinTransformer(nn.Module):
             tree_idx, tree_mask, rot, _ = ops.balltree_build(
                 node_positions, n_clouds, M, self.strides, self.ball_sizes, float(self.rotate))
         self.__dict__["last_positions"] = node_positions
-        return ops.erwin_fwd(node_features, node_positions, tree_idx, tree_mask, rot, blob, desc, n_clouds, M)
+        return ops.erwin_fwd(node_features, node_positions, tree_idx, tree_mask, rot, blob, desc, n_clouds, M, train)
+
+    def _train_state(self, desc, n_clouds, device):
+        """ops.ErwinTrainState for this (weights object set, cloud count): pointers to the BatchNorm running
+        statistics (updated in place by the kernel), batch-statistics output, grid-barrier workspace."""
+        key = (n_clouds, str(device), tuple(b.data_ptr() for b in self.buffers()))
+        hit = self.__dict__.get("_train_cache")
+        if hit is None or hit[0] != key:
+            hit = (key, ops.ErwinTrainState(self, desc, n_clouds, device))
+            self.__dict__["_train_cache"] = hit
+        return hit[1]

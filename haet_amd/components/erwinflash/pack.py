@@ -8,7 +8,9 @@ Blob = [ copy of the descriptor | tensors ], offsets in floats from the blob sta
   give fp32-class accuracy).
 * pe_proj (2/3 inputs) stays fp32, transposed [d][c]; biases / norm weights fp32.
 * eval-mode BatchNorm1d is folded to y*scale + shift (scale = gamma / sqrt(running_var + eps),
-  shift = beta - running_mean * scale; models/components/erwinflash/components/pooling.py:23,38,56,68).
+  shift = beta - running_mean * scale; models/components/erwinflash/components/pooling.py:23,38,56,68);
+  in train mode (desc.bn_train) the same two slots carry gamma and beta and the kernel computes the batch
+  statistics over all clouds itself.
 """
 from __future__ import annotations
 
@@ -92,13 +94,19 @@ def _fill_layer(dst, layer, blob):
         w.w3_w = blob.planes(blk.swiglu.w3)
 
 
-def _fill_resample(dst, mod, blob):
+def _fill_resample(dst, mod, blob, train):
     dst.stride = mod.stride
     bn = mod.norm
-    scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+    dst.bn_eps = float(bn.eps)
+    dst.bn_momentum = float(bn.momentum) if bn.momentum is not None else 0.0
     dst.b = blob.add(mod.proj.bias.detach().float())
-    dst.bn_scale = blob.add(scale)
-    dst.bn_shift = blob.add(bn.bias.detach().float() - bn.running_mean.float() * scale)
+    if train:  # batch statistics: the kernel needs gamma / beta themselves (haet_erwin_train carries the running stats)
+        dst.bn_scale = blob.add(bn.weight.detach().float())
+        dst.bn_shift = blob.add(bn.bias.detach().float())
+    else:
+        scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+        dst.bn_scale = blob.add(scale)
+        dst.bn_shift = blob.add(bn.bias.detach().float() - bn.running_mean.float() * scale)
     dst.small_off, dst.small_len = blob.end_group(dst.b)
     dst.w = blob.planes(mod.proj)
 
@@ -111,13 +119,15 @@ def pack_erwin(erwin):
     desc, blob = ErwinDesc(), _Blob(device)
     desc.n_levels, desc.d = n_levels, erwin.dimensionality
     desc.rotate, desc.decode = int(erwin.rotate > 0), int(bool(erwin.decode))
+    train = bool(erwin.training)
+    desc.bn_train = int(train)
     for i, layer in enumerate(erwin.encoder):
         _fill_layer(desc.enc[i], layer, blob)
-        _fill_resample(desc.pool[i], layer.pool, blob)
+        _fill_resample(desc.pool[i], layer.pool, blob, train)
     _fill_layer(desc.enc[n_levels - 1], erwin.bottleneck, blob)
     # decoder[k] runs at level n_levels-2-k (erwin_flash.py:108-123)
     for k, layer in enumerate(erwin.decoder):
         lvl = n_levels - 2 - k
         _fill_layer(desc.dec[lvl], layer, blob)
-        _fill_resample(desc.unpool[lvl], layer.unpool, blob)
+        _fill_resample(desc.unpool[lvl], layer.unpool, blob, train)
     return blob.tensor(desc), desc

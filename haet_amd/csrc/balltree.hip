@@ -268,6 +268,20 @@ int balltree_wave_launch(const float* pos, int n_clouds, int M, int d, int n_lev
                          uint8_t* tree_mask, int32_t* rot, hipStream_t stream, const float* S, int C,
                          float* pos_out);
 
+// generate_rotation_matrix (balltree.pyx:576-596): python doubles -> fp32 tensor
+void rotation_matrix_f32(float angle_deg, int d, float* r) {
+    const double a = (double)angle_deg * (3.14159265358979323846 / 180.0);  // math.radians
+    const double c = cos(a), s = sin(a);
+    if (d == 2) {
+        const double m[4] = {c, -s, s, c};
+        for (int i = 0; i < 4; ++i) r[i] = (float)m[i];
+    } else {
+        const double m[9] = {c * c, s * c * (s - 1), s * (s + c * c), s * c, s * s * s + c * c,
+                             s * c * (s - 1), -s, s * c, c * c};
+        for (int i = 0; i < 9; ++i) r[i] = (float)m[i];
+    }
+}
+
 }  // namespace haet
 
 using namespace haet;
@@ -302,18 +316,8 @@ static int balltree_build_impl(const float* pos, int n_clouds, int M, int d, int
             }
         }
     }
-    // generate_rotation_matrix (balltree.pyx:576-596): python doubles -> fp32 tensor
     Rot3 R = {};
-    const double a = (double)angle_deg * (3.14159265358979323846 / 180.0);  // math.radians
-    const double c = cos(a), s = sin(a);
-    if (d == 2) {
-        const double m[4] = {c, -s, s, c};
-        for (int i = 0; i < 4; ++i) R.r[i] = (float)m[i];
-    } else {
-        const double m[9] = {c * c, s * c * (s - 1), s * (s + c * c), s * c, s * s * s + c * c,
-                             s * c * (s - 1), -s, s * c, c * c};
-        for (int i = 0; i < 9; ++i) R.r[i] = (float)m[i];
-    }
+    rotation_matrix_f32(angle_deg, d, R.r);
     const char* force_lds = getenv("HAET_TREE_LDS");
     if (!(force_lds && force_lds[0] == '1') && balltree_wave_ok(M, n_levels, st))
         return balltree_wave_launch(pos, n_clouds, M, d, n_levels, st, tg, rotate, R.r, tree_idx,

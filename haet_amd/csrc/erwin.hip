@@ -18,6 +18,7 @@
 // conversion work; the weight loads of the next two (tile, k-step) items are in flight while
 // the current one is multiplied.
 #include "common.h"
+#include "balltree_wave_dev.h"
 
 namespace haet {
 
@@ -54,6 +55,7 @@ __device__ __forceinline__ unsigned short bf16_rne(float a) {
 // in structs / arrays / passed to non-inlined routines) make hipcc emit flat_load/flat_store, and a
 // flat access must wait vmcnt(0) AND lgkmcnt(0): the first version of this kernel had 1038 flat
 // and 4 ds instructions and every phase ran at one memory latency per access.
+// (declared in balltree_wave_dev.h as well: one dynamic LDS array for the whole kernel)
 extern __shared__ __attribute__((aligned(16))) char smem[];
 // Arguments of a non-inlined routine arrive in VGPRs, i.e. "divergent" to the compiler: every
 // `if (mode == ...)` becomes an exec-mask dance and every address a vector computation.  The
@@ -117,7 +119,7 @@ __host__ __device__ inline int img_stride(int K) { return round32(K) * 2 + kImgP
 // LDS directory, itself in LDS (ints at smem[0..]): per level l the BYTE offsets of X_l, P_l,
 // rot_l and n_l, ld_l (floats); then the shared regions.
 constexpr int T_X = 0, T_P = 4, T_ROT = 8, T_N = 12, T_LD = 16;  // + level
-constexpr int T_IA = 20, T_WIDE = 21, T_REL = 22, T_PAR = 23, T_IDENT = 24, T_WORDS = 32;
+constexpr int T_IA = 20, T_WIDE = 21, T_REL = 22, T_PAR = 23, T_IDENT = 24, T_TREE = 25, T_BN = 26, T_WORDS = 32;
 __device__ __forceinline__ int T(int i) { return __builtin_amdgcn_readfirstlane(I(4 * i)); }
 
 // copy `len` floats (16-B aligned, multiple of 4) of small parameters into LDS
@@ -288,7 +290,7 @@ __device__ ERWIN_PHASE void linear_core_t(
                 }
                 if (mode == EP_QKV || mode == EP_RESID || mode == EP_BN) {
                     const int row = dst + 4 * (t * ldd + o0);
-                    if (mode == EP_BN) {
+                    if (mode == EP_BN && sc >= 0) {  // (sc < 0: train-mode BatchNorm, applied by bn_train_phase)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             v[r] = v[r] * F(sc + 4 * min(o0 + r, O - 1)) + F(sh + 4 * min(o0 + r, O - 1));
@@ -323,7 +325,7 @@ __device__ ERWIN_PHASE void linear_core_t(
                         if (o < O) {
                             const int q = o / aux, ch = o - q * aux;  // 'n (m d) -> (n m) d'
                             float& y = F(dst + 4 * ((t * st + q) * ldd + ch));
-                            y = (y + v[r]) * F(sc + 4 * ch) + F(sh + 4 * ch);
+                            y = sc >= 0 ? (y + v[r]) * F(sc + 4 * ch) + F(sh + 4 * ch) : y + v[r];
                         }
                     }
                 }
@@ -716,9 +718,109 @@ __device__ ERWIN_PHASE void erwin_block(int lvl, const haet_erwin_layer& L,
     BSTAMP(24);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Train-mode BatchNorm1d of BallPooling / BallUnpooling (pooling.py:23,38,56,68): the statistics run over the
+// tokens of ALL clouds, i.e. over all workgroups of the launch.  Every workgroup reduces its own tokens to a
+// per-channel (mean, M2) pair, publishes it, the workgroups meet at a grid barrier, and each combines all pairs
+// itself (Chan's formula with equal counts: no cancellation, same result on every workgroup).  The launch has
+// one workgroup per cloud and at most one per CU (checked on the host), so all of them are resident.
+struct ErwinTrain {
+    float* rmean[2 * HAET_ERWIN_MAX_LEVELS];  // [2l] pool l, [2l+1] unpool l: running statistics, updated in place
+    float* rvar[2 * HAET_ERWIN_MAX_LEVELS];
+    long long* nbt[2 * HAET_ERWIN_MAX_LEVELS];
+    float* stats;     // out [2*MAX_LEVELS][2][cmax]: batch mean, 1/sqrt(var + eps) (nullptr: not wanted)
+    unsigned* bar;    // grid-barrier counter (zeroed by the launch function before every launch)
+    unsigned* tmo;    // set to 1 if a barrier gave up (bounded spin)
+    float* partial;   // [2*MAX_LEVELS][n_clouds][2][cmax]
+    int cmax, on;
+};
+
+// Counter barrier over the workgroups of the launch (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md
+// 'barrier-counter'): every storing wave drains its stores, the workgroup meets, ONE lane releases at agent scope,
+// arrives, polls relaxed (bounded), acquires at agent scope; the workgroup barrier after it holds the other waves
+// until the invalidate has completed.
+__device__ __attribute__((noinline)) void erwin_grid_barrier(unsigned* counter, unsigned target, unsigned* tmo) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 22)) {  // ~1 s: a workgroup is not resident -- give up rather than hang the GPU
+                __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+// X [n][ld] (LDS, fp32) holds the pre-BatchNorm values of this cloud; normalised in place with the batch
+// statistics of all clouds.  gamma / beta: LDS byte offsets of the affine parameters.
+__device__ __attribute__((noinline)) void bn_train_phase(int X, int ld, int n, int c, int gamma, int beta, float eps,
+                                                         float momentum, int slot, const ErwinTrain& tr, int cloud,
+                                                         int n_clouds, int epoch) {
+    X = U(X), ld = U(ld), n = U(n), c = U(c), gamma = U(gamma), beta = U(beta), slot = U(slot);
+    const int bn = T(T_BN), cmax = tr.cmax, cmp = (cmax + 3) & ~3;
+    float* part = tr.partial + ((size_t)slot * n_clouds + cloud) * 2 * cmax;
+    const int ch = threadIdx.x;
+    if (ch < c) {
+        float sum = 0.f;
+        for (int t = 0; t < n; ++t) sum += F(X + 4 * (t * ld + ch));
+        const float mean = sum / (float)n;
+        float m2 = 0.f;
+        for (int t = 0; t < n; ++t) {
+            const float dlt = F(X + 4 * (t * ld + ch)) - mean;
+            m2 = fmaf(dlt, dlt, m2);
+        }
+        part[ch] = mean;
+        part[cmax + ch] = m2;
+    }
+    erwin_grid_barrier(tr.bar, (unsigned)n_clouds * (unsigned)(epoch + 1), tr.tmo);
+    if (ch < c) {
+        const float* all = tr.partial + (size_t)slot * n_clouds * 2 * cmax;
+        float msum = 0.f;
+        for (int k = 0; k < n_clouds; ++k) msum += all[(size_t)k * 2 * cmax + ch];
+        const float mean = msum / (float)n_clouds;
+        float m2 = 0.f;
+        for (int k = 0; k < n_clouds; ++k) {
+            const float dk = all[(size_t)k * 2 * cmax + ch] - mean;
+            m2 += all[(size_t)k * 2 * cmax + cmax + ch] + (float)n * dk * dk;
+        }
+        const float cnt = (float)n * (float)n_clouds;
+        const float var = m2 / cnt, invstd = 1.0f / sqrtf(var + eps);
+        const float sc = F(gamma + 4 * ch) * invstd;
+        F(bn + 4 * ch) = sc;
+        F(bn + 4 * (cmp + ch)) = F(beta + 4 * ch) - mean * sc;
+        if (cloud == 0) {
+            if (tr.stats) {
+                tr.stats[(size_t)slot * 2 * cmax + ch] = mean;
+                tr.stats[(size_t)slot * 2 * cmax + cmax + ch] = invstd;
+            }
+            if (tr.rmean[slot]) {  // nn.BatchNorm1d: running = (1 - momentum) running + momentum batch (unbiased variance)
+                tr.rmean[slot][ch] = (1.0f - momentum) * tr.rmean[slot][ch] + momentum * mean;
+                tr.rvar[slot][ch] = (1.0f - momentum) * tr.rvar[slot][ch] + momentum * (m2 / fmaxf(cnt - 1.0f, 1.0f));
+            }
+            if (ch == 0 && tr.nbt[slot]) *tr.nbt[slot] += 1;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n * c; i += kErwinThreads) {
+        const int t = i / c, k = i - t * c;
+        float& y = F(X + 4 * (t * ld + k));
+        y = fmaf(y, F(bn + 4 * k), F(bn + 4 * (cmp + k)));
+    }
+    __syncthreads();
+}
+
 // BallPooling (pooling.py:25-40): level l -> l+1
-__device__ ERWIN_PHASE void erwin_pool(int l, const haet_erwin_desc& D,
-                                                     const float* __restrict__ W) {
+__device__ ERWIN_PHASE void erwin_pool(int l, const haet_erwin_desc& D, const float* __restrict__ W,
+                                       const ErwinTrain& tr, int cloud, int n_clouds, int& epoch) {
     const haet_erwin_resample& R = D.pool[l];
     const int d = D.d, st = R.stride, n2 = T(T_N + l + 1), c = D.enc[l].c, K = st * c + st * d;
     const int X0 = T(T_X + l), ld0 = T(T_LD + l), P0 = T(T_P + l), P1 = T(T_P + l + 1);
@@ -756,14 +858,20 @@ __device__ ERWIN_PHASE void erwin_pool(int l, const haet_erwin_desc& D,
     }
     __syncthreads();
     const int par = T(T_PAR) - 4 * R.small_off;
+    const bool train = tr.on != 0;  // batch statistics: the epilogue leaves y, bn_train_phase normalises it
     linear_core(rows, n2, K, wptr(W, R.w), nullptr, D.enc[l + 1].c, EP_BN, T(T_X + l + 1), T(T_LD + l + 1),
-                par + 4 * R.b, 0, par + 4 * R.bn_scale, par + 4 * R.bn_shift, none, 0, 0);
+                par + 4 * R.b, 0, train ? -1 : par + 4 * R.bn_scale, par + 4 * R.bn_shift, none, 0, 0);
     __syncthreads();
+    if (train) {
+        bn_train_phase(T(T_X + l + 1), T(T_LD + l + 1), n2, D.enc[l + 1].c, par + 4 * R.bn_scale, par + 4 * R.bn_shift,
+                       R.bn_eps, R.bn_momentum, 2 * l, tr, cloud, n_clouds, epoch);
+        ++epoch;
+    }
 }
 
 // BallUnpooling (pooling.py:58-72): level l+1 -> l
-__device__ ERWIN_PHASE void erwin_unpool(int l, const haet_erwin_desc& D,
-                                                       const float* __restrict__ W) {
+__device__ ERWIN_PHASE void erwin_unpool(int l, const haet_erwin_desc& D, const float* __restrict__ W,
+                                         const ErwinTrain& tr, int cloud, int n_clouds, int& epoch) {
     const haet_erwin_resample& R = D.unpool[l];
     const int d = D.d, st = R.stride, n2 = T(T_N + l + 1), c2 = D.enc[l + 1].c, c = D.enc[l].c;
     const int K = c2 + st * d, Kp = round32(K);
@@ -784,9 +892,15 @@ __device__ ERWIN_PHASE void erwin_unpool(int l, const haet_erwin_desc& D,
     }
     __syncthreads();
     const int par = T(T_PAR) - 4 * R.small_off;
+    const bool train = tr.on != 0;
     linear_core(rows, n2, K, wptr(W, R.w), nullptr, st * c, EP_UNPOOL, T(T_X + l), T(T_LD + l), par + 4 * R.b, 0,
-                par + 4 * R.bn_scale, par + 4 * R.bn_shift, none, c, st);
+                train ? -1 : par + 4 * R.bn_scale, par + 4 * R.bn_shift, none, c, st);
     __syncthreads();
+    if (train) {
+        bn_train_phase(T(T_X + l), T(T_LD + l), n2 * st, c, par + 4 * R.bn_scale, par + 4 * R.bn_shift, R.bn_eps,
+                       R.bn_momentum, 2 * l + 1, tr, cloud, n_clouds, epoch);
+        ++epoch;
+    }
 }
 
 // largest small-parameter group (floats, multiple of 4)
@@ -831,7 +945,10 @@ __host__ __device__ inline int erwin_layout(const haet_erwin_desc& D, int Mp, in
     }
     *ia_bytes = (ia + 15) & ~15;
     *wide_bytes = (wide + 15) & ~15;
-    tot += (*ia_bytes + *wide_bytes) / 4 + ((Mp * d + 3) & ~3) + erwin_max_small(D) + idx + Mp;
+    int cmax = 4;
+    for (int l = 0; l < D.n_levels; ++l) cmax = cmax > D.enc[l].c ? cmax : D.enc[l].c;
+    // + identity map, tree map (fused token stage), train-mode BatchNorm scale/shift scratch [2][cmax]
+    tot += (*ia_bytes + *wide_bytes) / 4 + ((Mp * d + 3) & ~3) + erwin_max_small(D) + idx + 2 * Mp + 2 * ((cmax + 3) & ~3);
     return tot;
 }
 
@@ -872,13 +989,27 @@ inline void erwin_directory(const haet_erwin_desc& D, int Mp, ErwinDir* out) {
         p += 4 * t[T_N + l];
     }
     t[T_IDENT] = p;
+    p += 4 * Mp;
+    t[T_TREE] = p;
+    p += 4 * Mp;
+    t[T_BN] = p;
 }
 
+// FUSED: the token stage in ONE launch -- token positions (IrregularMesh.py:204-209), the ball tree with its
+// rotated re-partitions (balltree.pyx:598-662) and the Erwin transformer; the tree stays in LDS (it is also written
+// to tree_idx / tree_mask / rot / pos_out for the callers that want it, off the critical path).  While the builder
+// runs (a latency chain of ~30 us on registers and LDS) the workgroup reads the Erwin weight blob once, a slice per
+// tree level: the blob (~0.8 MB at C3) has been evicted from this XCD's L2 by the streaming kernels since the last
+// forward, and every Linear of the Erwin stage is otherwise a chain of HBM misses (w1/w2 of a level-1 block: 8
+// dependent ~2k-cycle rounds).  Clouds must be powers of two <= 64 (balltree_wave_ok).
+constexpr int kWarmPieces = 16;  // 16-B loads per thread per builder step (64 VGPRs in flight)
+template <bool FUSED>
 __global__ __launch_bounds__(512) void erwin_kernel(
     const float* __restrict__ tokens, const float* __restrict__ pos,
-    const int32_t* __restrict__ tree_idx, const uint8_t* __restrict__ tree_mask,
-    const int32_t* __restrict__ rot, const float* __restrict__ W, int M, int Mp,
-    float* __restrict__ out, ErwinDir dir) {
+    int32_t* __restrict__ tree_idx, uint8_t* __restrict__ tree_mask,
+    int32_t* __restrict__ rot, const float* __restrict__ W, int M, int Mp,
+    float* __restrict__ out, ErwinDir dir, ErwinTrain tr, WTreeCfg tcfg, float* __restrict__ pos_out,
+    unsigned blob_pieces) {
     STAMP(0);
     const haet_erwin_desc& D = *reinterpret_cast<const haet_erwin_desc*>(W);
     const int cloud = blockIdx.x, n_clouds = gridDim.x, d = D.d, nl = D.n_levels;
@@ -886,28 +1017,60 @@ __global__ __launch_bounds__(512) void erwin_kernel(
     if (threadIdx.x < T_WORDS) I(4 * threadIdx.x) = dir.t[threadIdx.x];
     __syncthreads();
     STAMP(1);
-    // gather the cloud into tree order (erwin_flash.py:176-181)
-    const int c0 = D.enc[0].c, X0 = T(T_X), ld0 = T(T_LD), P0 = T(T_P), ident = T(T_IDENT);
-    for (int i = threadIdx.x; i < Mp * c0; i += kErwinThreads) {
-        const int slot = i / c0, ch = i % c0;
-        F(X0 + 4 * (slot * ld0 + ch)) = tokens[(size_t)tree_idx[(size_t)cloud * Mp + slot] * c0 + ch];
-    }
-    for (int i = threadIdx.x; i < Mp * d; i += kErwinThreads) {
-        const int slot = i / d, j = i % d;
-        F(P0 + 4 * i) = pos[(size_t)tree_idx[(size_t)cloud * Mp + slot] * d + j];
-    }
-    for (int i = threadIdx.x; i < Mp; i += kErwinThreads) I(ident + 4 * i) = i;
-    if (D.rotate) {
-        size_t off = 0;
-        for (int l = 0; l < nl; ++l) {
-            const int nlv = T(T_N + l), ro = T(T_ROT + l);
-            for (int i = threadIdx.x; i < nlv; i += kErwinThreads)
-                I(ro + 4 * i) = rot[off + (size_t)cloud * nlv + i] - cloud * nlv;
-            off += (size_t)n_clouds * nlv;
+    const int c0 = D.enc[0].c, X0 = T(T_X), ld0 = T(T_LD), P0 = T(T_P), ident = T(T_IDENT), tmap = T(T_TREE);
+    if (FUSED) {
+        const WTreeLds sink = {tmap, P0, {T(T_ROT), T(T_ROT + 1), T(T_ROT + 2), T(T_ROT + 3)}};
+        // L2 warm-up, software-pipelined over the builder's steps: step i first folds the pieces requested at step
+        // i - 1 (long since arrived) into a checksum nothing reads, then requests its own -- no load is waited for
+        // inside the step that issued it.  Unconditional, clamped addresses (counted waits).
+        typedef const __attribute__((address_space(1))) u32x4* gv4;
+        u32x4 pend[kWarmPieces];
+        unsigned sink_x = 0;
+#pragma unroll
+        for (int k = 0; k < kWarmPieces; ++k) pend[k] = u32x4{0u, 0u, 0u, 0u};
+        auto step = [&](int i) {
+#pragma unroll
+            for (int k = 0; k < kWarmPieces; ++k) sink_x ^= pend[k][0];
+            const unsigned base = (unsigned)i * (kErwinThreads * kWarmPieces) + threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < kWarmPieces; ++k)
+                pend[k] = ((gv4)W)[min(base + (unsigned)k * kErwinThreads, blob_pieces - 1)];
+        };
+        w_tree_build(tcfg, nullptr, tokens, c0, cloud, n_clouds, tree_idx, tree_mask, rot, pos_out, sink, step);
+#pragma unroll
+        for (int k = 0; k < kWarmPieces; ++k) sink_x ^= pend[k][0];
+        asm volatile("" ::"v"(sink_x));
+        __syncthreads();
+        // gather the cloud into tree order (erwin_flash.py:176-181) through the tree map in LDS
+        for (int i = threadIdx.x; i < Mp * c0; i += kErwinThreads) {
+            const int slot = i / c0, ch = i % c0;
+            F(X0 + 4 * (slot * ld0 + ch)) = tokens[((size_t)cloud * Mp + I(tmap + 4 * slot)) * c0 + ch];
+        }
+        for (int i = threadIdx.x; i < Mp; i += kErwinThreads) I(ident + 4 * i) = i;
+    } else {
+        // gather the cloud into tree order (erwin_flash.py:176-181)
+        for (int i = threadIdx.x; i < Mp * c0; i += kErwinThreads) {
+            const int slot = i / c0, ch = i % c0;
+            F(X0 + 4 * (slot * ld0 + ch)) = tokens[(size_t)tree_idx[(size_t)cloud * Mp + slot] * c0 + ch];
+        }
+        for (int i = threadIdx.x; i < Mp * d; i += kErwinThreads) {
+            const int slot = i / d, j = i % d;
+            F(P0 + 4 * i) = pos[(size_t)tree_idx[(size_t)cloud * Mp + slot] * d + j];
+        }
+        for (int i = threadIdx.x; i < Mp; i += kErwinThreads) I(ident + 4 * i) = i;
+        if (D.rotate) {
+            size_t off = 0;
+            for (int l = 0; l < nl; ++l) {
+                const int nlv = T(T_N + l), ro = T(T_ROT + l);
+                for (int i = threadIdx.x; i < nlv; i += kErwinThreads)
+                    I(ro + 4 * i) = rot[off + (size_t)cloud * nlv + i] - cloud * nlv;
+                off += (size_t)n_clouds * nlv;
+            }
         }
     }
     __syncthreads();
     STAMP(2);
+    int epoch = 0;  // grid barriers passed so far (train-mode BatchNorm)
 
     // Op list (erwin_flash.py:183-192): [blocks_l, pool_l]* , bottleneck blocks, [unpool_l, blocks_l]*.
     // kind 0 = block (a = level, b = block index | decoder flag << 8), 1 = pool, 2 = unpool.
@@ -940,20 +1103,27 @@ __global__ __launch_bounds__(512) void erwin_kernel(
             const bool rt = D.rotate && L.depth > 1 && (j & 1);  // layers.py:66,75-89
             erwin_block(a, L, L.blocks[j], W, d, rt ? T(T_ROT + a) : ident);
         } else if (kind == 1) {
-            erwin_pool(a, D, W);
+            erwin_pool(a, D, W, tr, cloud, n_clouds, epoch);
         } else {
-            erwin_unpool(a, D, W);
+            erwin_unpool(a, D, W, tr, cloud, n_clouds, epoch);
         }
         STAMP(3 + (op < 8 ? op : 8));
     }
     // node.x[tree_mask][argsort(tree_idx[tree_mask])]  (erwin_flash.py:193)
     for (int i = threadIdx.x; i < Mp * c0; i += kErwinThreads) {
         const int slot = i / c0, ch = i % c0;
-        const size_t g = (size_t)cloud * Mp + slot;
-        if (tree_mask[g]) out[(size_t)tree_idx[g] * c0 + ch] = F(X0 + 4 * (slot * ld0 + ch));
+        if (FUSED) {  // (power-of-two clouds: every slot holds a token)
+            out[((size_t)cloud * Mp + I(tmap + 4 * slot)) * c0 + ch] = F(X0 + 4 * (slot * ld0 + ch));
+        } else {
+            const size_t g = (size_t)cloud * Mp + slot;
+            if (tree_mask[g]) out[(size_t)tree_idx[g] * c0 + ch] = F(X0 + 4 * (slot * ld0 + ch));
+        }
     }
     STAMP(12);
 }
+
+bool balltree_wave_ok(int M, int n_levels, const int* st);             // balltree_wave.hip
+void rotation_matrix_f32(float angle_deg, int d, float* r9);             // balltree.hip
 
 static int erwin_validate(const haet_erwin_desc* D, int Mp) {
     if (!D) return fail(HAET_E_ARG, "erwin: desc is NULL");
@@ -1009,10 +1179,78 @@ extern "C" size_t haet_erwin_lds_bytes(const haet_erwin_desc* desc, int Mp) {
     return (size_t)erwin_layout(*desc, Mp, &a, &w) * sizeof(float);
 }
 
+static int erwin_train_args(const haet_erwin_desc* desc, const haet_erwin_train* train, int n_clouds,
+                            hipStream_t stream, ErwinTrain* out) {
+    ErwinTrain t = {};
+    if (!desc->bn_train) {
+        *out = t;
+        return HAET_OK;
+    }
+    if (!train || !train->workspace)
+        return fail(HAET_E_ARG, "erwin: desc->bn_train is set but no train-mode plumbing (haet_erwin_train) was passed");
+    if (n_clouds > 256)
+        return fail(HAET_E_RESOURCE, "erwin: train-mode BatchNorm meets all %d clouds at a grid barrier: at most 256 "
+                                     "(one workgroup per CU)", n_clouds);
+    int cmax = 4;
+    for (int l = 0; l < desc->n_levels; ++l) cmax = cmax > desc->enc[l].c ? cmax : desc->enc[l].c;
+    for (int i = 0; i < 2 * HAET_ERWIN_MAX_LEVELS; ++i) {
+        t.rmean[i] = train->running_mean[i];
+        t.rvar[i] = train->running_var[i];
+        t.nbt[i] = train->num_batches_tracked[i];
+        if ((t.rmean[i] == nullptr) != (t.rvar[i] == nullptr))
+            return fail(HAET_E_ARG, "erwin: running_mean / running_var must be given in pairs");
+    }
+    t.stats = train->batch_stats;
+    t.bar = reinterpret_cast<unsigned*>(train->workspace);
+    t.tmo = t.bar + 1;
+    t.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(train->workspace) + 64);
+    t.cmax = cmax;
+    t.on = 1;
+    // the barrier words are zeroed before EVERY launch (a memset node under graph capture)
+    hipError_t e = hipMemsetAsync(train->workspace, 0, 64, stream);
+    if (e != hipSuccess) return fail(HAET_E_LAUNCH, "erwin: hipMemsetAsync: %s", hipGetErrorString(e));
+    *out = t;
+    return HAET_OK;
+}
+
+extern "C" size_t haet_erwin_train_workspace_bytes(const haet_erwin_desc* desc, int n_clouds) {
+    if (!desc || n_clouds < 1) return 0;
+    int cmax = 4;
+    for (int l = 0; l < desc->n_levels && l < HAET_ERWIN_MAX_LEVELS; ++l) cmax = cmax > desc->enc[l].c ? cmax : desc->enc[l].c;
+    return 64 + (size_t)2 * HAET_ERWIN_MAX_LEVELS * n_clouds * 2 * cmax * sizeof(float);
+}
+
+template <bool FUSED>
+static int erwin_launch(const float* tokens, const float* pos, int32_t* tree_idx, uint8_t* tree_mask, int32_t* rot,
+                        const float* weights, size_t weight_floats, const haet_erwin_desc* desc,
+                        const haet_erwin_train* train, int n_clouds, int M, int Mp, float* out, hipStream_t stream,
+                        const WTreeCfg& tcfg, float* pos_out) {
+    int a, w;
+    const size_t bytes = (size_t)erwin_layout(*desc, Mp, &a, &w) * sizeof(float);
+    const size_t statics = FUSED ? 8 * 1024 : 0;  // the tree builder's static tables (balltree_wave_dev.h)
+    if (bytes + statics > 160 * 1024)
+        return fail(HAET_E_RESOURCE, "erwin: one cloud needs %zu B of LDS (> 160 KiB)", bytes + statics);
+    static std::atomic<size_t> attr_set[2][64];  // per kernel, per device ordinal (the attribute is per device)
+    std::atomic<size_t>& attr_dev = attr_set[FUSED ? 1 : 0][PerDeviceOnce::bit()];
+    if (bytes > 48 * 1024 && bytes > attr_dev.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(erwin_kernel<FUSED>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return fail(HAET_E_LAUNCH, "erwin: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_dev.store(bytes, std::memory_order_release);
+    }
+    ErwinTrain tr;
+    if (int rc = erwin_train_args(desc, train, n_clouds, stream, &tr)) return rc;
+    ErwinDir dir;
+    erwin_directory(*desc, Mp, &dir);
+    hipLaunchKernelGGL(erwin_kernel<FUSED>, dim3(n_clouds), dim3(kErwinThreads), bytes, stream, tokens, pos, tree_idx,
+                       tree_mask, rot, weights, M, Mp, out, dir, tr, tcfg, pos_out, (unsigned)(weight_floats / 4));
+    return check_launch(FUSED ? "erwin_kernel<fused token stage>" : "erwin_kernel");
+}
+
 extern "C" int haet_erwin_fwd(const float* tokens, const float* pos, const int32_t* tree_idx,
                               const uint8_t* tree_mask, const int32_t* rot, const float* weights,
-                              size_t weight_floats, const haet_erwin_desc* desc, int n_clouds, int M,
-                              float* out, haet_stream_t stream) {
+                              size_t weight_floats, const haet_erwin_desc* desc, const haet_erwin_train* train,
+                              int n_clouds, int M, float* out, haet_stream_t stream) {
     if (weight_floats * 4 < sizeof(haet_erwin_desc))
         return fail(HAET_E_ARG, "erwin: weight blob smaller than its descriptor header");
     if (!tokens || !pos || !tree_idx || !tree_mask || !weights || !out || n_clouds < 1 || M < 2)
@@ -1023,21 +1261,53 @@ extern "C" int haet_erwin_fwd(const float* tokens, const float* pos, const int32
     int rc = erwin_validate(desc, Mp);
     if (rc != HAET_OK) return rc;
     if (desc->rotate && !rot) return fail(HAET_E_ARG, "erwin: rotate set but rot is NULL");
+    WTreeCfg none = {};
+    return erwin_launch<false>(tokens, pos, const_cast<int32_t*>(tree_idx), const_cast<uint8_t*>(tree_mask),
+                               const_cast<int32_t*>(rot), weights, weight_floats, desc, train, n_clouds, M, Mp, out,
+                               as_stream(stream), none, nullptr);
+}
+
+extern "C" int haet_token_stage_supported(const haet_erwin_desc* desc, int n_clouds, int M) {
+    if (!desc || n_clouds < 1 || erwin_validate(desc, M) != HAET_OK) return 0;
+    int st[3] = {1, 1, 1};
+    for (int l = 0; l < desc->n_levels - 1 && l < 3; ++l) st[l] = desc->pool[l].stride;
+    if (desc->n_levels > 4 || !balltree_wave_ok(M, desc->n_levels, st)) return 0;
     int a, w;
-    const size_t bytes = (size_t)erwin_layout(*desc, Mp, &a, &w) * sizeof(float);
-    if (bytes > 160 * 1024)
-        return fail(HAET_E_RESOURCE, "erwin: one cloud needs %zu B of LDS (> 160 KiB)", bytes);
-    static std::atomic<size_t> attr_set[64];  // per device ordinal (the attribute is per device)
-    std::atomic<size_t>& attr_dev = attr_set[PerDeviceOnce::bit()];
-    if (bytes > 64 * 1024 && bytes > attr_dev.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(erwin_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return fail(HAET_E_LAUNCH, "erwin: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_dev.store(bytes, std::memory_order_release);
+    return (size_t)erwin_layout(*desc, M, &a, &w) * sizeof(float) + 8 * 1024 <= 160 * 1024;
+}
+
+extern "C" int haet_token_stage_fwd(const float* S, int n_clouds, int M, float angle_deg, const float* weights,
+                                    size_t weight_floats, const haet_erwin_desc* desc, const haet_erwin_train* train,
+                                    float* pos_out, int32_t* tree_idx, uint8_t* tree_mask, int32_t* rot, float* out,
+                                    haet_stream_t stream) {
+    if (weight_floats * 4 < sizeof(haet_erwin_desc))
+        return fail(HAET_E_ARG, "token_stage: weight blob smaller than its descriptor header");
+    if (!S || !weights || !out || !desc) return fail(HAET_E_ARG, "token_stage: null pointer");
+    if (!haet_token_stage_supported(desc, n_clouds, M))
+        return fail(HAET_E_ARG, "token_stage: needs power-of-two clouds of <= 64 tokens (M=%d) and <= 4 levels; use "
+                                "haet_tokens_tree_build + haet_erwin_fwd", M);
+    if ((tree_idx == nullptr) != (tree_mask == nullptr)) return fail(HAET_E_ARG, "token_stage: tree_idx / tree_mask go together");
+    WTreeCfg cfg = {};
+    cfg.M = M;
+    cfg.nd = desc->d;
+    cfg.n_levels = desc->n_levels;
+    cfg.rotate = desc->rotate && angle_deg > 0.f;
+    if ((desc->rotate != 0) != (angle_deg > 0.f)) return fail(HAET_E_ARG, "token_stage: desc->rotate and angle disagree");
+    cfg.s[0] = cfg.s[1] = cfg.s[2] = 1;
+    int n = M;
+    for (int l = 0; l < desc->n_levels; ++l) {
+        // balltree.pyx:643: int(log2(TOTAL leaf count / ball size)) -- the total over all clouds (reference quirk)
+        const double q = (double)n_clouds * M / (double)desc->enc[l].ball;
+        int tg = 0;
+        while ((double)(2ll << tg) <= q) ++tg;  // floor(log2 q) for q >= 1, 0 below
+        cfg.t[l] = q >= 1.0 ? tg : 0;
+        if (l < desc->n_levels - 1) {
+            cfg.s[l] = desc->pool[l].stride;
+            n /= cfg.s[l];
+        }
     }
-    ErwinDir dir;
-    erwin_directory(*desc, Mp, &dir);
-    hipLaunchKernelGGL(erwin_kernel, dim3(n_clouds), dim3(kErwinThreads), bytes, as_stream(stream), tokens,
-                       pos, tree_idx, tree_mask, rot, weights, M, Mp, out, dir);
-    return check_launch("erwin_kernel");
+    (void)n;
+    rotation_matrix_f32(angle_deg, desc->d, cfg.R.r);
+    return erwin_launch<true>(S, nullptr, tree_idx, tree_mask, rot, weights, weight_floats, desc, train, n_clouds, M, M,
+                              out, as_stream(stream), cfg, pos_out);
 }

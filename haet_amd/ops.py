@@ -146,15 +146,82 @@ def balltree_build(pos: Optional[Tensor], n_clouds: int, M: int, strides: Sequen
     return tree_idx, tree_mask, rot, sizes
 
 
+class ErwinTrainState:
+    """Device plumbing of train-mode BatchNorm for haet_erwin_fwd / haet_token_stage_fwd (include/haet_hip.h
+    haet_erwin_train): running statistics of the pool / unpool norms (updated in place by the kernel), the
+    batch statistics of the forward (kept for the backward) and the grid-barrier workspace."""
+
+    def __init__(self, erwin, desc, n_clouds: int, device):
+        lib = _lib.load()
+        self.c = _lib.ErwinTrain()
+        self.keep = []
+        n_levels = len(erwin.encoder) + 1
+        cmax = max(erwin.c_hidden)
+        self.batch_stats = torch.zeros((2 * _lib.MAX_LEVELS, 2, cmax), dtype=torch.float32, device=device)
+        self.workspace = torch.zeros(lib.haet_erwin_train_workspace_bytes(ctypes.byref(desc), n_clouds) // 4 + 1,
+                                     dtype=torch.float32, device=device)
+        self.c.batch_stats = self.batch_stats.data_ptr()
+        self.c.workspace = self.workspace.data_ptr()
+        for i, layer in enumerate(erwin.encoder):
+            self._slot(2 * i, layer.pool.norm)
+        for k, layer in enumerate(erwin.decoder):
+            self._slot(2 * (n_levels - 2 - k) + 1, layer.unpool.norm)
+
+    def _slot(self, slot, bn):
+        if bn.momentum is None:
+            raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative average) is not supported by the HIP Erwin stage")
+        if bn.track_running_stats and bn.running_mean is not None:
+            for t in (bn.running_mean, bn.running_var):
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    raise HaetError("BatchNorm running statistics must be contiguous fp32")
+            self.c.running_mean[slot] = bn.running_mean.data_ptr()
+            self.c.running_var[slot] = bn.running_var.data_ptr()
+            self.c.num_batches_tracked[slot] = bn.num_batches_tracked.data_ptr()
+            self.keep += [bn.running_mean, bn.running_var, bn.num_batches_tracked]
+
+
 def erwin_fwd(tokens: Tensor, pos: Tensor, tree_idx: Tensor, tree_mask: Tensor, rot: Optional[Tensor],
-              weights: Tensor, desc: "_lib.ErwinDesc", n_clouds: int, M: int) -> Tensor:
+              weights: Tensor, desc: "_lib.ErwinDesc", n_clouds: int, M: int, train: Optional[ErwinTrainState] = None) -> Tensor:
     lib = _lib.load()
     tokens, pos = _f32(tokens, "tokens"), _f32(pos, "pos")
     out = torch.empty_like(tokens)
     check(lib.haet_erwin_fwd(_p(tokens), _p(pos), _p(tree_idx), _p(tree_mask), _p(rot), _p(weights),
-                             weights.numel(), ctypes.byref(desc), n_clouds, M, _p(out), _stream()),
+                             weights.numel(), ctypes.byref(desc), ctypes.byref(train.c) if train is not None else None,
+                             n_clouds, M, _p(out), _stream()),
           "haet_erwin_fwd")
     return out
+
+
+def token_stage_supported(desc: "_lib.ErwinDesc", n_clouds: int, M: int) -> bool:
+    return bool(_lib.load().haet_token_stage_supported(ctypes.byref(desc), n_clouds, M))
+
+
+def token_stage(S: Tensor, weights: Tensor, desc: "_lib.ErwinDesc", n_clouds: int, M: int, d: int, strides: Sequence[int],
+                angle: float, train: Optional[ErwinTrainState] = None, want_tree: bool = False):
+    """haet_token_stage_fwd: positions + ball tree + Erwin in one launch.  Returns (tokens', pos) and, with
+    want_tree, also (tree_idx, tree_mask, rot flat | None, level sizes)."""
+    lib = _lib.load()
+    S = _f32(S, "S")
+    dev = S.device
+    out = torch.empty_like(S)
+    pos = torch.empty((S.shape[0], d), dtype=torch.float32, device=dev)
+    tree_idx = tree_mask = rot = None
+    sizes = []
+    if want_tree:
+        tree_idx = torch.empty(n_clouds * M, dtype=torch.int32, device=dev)
+        tree_mask = torch.empty(n_clouds * M, dtype=torch.uint8, device=dev)
+        n = M
+        for i in range(desc.n_levels):
+            sizes.append(n_clouds * n)
+            if i < desc.n_levels - 1:
+                n //= strides[i]
+        rot = torch.empty(sum(sizes), dtype=torch.int32, device=dev) if angle > 0 else None
+    check(lib.haet_token_stage_fwd(_p(S), n_clouds, M, float(angle), _p(weights), weights.numel(), ctypes.byref(desc),
+                                   ctypes.byref(train.c) if train is not None else None, _p(pos), _p(tree_idx),
+                                   _p(tree_mask), _p(rot), _p(out), _stream()), "haet_token_stage_fwd")
+    if want_tree:
+        return out, pos, tree_idx, tree_mask, rot, sizes
+    return out, pos
 
 
 def deslice(x_lin: Tensor, p: SliceParams, col_max: Tensor, col_sum: Tensor, S2: Tensor,

@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define HAET_ABI_VERSION 3  /* 2: + haet_tokens_tree_build, haet_project_split_fwd, haet_*_fwd_split */
+#define HAET_ABI_VERSION 4  /* 2: + haet_tokens_tree_build, haet_project_split_fwd, haet_*_fwd_split; 4: train-mode
+                             BatchNorm (haet_erwin_train), haet_token_stage_fwd */
 
 #define HAET_OK 0
 #define HAET_E_ARG (-1)      /* bad argument / unsupported shape */
@@ -169,10 +170,11 @@ typedef struct {
 } haet_erwin_layer;
 
 typedef struct {
-    int32_t stride;
+    int32_t stride;             /* 1 in a pool: "no pooling", the node passes through (pooling.py:26-27) */
     int32_t w, b;               /* Linear, [out][K~] / [out] */
-    int32_t bn_scale, bn_shift; /* eval BatchNorm as y*scale+shift, [c_out] */
+    int32_t bn_scale, bn_shift; /* eval BatchNorm folded to y*scale+shift, [c_out]; with desc.bn_train: gamma, beta */
     int32_t small_off, small_len; /* b | bn_scale | bn_shift, contiguous like above */
+    float bn_eps, bn_momentum;  /* nn.BatchNorm1d eps / momentum (train mode) */
 } haet_erwin_resample;
 
 typedef struct {
@@ -180,6 +182,8 @@ typedef struct {
     int32_t d;        /* position dimensionality (2 or 3) */
     int32_t rotate;   /* 1: odd blocks run on the rotated partition */
     int32_t decode;   /* must be 1 */
+    int32_t bn_train; /* 1: BatchNorm uses batch statistics over the tokens of ALL clouds (module.train()) and the
+                         launch needs a haet_erwin_train; 0: running statistics, folded by pack.py */
     haet_erwin_layer enc[HAET_ERWIN_MAX_LEVELS];       /* enc[n_levels-1] is the bottleneck */
     haet_erwin_layer dec[HAET_ERWIN_MAX_LEVELS];       /* dec[i] runs at level i (i < n_levels-1) */
     haet_erwin_resample pool[HAET_ERWIN_MAX_LEVELS];   /* level i -> i+1 */
@@ -188,11 +192,37 @@ typedef struct {
 
 size_t haet_erwin_lds_bytes(const haet_erwin_desc* desc, int Mp);
 
+/* Train-mode BatchNorm plumbing (BallPooling / BallUnpooling `norm` under module.train(), pooling.py:23,38,56,68:
+ * batch statistics over the tokens of ALL clouds, running statistics updated with `momentum`, num_batches_tracked
+ * incremented).  Slot 2l = pool of level l, 2l+1 = unpool of level l.  The clouds' workgroups meet at a grid
+ * barrier per BatchNorm, so a train-mode launch takes at most 256 clouds (HAET_E_RESOURCE beyond). */
+typedef struct {
+    float* running_mean[2 * HAET_ERWIN_MAX_LEVELS];          /* device, updated in place; NULL: slot unused / not tracked */
+    float* running_var[2 * HAET_ERWIN_MAX_LEVELS];
+    long long* num_batches_tracked[2 * HAET_ERWIN_MAX_LEVELS];
+    float* batch_stats; /* out (may be NULL): [2*HAET_ERWIN_MAX_LEVELS][2][cmax] batch mean, 1/sqrt(var+eps); cmax = max channels */
+    void* workspace;    /* device, haet_erwin_train_workspace_bytes() bytes, caller-owned scratch */
+} haet_erwin_train;
+
+size_t haet_erwin_train_workspace_bytes(const haet_erwin_desc* desc, int n_clouds);
+
 int haet_erwin_fwd(const float* tokens /*[n_clouds*M, c0]*/, const float* pos /*[n_clouds*M, d]*/,
                    const int32_t* tree_idx, const uint8_t* tree_mask, const int32_t* rot,
                    const float* weights, size_t weight_floats /* length of the blob */,
-                   const haet_erwin_desc* desc, int n_clouds, int M,
-                   float* out /*[n_clouds*M, c0]*/, haet_stream_t stream);
+                   const haet_erwin_desc* desc, const haet_erwin_train* train /* NULL unless desc->bn_train */,
+                   int n_clouds, int M, float* out /*[n_clouds*M, c0]*/, haet_stream_t stream);
+
+/* The whole token stage in ONE launch: haet_token_pos + haet_balltree_build + haet_erwin_fwd
+ * (IrregularMesh.py:196-218 = positions from the tokens' first d channels, build_balltree_with_rotations,
+ * ErwinTransformer.forward) for power-of-two clouds of <= 64 tokens (haet_token_stage_supported).  S [n_clouds*M, c0]
+ * are the slice tokens; the tree stays on the CU.  pos_out [n_clouds*M, d], tree_idx / tree_mask [n_clouds*M] and
+ * rot (levels concatenated, as haet_balltree_build) are optional outputs (NULL: not written).  `angle_deg` is the
+ * module's `rotate` (<= 0 with desc->rotate == 0). */
+int haet_token_stage_supported(const haet_erwin_desc* desc, int n_clouds, int M);
+int haet_token_stage_fwd(const float* S, int n_clouds, int M, float angle_deg, const float* weights,
+                         size_t weight_floats, const haet_erwin_desc* desc, const haet_erwin_train* train,
+                         float* pos_out, int32_t* tree_idx, uint8_t* tree_mask, int32_t* rot, float* out,
+                         haet_stream_t stream);
 
 /* ------------------------------------------------------------------ de-slice pass
  * Replaces einsum('bhgc,bhng->bhnc') + rearrange 'b h n d -> b n (h d)'

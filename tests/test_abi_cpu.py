@@ -36,7 +36,7 @@ def test_binding_loads_and_reports_errors_without_gpu():
     from haet_amd import _lib
 
     lib = _lib.load()
-    assert lib.haet_abi_version() == 3
+    assert lib.haet_abi_version() == 4
     # argument validation happens before any HIP call, so it is testable on CPU
     assert lib.haet_slice_num_parts(1, 1000, 8, 48, 64) < 0  # dim_head 48 unsupported
     assert b"dim_head" in lib.haet_last_error_string()
@@ -47,7 +47,10 @@ def test_binding_loads_and_reports_errors_without_gpu():
 def test_erwin_desc_struct_matches_header_size():
     from haet_amd import _lib
 
-    # 4 ints + 8 layers of (5 + 4*16) ints + 8 resamples of 7 ints
-    assert ctypes.sizeof(_lib.ErwinDesc) == 4 * (4 + 8 * (5 + 4 * 16) + 8 * 7)
+    # 5 ints + 8 layers of (5 + 4*16) ints + 8 resamples of 7 ints and 2 floats
+    assert ctypes.sizeof(_lib.ErwinDesc) == 4 * (5 + 8 * (5 + 4 * 16) + 8 * 9)
+    # haet_erwin_train: 3 pointer tables of 2 * MAX_LEVELS + 2 pointers
+    assert ctypes.sizeof(_lib.ErwinTrain) == 8 * (3 * 2 * _lib.MAX_LEVELS + 2)
+    assert _lib.load().haet_erwin_train_workspace_bytes(ctypes.byref(_lib.ErwinDesc()), 8) >= 64
     d = _lib.ErwinDesc()
     assert _lib.load().haet_erwin_lds_bytes(ctypes.byref(d), 64) == 0  # invalid desc -> 0

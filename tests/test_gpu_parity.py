@@ -138,13 +138,14 @@ def _hip_module(meta, sd, dev):
     return mod.to(dev).eval()
 
 
-@pytest.mark.parametrize("name", EVAL_CASES)
+@pytest.mark.parametrize("name", CASES)
 def test_erwin_stage_with_reference_tree(name, hip_device):
-    """Erwin kernel alone: reference tokens, positions AND tree injected."""
+    """Erwin kernel alone: reference tokens, positions AND tree injected.  Train-mode fixtures: BatchNorm on the batch
+    statistics of all clouds inside the kernel (grid barrier), running statistics updated like nn.BatchNorm1d."""
     from haet_amd import ops
 
     x, sd, meta, exp, cfg, tr, _ = _oracle_trace(name)
-    mod = _hip_module(meta, sd, hip_device)
+    mod = _hip_module(meta, sd, hip_device).train(meta["train"])
     blob, desc = mod.erwin.packed()
     e = cfg.erwin
     n_clouds = x.shape[0] * cfg.heads
@@ -152,9 +153,90 @@ def test_erwin_stage_with_reference_tree(name, hip_device):
     tm = exp["erwin.tree_mask"].to(torch.uint8).to(hip_device)
     rots = [exp[f"erwin.rot{j}"] for j in range(len(e.ball_sizes)) if f"erwin.rot{j}" in exp]
     rot = torch.cat(rots).to(torch.int32).to(hip_device) if rots else None
+    train = mod.erwin._train_state(desc, n_clouds, hip_device) if meta["train"] else None
     out = ops.erwin_fwd(exp["eidetic_flat"].to(hip_device), exp["pos"].to(hip_device), ti, tm, rot,
-                        blob, desc, n_clouds, cfg.slice_num)
+                        blob, desc, n_clouds, cfg.slice_num, train)
     assert O.rel_l2(out.cpu(), exp["processed_flat"]) < 5 * FP32_TOL
+    if meta["train"]:
+        _check_running_stats(mod, sd, exp, cfg, hip_device)
+
+
+def _check_running_stats(mod, sd, exp, cfg, dev):
+    """Running statistics after ONE train-mode forward from the fixture's initial state, against nn.BatchNorm1d's rule
+    applied to the reference's own pre-normalisation activations ... restated through the torch modules on the CPU."""
+    from haet_amd import _autograd
+    from tests.test_modules_cpu import CTOR
+
+    ref = CTOR[_kind_of(cfg)](**_kw_of(cfg))
+    ref.load_state_dict(sd)
+    ref.train()
+    n_clouds = exp["eidetic_flat"].shape[0] // cfg.slice_num
+    with torch.no_grad():
+        _patched_cpu_erwin(ref.erwin, exp, n_clouds)
+    for (k, a), (_, b) in zip(mod.erwin.named_buffers(), ref.erwin.named_buffers()):
+        if "num_batches_tracked" in k:
+            assert int(a) == int(b), k
+        else:
+            assert torch.allclose(a.cpu(), b, rtol=2e-4, atol=2e-5), k
+
+
+def _kind_of(cfg):
+    return cfg.kind
+
+
+def _kw_of(cfg):
+    e = cfg.erwin
+    kw = dict(dim=cfg.dim, heads=cfg.heads, dim_head=cfg.dim_head, slice_num=cfg.slice_num, rotate=cfg.rotate,
+              mlp_ratio=cfg.mlp_ratio, c_hidden=e.c_hidden, ball_sizes=e.ball_sizes, enc_num_heads=e.enc_num_heads,
+              enc_depths=e.enc_depths, dec_num_heads=e.dec_num_heads, dec_depths=e.dec_depths, strides=e.strides)
+    if cfg.kind == "structured2d":
+        kw.update(H=cfg.grid[0], W=cfg.grid[1])
+    elif cfg.kind == "structured3d":
+        kw.update(H=cfg.grid[0], W=cfg.grid[1], D=cfg.grid[2])
+    return kw
+
+
+def _patched_cpu_erwin(er, exp, n_clouds):
+    """haet_amd._autograd.erwin_forward on the CPU with the REFERENCE's tree injected (its tree builder is the HIP one)."""
+    from haet_amd import _autograd, ops
+
+    e_rots = [exp[k] for k in ("erwin.rot0", "erwin.rot1", "erwin.rot2") if k in exp]
+    sizes = [r.numel() for r in e_rots]
+    orig = ops.balltree_build
+    ops.balltree_build = lambda *a, **k: (exp["erwin.tree_idx"].int(), exp["erwin.tree_mask"].to(torch.uint8),
+                                         torch.cat(e_rots).int() if e_rots else None, sizes or [exp["erwin.tree_idx"].numel()])
+    try:
+        return _autograd.erwin_forward(er, exp["eidetic_flat"], exp["pos"], n_clouds)
+    finally:
+        ops.balltree_build = orig
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_token_stage_one_launch(name, hip_device):
+    """haet_token_stage_fwd (positions + ball tree + Erwin in ONE launch, the tree never leaves the CU) on the
+    reference's slice tokens: positions, tree and rotated permutations bit-exact, tokens' against the reference."""
+    from haet_amd import ops
+
+    x, sd, meta, exp, cfg, tr, _ = _oracle_trace(name)
+    mod = _hip_module(meta, sd, hip_device).train(meta["train"])
+    blob, desc = mod.erwin.packed()
+    e = cfg.erwin
+    n_clouds, M = x.shape[0] * cfg.heads, cfg.slice_num
+    if not ops.token_stage_supported(desc, n_clouds, M):
+        assert M > 64 or M & (M - 1)
+        pytest.skip("clouds that are not powers of two <= 64 take the three-launch path")
+    train = mod.erwin._train_state(desc, n_clouds, hip_device) if meta["train"] else None
+    out, pos, ti, tm, rot, sizes = ops.token_stage(exp["eidetic_flat"].to(hip_device), blob, desc, n_clouds, M,
+                                                   e.dimensionality, e.strides, float(e.rotate), train, want_tree=True)
+    assert torch.equal(pos.cpu(), exp["pos"])
+    rots = [exp[f"erwin.rot{j}"].numpy() for j in range(len(e.ball_sizes)) if f"erwin.rot{j}" in exp]
+    _check_tree(ti, tm, rot, sizes, exp["erwin.tree_idx"].numpy(), exp["erwin.tree_mask"].numpy(), rots)
+    assert O.rel_l2(out.cpu(), exp["processed_flat"]) < 5 * FP32_TOL
+    # and without the optional outputs (what the module calls)
+    train = mod.erwin._train_state(desc, n_clouds, hip_device) if meta["train"] else None
+    out2, pos2 = ops.token_stage(exp["eidetic_flat"].to(hip_device), blob, desc, n_clouds, M, e.dimensionality,
+                                 e.strides, float(e.rotate), train)
+    assert torch.equal(out2, out) and torch.equal(pos2, pos)
 
 
 @pytest.mark.parametrize("name", EVAL_CASES)
@@ -170,10 +252,19 @@ def test_deslice_pass_vs_oracle(name, hip_device, kernel_path):
     assert O.rel_l2(out_x.cpu(), tr["out_x"]) < FP32_TOL
 
 
-@pytest.mark.parametrize("name", EVAL_CASES)
-def test_attention_module_end_to_end(name, hip_device, kernel_path):
+@pytest.fixture(params=["fused", "three_launches"])
+def token_path(request, monkeypatch):
+    """'fused' = haet_token_stage_fwd where the shape allows; 'three_launches' = positions + tree, then Erwin."""
+    if request.param == "three_launches":
+        monkeypatch.setenv("HAET_NO_TOKEN_STAGE", "1")
+    return request.param
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_attention_module_end_to_end(name, hip_device, kernel_path, token_path):
+    """Eval fixtures and, under no_grad, the train-mode ones (BatchNorm batch statistics in the HIP Erwin stage)."""
     x, sd, meta, exp, cfg, tr, oracle_out = _oracle_trace(name)
-    mod = _hip_module(meta, sd, hip_device)
+    mod = _hip_module(meta, sd, hip_device).train(meta["train"])
     with torch.no_grad():
         out, inter = mod(x.to(hip_device), return_intermediates=True)
     assert O.rel_l2(inter["eidetic"].cpu(), exp["eidetic_flat"]) < FP32_TOL
