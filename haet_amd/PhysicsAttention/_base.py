@@ -408,6 +408,15 @@ class PhysicsAttentionBase(nn.Module):
         with ev("erwin"):  # token positions are derived inside the tree launch (haet_tokens_tree_build)
             S2 = self.erwin(S, None, n_clouds=B * H)                     # [B*H*G, C]
             pos = self.erwin.last_positions                              # [B*H*G, d]
+        w_out = None
+        if xs is not None and not return_intermediates and ops.deslice_out_supported(H, C, G, self.to_out[0].out_features):
+            w_out = self._split_linear("to_out", self.to_out[0])
+        if w_out is not None:  # de-slice + to_out in one pass: out_x [B, N, H*C] never exists
+            with ev("deslice"):
+                out = ops.deslice_out_split(xs, sp, col_max, col_sum, S2, G, w_out)
+            with ev("to_out"):
+                out = self.to_out[1](out).to(x.dtype)
+            return out
         with ev("deslice"):
             out_x = (ops.deslice_split(xs, sp, col_max, col_sum, S2, G) if xs is not None
                      else ops.deslice(x_lin, sp, col_max, col_sum, S2, H, C, G))  # [B, N, H*C]

@@ -513,6 +513,23 @@ def deslice_split(xs: SplitPoints, p: SliceParams, col_max: Tensor, col_sum: Ten
     return out
 
 
+def deslice_out_supported(H: int, C: int, M: int, O: int) -> bool:
+    return bool(_lib.load().haet_deslice_out_supported(int(H), int(C), int(M), int(O)))
+
+
+def deslice_out_split(xs: SplitPoints, p: SliceParams, col_max: Tensor, col_sum: Tensor, S2: Tensor, M: int,
+                      w: SplitLinear) -> Tensor:
+    """to_out(de-slice(...)) in one pass (haet_deslice_out_fwd_split): the [B, N, H*C] tensor between them is never
+    written.  `w`: the to_out Linear as split planes [O][H*C]."""
+    lib = _lib.load()
+    B, N, _ = xs.cells.shape
+    out = torch.empty((B, N, w.O), dtype=torch.float32, device=xs.cells.device)
+    check(lib.haet_deslice_out_fwd_split(_p(xs.cells), _p(xs.s), _p(p.Ws), _p(p.bs), p.c0, _p(col_max), _p(col_sum),
+                                         _p(_f32(S2, "S2")), _p(w.hi), _p(w.lo), _p(w.bias), B, N, xs.H, xs.C, M, w.O,
+                                         _p(out), _stream()), "haet_deslice_out_fwd_split")
+    return out
+
+
 # --------------------------------------------------------------------------- structured projection
 class SplitConv:
     """A Conv2d / Conv3d weight [O, C_in, k, k(, k)] as split planes laid out [O][C_in/32][taps][32]

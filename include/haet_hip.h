@@ -224,6 +224,17 @@ int haet_token_stage_fwd(const float* S, int n_clouds, int M, float angle_deg, c
                          float* pos_out, int32_t* tree_idx, uint8_t* tree_mask, int32_t* rot, float* out,
                          haet_stream_t stream);
 
+/* ------------------------------------------------------------------ de-slice + to_out in one pass
+ * Replaces einsum('bhgc,bhng->bhnc') + rearrange + self.to_out[0] (models/PhysicsAttention/IrregularMesh.py:221-235)
+ * for the fused operand format: out [B, N, O] = to_out( de-slice(cells, s; col_max, col_sum, S2) ); the [B, N, H*C]
+ * de-sliced tensor is never written.  Whi / Wlo / bias: the to_out Linear as haet_split_bf16 planes [O][H*C].
+ * Envelope: H = 8, C = 32, O = 256, M in {32, 64} (haet_deslice_out_supported). */
+int haet_deslice_out_supported(int H, int C, int M, int O);
+int haet_deslice_out_fwd_split(const float* cells, const float* s, const float* Ws, const float* bs, float c0,
+                               const float* col_max, const float* col_sum, const float* S2,
+                               const uint16_t* Whi, const uint16_t* Wlo, const float* bias,
+                               int B, int N, int H, int C, int M, int O, float* out, haet_stream_t stream);
+
 /* ------------------------------------------------------------------ de-slice pass
  * Replaces einsum('bhgc,bhng->bhnc') + rearrange 'b h n d -> b n (h d)'
  * (models/PhysicsAttention/IrregularMesh.py:228-232): recomputes the slice weights

@@ -885,3 +885,77 @@ def test_more_than_2_31_elements_per_tensor(hip_device):
     for a in range(0, N, 1_000_000):  # chunked: a float64 copy of the whole tensor is 17 GB
         tot += out1[:, a:a + 1_000_000].double().sum(dim=1)
     assert torch.allclose(tot, torch.full_like(tot, float(M)), rtol=2e-4)
+
+
+# --------------------------------------------------------------------------- de-slice fused with to_out
+def _split_points(x_lin, sd, cfg, dev):
+    """x_lin [B, N, H*C] fp32 (CPU) in the fused operand format (what haet_project_split_fwd writes): 16-B cells
+    {4 x bf16 hi, 4 x bf16 lo} per 4 channels + s = log2(e) / tau."""
+    from haet_amd import ops
+
+    B, N, HC = x_lin.shape
+    H, C = cfg.heads, cfg.dim_head
+    hi = x_lin.to(torch.bfloat16)
+    lo = (x_lin - hi.float()).to(torch.bfloat16)
+    cells = torch.stack([hi.reshape(B, N, HC // 4, 4), lo.reshape(B, N, HC // 4, 4)], dim=3).reshape(B, N, 2 * HC)
+    cells = cells.contiguous().view(torch.float32)
+    t = x_lin.reshape(B, N, H, C) @ sd["ada_temp_linear.weight"][0] + sd["ada_temp_linear.bias"]
+    s = 1.4426950408889634 / (cfg.base_temp + t.clamp(-0.4, 0.4))
+    return ops.SplitPoints(cells.to(dev), s.float().contiguous().to(dev), H, C)
+
+
+@pytest.mark.parametrize("N", [1, 31, 33, 1057, 40_003])
+@pytest.mark.parametrize("M", [32, 64])
+def test_deslice_out_fused_vs_fp64(N, M, hip_device):
+    """haet_deslice_out_fwd_split (de-slice + to_out in one pass, out_x never written) against an fp64 restatement
+    and against the two unfused kernels on the same operands; ragged point counts, B = 2."""
+    from haet_amd import ops
+
+    torch.manual_seed(N + M)
+    B, H, C, D = 2, 8, 32, 256
+    dev = hip_device
+    x = torch.randn(B, N, D)
+    lin_in, lin_out = torch.nn.Linear(D, H * C), torch.nn.Linear(H * C, D)
+    sd = {"in_project_slice.weight": torch.randn(M, C) * 0.3, "in_project_slice.bias": torch.randn(M) * 0.2,
+          "ada_temp_linear.weight": torch.randn(1, C) * 0.2, "ada_temp_linear.bias": torch.tensor([0.05])}
+    cfg = O.AttnCfg(dim=D, heads=H, dim_head=C, slice_num=M)
+    sp = _slice_params(sd, cfg, dev)
+    w_in = ops.SplitLinear(lin_in.weight.to(dev), lin_in.bias.to(dev))
+    w_out = ops.SplitLinear(lin_out.weight.to(dev), lin_out.bias.to(dev))
+    assert ops.deslice_out_supported(H, C, M, D)
+    xs = _split_points((x @ lin_in.weight.t() + lin_in.bias).detach(), sd, cfg, dev)
+    cm, cs, S = ops.merge_records(ops.slice_partials_split(xs, sp, M), B, H, C, M, True)
+    S2 = torch.randn(B * H * M, C)
+    out = ops.deslice_out_split(xs, sp, cm, cs, S2.to(dev), M, w_out)
+    # the unfused pair on the same operands
+    out_x = ops.deslice_split(xs, sp, cm, cs, S2.to(dev), M)
+    ref_pair = ops.linear(out_x, w_out)
+    assert O.rel_l2(out.cpu(), ref_pair.cpu()) < FP32_TOL
+    # fp64 restatement from the split x_lin and the kernel's own column statistics
+    xl = xs.to_float().cpu().double().reshape(B, N, H, C).permute(0, 2, 1, 3)
+    tau, z = O.slice_logits(xl, {k: v.double() for k, v in sd.items()}, cfg)
+    w = torch.exp(z - cm.cpu().double().reshape(B, H, 1, M)) / cs.cpu().double().reshape(B, H, 1, M)
+    ox = torch.einsum("bhgc,bhng->bhnc", S2.double().reshape(B, H, M, C), w).permute(0, 2, 1, 3).reshape(B, N, H * C)
+    ref = ox @ lin_out.weight.double().t() + lin_out.bias.double()
+    assert O.rel_l2(out.cpu(), ref) < 5 * FP32_TOL
+
+
+@pytest.mark.parametrize("name", ["irr_c3like_amp", "irr_c3like_model", "irr_c3like_amp_train"])
+def test_module_forward_fused_epilogue(name, hip_device):
+    """The module's default inference path at the C3 widths: projection -> slice -> token stage -> de-slice + to_out
+    in one pass (no intermediates requested, so nothing is unfused), against the reference's output."""
+    x, sd, meta, exp, cfg, tr, oracle_out = _oracle_trace(name)
+    mod = _hip_module(meta, sd, hip_device).train(meta["train"])
+    from haet_amd import ops
+
+    calls = []
+    orig = ops.deslice_out_split
+    ops.deslice_out_split = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            out = mod(x.to(hip_device))
+    finally:
+        ops.deslice_out_split = orig
+    assert calls, "the fused de-slice + to_out kernel did not run"
+    err = O.rel_l2(out.cpu(), exp["out"])
+    assert err < NORTH_STAR_TOL and err < 10 * FP32_TOL, err
