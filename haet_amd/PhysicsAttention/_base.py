@@ -225,9 +225,15 @@ class PhysicsAttentionBase(nn.Module):
         self.erwin.invalidate_caches()
 
     @torch.compiler.disable  # torch.compile(model) (the reference's scripts): the HIP path is an opaque eager call
-    def forward(self, x: torch.Tensor, return_intermediates: bool = False, pre_norm: Optional[nn.LayerNorm] = None):
-        """`pre_norm` (not in the reference's signature; used by the block's inference fast path): a LayerNorm
-        to apply to x first -- fused into the projection GEMM's loader where the variant supports it."""
+    def forward(self, x: torch.Tensor, return_intermediates: bool = False, pre_norm: Optional[nn.LayerNorm] = None,
+                residual: bool = False):
+        """`pre_norm`, `residual` (not in the reference's signature; used by the block's inference fast path): a
+        LayerNorm to apply to x first -- fused into the projection GEMM's loader where the variant supports it -- and
+        whether to return `forward(x) + x` (the block's residual, added in the fused de-slice + to_out epilogue)."""
+        if residual:
+            if not (x.is_cuda and not torch.is_grad_enabled() and not return_intermediates):
+                return self.forward(x, return_intermediates, pre_norm) + x
+            res_src = x
         if pre_norm is not None and not (x.is_cuda and not torch.is_grad_enabled() and not self.training
                                          and self.fuses_pre_norm(x, pre_norm)):
             x, pre_norm = pre_norm(x), None
@@ -250,7 +256,7 @@ class PhysicsAttentionBase(nn.Module):
             return self.to_out[1](y).to(x.dtype)
         # no gradient wanted (inference; validation passes under no_grad, also in .train() mode: the Erwin kernel
         # then runs BatchNorm on batch statistics and updates the running ones, like the reference)
-        return self._forward_hip(x, return_intermediates, pre_norm)
+        return self._forward_hip(x, return_intermediates, pre_norm, res_src if residual else None)
 
     def project_torch(self, x: torch.Tensor) -> torch.Tensor:
         """The projection as stock torch ops (differentiable path, haet_amd/_autograd.py)."""
@@ -383,7 +389,7 @@ class PhysicsAttentionBase(nn.Module):
             cache[name] = (key, ops.SplitLinear(lin.weight.detach().t().contiguous(), None))
         return ops.linear(g, cache[name][1])
 
-    def _forward_hip(self, x: torch.Tensor, return_intermediates: bool = False, pre_norm=None):
+    def _forward_hip(self, x: torch.Tensor, return_intermediates: bool = False, pre_norm=None, residual=None):
         B, N, _ = x.shape
         H, C, G = self.heads, self.dim_head, self.slice_num
         self.__dict__["_event_chain"] = [None] if self.stage_events is not None else None
@@ -412,16 +418,21 @@ class PhysicsAttentionBase(nn.Module):
         if xs is not None and not return_intermediates and ops.deslice_out_supported(H, C, G, self.to_out[0].out_features):
             w_out = self._split_linear("to_out", self.to_out[0])
         if w_out is not None:  # de-slice + to_out in one pass: out_x [B, N, H*C] never exists
+            drop = self.training and self.to_out[1].p > 0  # dropout sits between to_out and the residual
             with ev("deslice"):
-                out = ops.deslice_out_split(xs, sp, col_max, col_sum, S2, G, w_out)
+                out = ops.deslice_out_split(xs, sp, col_max, col_sum, S2, G, w_out, None if drop else residual)
             with ev("to_out"):
                 out = self.to_out[1](out).to(x.dtype)
+                if drop and residual is not None:
+                    out = out + residual
             return out
         with ev("deslice"):
             out_x = (ops.deslice_split(xs, sp, col_max, col_sum, S2, G) if xs is not None
                      else ops.deslice(x_lin, sp, col_max, col_sum, S2, H, C, G))  # [B, N, H*C]
         with ev("to_out"):
             out = self.to_out[1](self._linear("to_out", self.to_out[0], out_x)).to(x.dtype)
+        if residual is not None:
+            out = out + residual
         if return_intermediates:
             if xs is not None:
                 x_lin = xs.to_float()

@@ -102,7 +102,7 @@ SIGNATURES = {
     "haet_erwin_lds_bytes": (c_size_t, [POINTER(ErwinDesc), c_int]),
     "haet_erwin_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, POINTER(ErwinDesc), POINTER(ErwinTrain), c_int, c_int, _P, _P]),
     "haet_deslice_out_supported": (c_int, [c_int, c_int, c_int, c_int]),
-    "haet_deslice_out_fwd_split": (c_int, [_P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P] + [c_int] * 6 + [_P, _P]),
+    "haet_deslice_out_fwd_split": (c_int, [_P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P] + [c_int] * 6 + [_P, _P]),
     "haet_erwin_train_workspace_bytes": (c_size_t, [POINTER(ErwinDesc), c_int]),
     "haet_token_stage_supported": (c_int, [POINTER(ErwinDesc), c_int, c_int]),
     "haet_token_stage_fwd": (c_int, [_P, c_int, c_int, c_float, _P, c_size_t, POINTER(ErwinDesc), POINTER(ErwinTrain),

@@ -35,8 +35,8 @@ class TransolverErwinBlockBase(nn.Module):
         if _fast.usable(fx):  # LayerNorms / MLP on the HIP kernels too, both directions (haet_amd/_fast.py)
             if _fast.enabled(fx):
                 # inference: ln_1 rides in the projection GEMM's loader, ln_2 in the MLP's first GEMM's
-                a = self.Attn(fx, pre_norm=self.ln_1)
-                fx = a.add_(fx)
+                # ... and the residual in the epilogue of the fused de-slice + to_out pass
+                fx = self.Attn(fx, pre_norm=self.ln_1, residual=True)
                 m = _fast.mlp(self.mlp, fx, pre_norm=self.ln_2)
                 if m is None:
                     m = self.mlp(_fast.layer_norm(self.ln_2, fx))

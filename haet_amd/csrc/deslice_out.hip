@@ -35,7 +35,7 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
     const float* __restrict__ x, const float* __restrict__ s_in, const float* __restrict__ Ws,
     const float* __restrict__ bs, float c0, const float* __restrict__ col_max, const float* __restrict__ col_sum,
     const float* __restrict__ S2, const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo,
-    const float* __restrict__ bias_out, int N, float* __restrict__ out) {
+    const float* __restrict__ bias_out, const float* __restrict__ residual, int N, float* __restrict__ out) {
     constexpr int M = 32 * MB, H = 8;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hf = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y;
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
     const float* xb = x + (size_t)b * N * H * kC;
     const float* sb = s_in + (size_t)b * N * H;
     float* ob = out + (size_t)b * N * kDO;
+    const float* rb = residual ? residual + (size_t)b * N * kDO : nullptr;  // out += residual (the block's `+ fx`)
 
     for (int i = threadIdx.x; i < H * M; i += 512) {
         *reinterpret_cast<float*>(smem + biasL + 4 * i) = bs[i % M] - c0;
@@ -198,6 +199,14 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[4 * i + q] = b4[q];
             }
+            // residual rows of this lane's point (the block's `Attn(ln_1(fx)) + fx`,
+            // HAETransolver_Irregular_Mesh.py:125): requested before the 48 MFMAs, added after them
+            f32x4 res[4];
+            if (rb) {  // (uniform; rows past the end: clamped, never stored)
+                const float* rrow = rb + (size_t)min(t * TN + l31, N - 1) * kDO + 32 * wave + 4 * hf;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) res[i] = *reinterpret_cast<const f32x4*>(rrow + 8 * i);
+            }
 #pragma unroll
             for (int h = 0; h < H; ++h) {
 #pragma unroll
@@ -213,7 +222,8 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
                 float* orow = ob + (size_t)(t * TN + l31) * kDO + 32 * wave + 4 * hf;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 v = {acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]};
+                    f32x4 v = {acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]};
+                    if (rb) v += res[i];
                     *reinterpret_cast<f32x4*>(orow + 8 * i) = v;
                 }
             }
@@ -225,7 +235,8 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
 template <int MB>
 static int deslice_out_launch(const float* x, const float* s_in, const float* Ws, const float* bs, float c0,
                               const float* cm, const float* cs, const float* S2, const unsigned short* Whi,
-                              const unsigned short* Wlo, const float* bias, int B, int N, float* out, hipStream_t st) {
+                              const unsigned short* Wlo, const float* bias, const float* residual, int B, int N,
+                              float* out, hipStream_t st) {
     constexpr int M = 32 * MB, H = 8;
     const size_t lds = (size_t)3 * H * 2 * IMG + H * TN * 4 + 2 * H * M * 4 + kDO * 4 + MB * 2 * IMG;
     auto kern = deslice_out_kernel<MB>;
@@ -239,7 +250,7 @@ static int deslice_out_launch(const float* x, const float* s_in, const float* Ws
     int wgs = 256 / (B < 1 ? 1 : B);
     if (wgs < 1) wgs = 1;
     dim3 grid(n_tiles < wgs ? n_tiles : wgs, B);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, x, s_in, Ws, bs, c0, cm, cs, S2, Whi, Wlo, bias, N, out);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, x, s_in, Ws, bs, c0, cm, cs, S2, Whi, Wlo, bias, residual, N, out);
     return check_launch("deslice_out_kernel");
 }
 
@@ -253,14 +264,15 @@ extern "C" int haet_deslice_out_supported(int H, int C, int M, int O) {
 
 extern "C" int haet_deslice_out_fwd_split(const float* cells, const float* s, const float* Ws, const float* bs, float c0,
                                           const float* col_max, const float* col_sum, const float* S2,
-                                          const uint16_t* Whi, const uint16_t* Wlo, const float* bias, int B, int N,
-                                          int H, int C, int M, int O, float* out, haet_stream_t stream) {
+                                          const uint16_t* Whi, const uint16_t* Wlo, const float* bias,
+                                          const float* residual, int B, int N, int H, int C, int M, int O, float* out,
+                                          haet_stream_t stream) {
     if (!cells || !s || !Ws || !bs || !col_max || !col_sum || !S2 || !Whi || !Wlo || !out)
         return fail(HAET_E_ARG, "deslice_out: null pointer");
     if (B < 1 || N < 1) return fail(HAET_E_ARG, "deslice_out: B=%d N=%d", B, N);
     if (!(H == 8 && C == 32 && O == 256 && (M == 32 || M == 64)))
         return fail(HAET_E_ARG, "deslice_out: H=%d C=%d M=%d O=%d outside the fused kernel's envelope (8 x 32 -> 256, M 32 / 64)", H, C, M, O);
     if (M == 32)
-        return deslice_out_launch<1>(cells, s, Ws, bs, c0, col_max, col_sum, S2, Whi, Wlo, bias, B, N, out, as_stream(stream));
-    return deslice_out_launch<2>(cells, s, Ws, bs, c0, col_max, col_sum, S2, Whi, Wlo, bias, B, N, out, as_stream(stream));
+        return deslice_out_launch<1>(cells, s, Ws, bs, c0, col_max, col_sum, S2, Whi, Wlo, bias, residual, B, N, out, as_stream(stream));
+    return deslice_out_launch<2>(cells, s, Ws, bs, c0, col_max, col_sum, S2, Whi, Wlo, bias, residual, B, N, out, as_stream(stream));
 }

@@ -518,14 +518,15 @@ def deslice_out_supported(H: int, C: int, M: int, O: int) -> bool:
 
 
 def deslice_out_split(xs: SplitPoints, p: SliceParams, col_max: Tensor, col_sum: Tensor, S2: Tensor, M: int,
-                      w: SplitLinear) -> Tensor:
+                      w: SplitLinear, residual: Optional[Tensor] = None) -> Tensor:
     """to_out(de-slice(...)) in one pass (haet_deslice_out_fwd_split): the [B, N, H*C] tensor between them is never
-    written.  `w`: the to_out Linear as split planes [O][H*C]."""
+    written.  `w`: the to_out Linear as split planes [O][H*C]; `residual` [B, N, O] is added to the output."""
     lib = _lib.load()
     B, N, _ = xs.cells.shape
     out = torch.empty((B, N, w.O), dtype=torch.float32, device=xs.cells.device)
     check(lib.haet_deslice_out_fwd_split(_p(xs.cells), _p(xs.s), _p(p.Ws), _p(p.bs), p.c0, _p(col_max), _p(col_sum),
-                                         _p(_f32(S2, "S2")), _p(w.hi), _p(w.lo), _p(w.bias), B, N, xs.H, xs.C, M, w.O,
+                                         _p(_f32(S2, "S2")), _p(w.hi), _p(w.lo), _p(w.bias),
+                                         _p(None if residual is None else _f32(residual, "residual")), B, N, xs.H, xs.C, M, w.O,
                                          _p(out), _stream()), "haet_deslice_out_fwd_split")
     return out
 

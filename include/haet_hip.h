@@ -233,6 +233,8 @@ int haet_deslice_out_supported(int H, int C, int M, int O);
 int haet_deslice_out_fwd_split(const float* cells, const float* s, const float* Ws, const float* bs, float c0,
                                const float* col_max, const float* col_sum, const float* S2,
                                const uint16_t* Whi, const uint16_t* Wlo, const float* bias,
+                               const float* residual /* [B, N, O] added to the output (the block's `+ fx`,
+                               HAETransolver_Irregular_Mesh.py:125), or NULL */,
                                int B, int N, int H, int C, int M, int O, float* out, haet_stream_t stream);
 
 /* ------------------------------------------------------------------ de-slice pass

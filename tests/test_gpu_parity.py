@@ -938,6 +938,10 @@ def test_deslice_out_fused_vs_fp64(N, M, hip_device):
     ox = torch.einsum("bhgc,bhng->bhnc", S2.double().reshape(B, H, M, C), w).permute(0, 2, 1, 3).reshape(B, N, H * C)
     ref = ox @ lin_out.weight.double().t() + lin_out.bias.double()
     assert O.rel_l2(out.cpu(), ref) < 5 * FP32_TOL
+    # the block's residual (`Attn(ln_1(fx)) + fx`) added in the same epilogue
+    res = torch.randn(B, N, D)
+    out_r = ops.deslice_out_split(xs, sp, cm, cs, S2.to(dev), M, w_out, res.to(dev))
+    assert torch.allclose(out_r.cpu(), out.cpu() + res, rtol=0, atol=1e-6 * float(out.abs().max() + res.abs().max()))
 
 
 @pytest.mark.parametrize("name", ["irr_c3like_amp", "irr_c3like_model", "irr_c3like_amp_train"])
