@@ -58,7 +58,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep", action="store_true",
+                    help="the reference's own harness instead of the headline bench: forward time and peak memory of "
+                         "HAETransolver_Irregular_Mesh at 1e3 .. 3e6 points (benchmarks/00-VelocityMemMocker/"
+                         "velocity-mem-checker.py), one JSON line")
+    ap.add_argument("--sweep-fp32", action="store_true", help="--sweep without torch.autocast (the reference runs under it)")
     args = ap.parse_args()
+    if args.sweep:
+        raise SystemExit(sweep_main(args))
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python3 bench.py --gpus N`: become the launcher -- N children under torch.distributed.run, started
@@ -185,6 +192,20 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sweep_main(args):
+    from haet_amd import _lib, harness
+
+    _lib.load()
+    torch.cuda.set_device(0)
+    rows = harness.sweep(autocast=not args.sweep_fp32, timed=max(1, min(args.steps, 10)), log=lambda m: print(m, file=sys.stderr))
+    print(json.dumps({"metric": "forward seconds and peak memory vs points, HAETransolver_Irregular_Mesh "
+                                "(velocity-mem-checker.py sweep)", "unit": "s", "n_gpus": 1, "data": "synthetic",
+                      "config": {"workload": "n_hidden=256, n_layers=1, n_head=8, mlp_ratio=2, out_dim=4, slice_num=32, "
+                                             "space_dim=3, fun_dim=1, batch 1, torch.rand inputs",
+                                 "autocast": not args.sweep_fp32}, "rows": rows}), flush=True)
+    return 0
 
 
 def self_launch(args):

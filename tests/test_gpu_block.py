@@ -221,3 +221,36 @@ def test_layernorm_narrow_linear_vs_fp64(rows, od, with_res, hip_device):
                               1e-5, W.to(hip_device), b.to(hip_device))
     assert out.shape == (rows, od)
     assert O.rel_l2(out.cpu().double(), ref) < 2e-6
+
+
+def test_reference_sweep_harness_small_sizes(hip_device):
+    """The velocity-mem-checker sweep (haet_amd.harness.sweep) at its two smallest sizes, with and without autocast."""
+    from haet_amd import harness
+
+    for ac in (True, False):
+        rows = harness.sweep(points=(1000, 10000), autocast=ac, timed=2, log=lambda m: None)
+        assert [r["points"] for r in rows] == [1000, 10000]
+        assert all(r["finite"] and r["seconds"] > 0 and r["peak_memory_mb"] > 0 for r in rows)
+
+
+def test_car_evaluation_on_cached_sample_format(tmp_path, hip_device):
+    """Cached-ShapeNetCar-format samples -> model -> the car benchmark's metrics, end to end on the device."""
+    import numpy as np
+
+    import haet_amd
+    from haet_amd import harness
+    from tests.test_harness_cpu import _write_samples
+
+    names = _write_samples(str(tmp_path), [3000, 2500])
+    samples, coef = harness.load_samples(str(tmp_path), names, norm=True)
+    torch.manual_seed(0)
+    model = haet_amd.HAETransolver_Irregular_Mesh(space_dim=7, fun_dim=0, n_hidden=64, n_layers=1, n_head=4, out_dim=4,
+                                                  slice_num=16).to(hip_device).eval()
+    ev = harness.CarEvaluation(coef)
+    with torch.no_grad():
+        for i, smp in enumerate(samples):
+            x, fx = harness.model_inputs(smp, hip_device)
+            out = model(x, fx)[0]
+            ev.add(out, smp.y, smp.surf, seconds=0.01, cd_true=0.3 + 0.1 * i, cd_pred=0.31 + 0.1 * i)
+    s = ev.summary()
+    assert s["samples"] == 2 and np.isfinite(s["rel_l2_press"]) and np.isfinite(s["rel_l2_velo"]) and abs(s["rho_d"] - 1) < 1e-12
