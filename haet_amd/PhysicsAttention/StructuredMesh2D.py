@@ -26,6 +26,9 @@ class Physics_Attention_Structured_Mesh_2D(PhysicsAttentionBase):
         g = x.reshape(B, self.H, self.W, D).permute(0, 3, 1, 2).contiguous()
         return self.in_project_x(g).permute(0, 2, 3, 1).reshape(B, N, -1)
 
+    def _prime_points(self):
+        return self.H * self.W
+
     def grid_shape(self):
         return (self.H, self.W)
 

@@ -26,6 +26,9 @@ class Physics_Attention_Structured_Mesh_3D(PhysicsAttentionBase):
         g = x.reshape(B, self.H, self.W, self.D, Dm).permute(0, 4, 1, 2, 3).contiguous()
         return self.in_project_x(g).permute(0, 2, 3, 4, 1).reshape(B, N, -1)
 
+    def _prime_points(self):
+        return self.H * self.W * self.D
+
     def grid_shape(self):
         return (self.H, self.W, self.D)
 

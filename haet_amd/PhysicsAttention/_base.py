@@ -23,6 +23,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from .. import _compile
 from .. import _lib as _lib_mod
 from .. import ops
 from ..components import ErwinFlashTransformer as ErwinTransformer
@@ -58,7 +59,7 @@ class _StageTimer:
         return False
 
 
-class PhysicsAttentionBase(nn.Module):
+class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
     dimensionality = 3
 
     def _init_common(self, dim, heads, dim_head, dropout, slice_num, base_temp, epsilon, c_hidden,
@@ -95,6 +96,7 @@ class PhysicsAttentionBase(nn.Module):
         self.stage_events = None  # set to [] to collect (stage, start, end) HIP events (bench.py)
         self.event_pool = None    # optional list of pre-recorded timing events the stage timer draws from
         self._slice_cache = None
+        _compile.register(self)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_caches())
 
     # -- per-variant projection to [B, N, H*C] -------------------------------------------
@@ -224,15 +226,42 @@ class PhysicsAttentionBase(nn.Module):
         self.__dict__["_grad_check_stale"] = True
         self.erwin.invalidate_caches()
 
-    @torch.compiler.disable  # torch.compile(model) (the reference's scripts): the HIP path is an opaque eager call
     def forward(self, x: torch.Tensor, return_intermediates: bool = False, pre_norm: Optional[nn.LayerNorm] = None,
                 residual: bool = False):
+        # Under torch.compile without gradients the module is ONE opaque operator of the graph (haet_amd/_compile.py);
+        # everything else is the eager path below, which Dynamo does not trace.
+        if _compile.use_operator(x) and not return_intermediates and pre_norm is None and not residual:
+            return torch.ops.haet.module_forward(x, _compile.primed_handle(self._haet_handle), x.shape[-1])
+        return self._forward_eager(x, return_intermediates, pre_norm, residual)
+
+    def _opaque_forward(self, x: torch.Tensor) -> torch.Tensor:  # body of haet::module_forward
+        return self._forward_eager(x)
+
+    def _prime_points(self) -> int:
+        """Points of the dummy cloud used to build the weight caches ahead of a compiled run (structured variants: the grid)."""
+        return 256
+
+    def _prime(self):
+        p = next(self.parameters())
+        if p.is_cuda:
+            was = self.training
+            self.eval()  # (no running-statistics update from a dummy input)
+            try:
+                lin = self.in_project_x
+                d_in = lin.in_features if isinstance(lin, nn.Linear) else lin.in_channels
+                self._forward_eager(torch.zeros(1, self._prime_points(), d_in, device=p.device))
+            finally:
+                self.train(was)
+
+    @torch.compiler.disable  # ctypes calls into libhaet_hip.so: an opaque eager call for Dynamo
+    def _forward_eager(self, x: torch.Tensor, return_intermediates: bool = False, pre_norm: Optional[nn.LayerNorm] = None,
+                       residual: bool = False):
         """`pre_norm`, `residual` (not in the reference's signature; used by the block's inference fast path): a
         LayerNorm to apply to x first -- fused into the projection GEMM's loader where the variant supports it -- and
         whether to return `forward(x) + x` (the block's residual, added in the fused de-slice + to_out epilogue)."""
         if residual:
             if not (x.is_cuda and not torch.is_grad_enabled() and not return_intermediates):
-                return self.forward(x, return_intermediates, pre_norm) + x
+                return self._forward_eager(x, return_intermediates, pre_norm) + x
             res_src = x
         if pre_norm is not None and not (x.is_cuda and not torch.is_grad_enabled() and not self.training
                                          and self.fuses_pre_norm(x, pre_norm)):
@@ -412,8 +441,9 @@ class PhysicsAttentionBase(nn.Module):
                 parts = allgather_records(local, self.shard_group)      # [R, record]
             col_max, col_sum, S = ops.merge_records(parts, B, H, C, G, finalize=True)
         with ev("erwin"):  # token positions are derived inside the tree launch (haet_tokens_tree_build)
+            self.erwin.__dict__["keep_positions"] = bool(return_intermediates)
             S2 = self.erwin(S, None, n_clouds=B * H)                     # [B*H*G, C]
-            pos = self.erwin.last_positions                              # [B*H*G, d]
+            pos = self.erwin.__dict__.get("last_positions")              # [B*H*G, d] (kept on request only)
         w_out = None
         if xs is not None and not return_intermediates and ops.deslice_out_supported(H, C, G, self.to_out[0].out_features):
             w_out = self._split_linear("to_out", self.to_out[0])

@@ -13,11 +13,11 @@ import torch.nn as nn
 import torch.utils.checkpoint as checkpoint
 from torch.nn.init import trunc_normal_
 
-from . import _fast
+from . import _compile, _fast
 from .components import MLP, timestep_embedding
 
 
-class TransolverErwinBlockBase(nn.Module):
+class TransolverErwinBlockBase(_compile.OpaqueForwardMixin, nn.Module):
     """LN -> Attn -> +res -> LN -> MLP -> +res [-> LN -> Linear]
     (HAETransolver_Irregular_Mesh.py:114-134)."""
 
@@ -30,8 +30,30 @@ class TransolverErwinBlockBase(nn.Module):
         if self.last_layer:
             self.ln_3 = nn.LayerNorm(hidden_dim)
             self.mlp2 = nn.Linear(hidden_dim, out_dim)
+        _compile.register(self)
 
     def forward(self, fx):
+        # torch.compile without gradients: the whole block is one opaque operator (haet_amd/_compile.py)
+        if _compile.use_operator(fx):
+            out = self.mlp2.out_features if self.last_layer else fx.shape[-1]
+            return torch.ops.haet.module_forward(fx, _compile.primed_handle(self._haet_handle), out)
+        return self._forward_eager(fx)
+
+    def _opaque_forward(self, fx):
+        return self._forward_eager(fx)
+
+    def _prime(self):
+        p = next(self.parameters())
+        if p.is_cuda:
+            was = self.training
+            self.eval()
+            try:
+                self._forward_eager(torch.zeros(1, self.Attn._prime_points(), self.ln_1.normalized_shape[0], device=p.device))
+            finally:
+                self.train(was)
+
+    @torch.compiler.disable
+    def _forward_eager(self, fx):
         if _fast.usable(fx):  # LayerNorms / MLP on the HIP kernels too, both directions (haet_amd/_fast.py)
             if _fast.enabled(fx):
                 # inference: ln_1 rides in the projection GEMM's loader, ln_2 in the MLP's first GEMM's
@@ -55,7 +77,27 @@ class TransolverErwinBlockBase(nn.Module):
         return fx
 
 
-class ModelBase(nn.Module):
+class _PreprocessOp:
+    """Handle target of haet::module_forward for a model's preprocess step (not an nn.Module: it must not appear in
+    the model's state_dict or module tree)."""
+
+    def __init__(self, model, with_placeholder: bool):
+        import weakref
+
+        self._model = weakref.ref(model)
+        self._with = with_placeholder
+
+    def _opaque_forward(self, inp):
+        return self._model()._preprocess(inp, self._with)
+
+    def _prime(self):
+        m = self._model()
+        lin = m.preprocess.linear_pre[0]
+        if lin.weight.is_cuda:
+            m._preprocess(torch.zeros(1, 256, lin.in_features, device=lin.weight.device), self._with)
+
+
+class ModelBase(_compile.OpaqueForwardMixin, nn.Module):
     placeholder_always = False  # irregular: always added; structured: only when fx is None
 
     def _init_model(self, make_block, in_dim, n_layers, n_hidden, act, Time_Input):
@@ -65,9 +107,20 @@ class ModelBase(nn.Module):
         self.blocks = nn.ModuleList([make_block(i == n_layers - 1) for i in range(n_layers)])
         self.initialize_weights()
         self.placeholder = nn.Parameter((1 / n_hidden) * torch.rand(n_hidden, dtype=torch.float))
+        self._after_copy()
+
+    def _after_copy(self):
+        # the preprocess step as opaque operators for torch.compile (without / with the placeholder)
+        pre = (_PreprocessOp(self, False), _PreprocessOp(self, True))
+        self.__dict__["_pre_ops"] = pre  # (strong references: the registry only holds weak ones)
+        self.__dict__["_pre_handles"] = (_compile.register(pre[0]), _compile.register(pre[1]))
 
     def initialize_weights(self):
         self.apply(self._init_weights)
+
+    @torch.compiler.disable
+    def _preprocess_eager(self, inp, with_placeholder: bool):
+        return self._preprocess(inp, with_placeholder)
 
     def _init_weights(self, m):
         # HAETransolver_Irregular_Mesh.py:279-295
@@ -92,18 +145,26 @@ class ModelBase(nn.Module):
     def unified_positions(self, x):
         raise NotImplementedError
 
+    def _preprocess(self, inp, with_placeholder: bool):
+        """preprocess MLP (+ placeholder): HIP fast path where it applies (inference: the placeholder rides in the last
+        Linear's bias), stock modules otherwise."""
+        fast = _fast.mlp(self.preprocess, inp, self.placeholder if with_placeholder else None)
+        if fast is not None:
+            return fast
+        fx = self.preprocess(inp)
+        if with_placeholder:
+            fx = fx + self.placeholder[None, None, :]
+        return fx
+
     def forward(self, x, fx, T=None):
         if self.unified_pos:
             x = self.unified_positions(x)
         inp = torch.cat((x, fx), -1) if fx is not None else x
         with_placeholder = fx is None or self.placeholder_always
-        fast = _fast.mlp(self.preprocess, inp, self.placeholder if with_placeholder else None)
-        if fast is not None:  # inference: the placeholder rides in the last Linear's bias
-            fx = fast
+        if _compile.use_operator(inp):  # torch.compile without gradients: one opaque operator (haet_amd/_compile.py)
+            fx = torch.ops.haet.module_forward(inp, _compile.primed_handle(self._pre_handles[1 if with_placeholder else 0]), self.n_hidden)
         else:
-            fx = self.preprocess(inp)
-            if with_placeholder:
-                fx = fx + self.placeholder[None, None, :]
+            fx = self._preprocess_eager(inp, with_placeholder)
         if T is not None:
             emb = timestep_embedding(T, self.n_hidden).repeat(1, x.shape[1], 1)
             fx = fx + self.time_fc(emb)

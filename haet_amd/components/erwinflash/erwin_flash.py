@@ -202,7 +202,7 @@ class ErwinTransformer(nn.Module):
         if node_positions is None and not os.environ.get("HAET_NO_TOKEN_STAGE") and ops.token_stage_supported(desc, n_clouds, M):
             out, node_positions = ops.token_stage(node_features, blob, desc, n_clouds, M, self.dimensionality,
                                                   self.strides, float(self.rotate), train)
-            self.__dict__["last_positions"] = node_positions
+            self.__dict__["last_positions"] = node_positions if self.__dict__.get("keep_positions", True) else None
             return out
         if node_positions is None:
             tree_idx, tree_mask, rot, _, node_positions = ops.balltree_build(
@@ -211,7 +211,7 @@ class ErwinTransformer(nn.Module):
         else:
             tree_idx, tree_mask, rot, _ = ops.balltree_build(
                 node_positions, n_clouds, M, self.strides, self.ball_sizes, float(self.rotate))
-        self.__dict__["last_positions"] = node_positions
+        self.__dict__["last_positions"] = node_positions if self.__dict__.get("keep_positions", True) else None
         return ops.erwin_fwd(node_features, node_positions, tree_idx, tree_mask, rot, blob, desc, n_clouds, M, train)
 
     def _train_state(self, desc, n_clouds, device):

@@ -166,8 +166,10 @@ def test_pre_norm_in_the_projection_matches_separate_layernorm(hip_device):
 
 @pytest.mark.parametrize("mode", ["reduce-overhead", "max-autotune-no-cudagraphs"])
 def test_model_under_torch_compile(mode, hip_device):
-    """The reference's scripts wrap the model in torch.compile: the HIP path stays an opaque eager call inside
-    whatever the compiler does with the rest, same numbers as the eager model."""
+    """The reference's scripts wrap the model in torch.compile (exp_airfoil.py:137 "max-autotune", exp_plas.py:177
+    "reduce-overhead").  Without gradients the model traces into ONE graph -- fullgraph=True raises on any graph break
+    -- whose HIP stages are haet::module_forward operators (custom_op + fake impl, haet_amd/_compile.py); with
+    "reduce-overhead" the whole forward, device-side ball tree included, replays as one captured HIP graph."""
     import haet_amd
 
     torch.manual_seed(3)
@@ -176,10 +178,34 @@ def test_model_under_torch_compile(mode, hip_device):
     x = torch.randn(1, 3000, 7, device=hip_device)
     with torch.no_grad():
         ref = model(x, None)
-        compiled = torch.compile(model, mode=mode)
-        out = compiled(x, None)
-        out2 = compiled(x, None)
-    assert O.rel_l2(out.cpu(), ref.cpu()) < 1e-5 and O.rel_l2(out2.cpu(), ref.cpu()) < 1e-5
+        compiled = torch.compile(model, mode=mode, fullgraph=True)
+        outs = [compiled(x, None).clone() for _ in range(4)]  # warm-up, capture, replays
+        x2 = torch.randn(1, 3000, 7, device=hip_device)
+        ref2 = model(x2, None)
+        out_x2 = compiled(x2, None).clone()  # same shapes, new data: a replay with refreshed inputs
+    for o in outs:
+        assert O.rel_l2(o.cpu(), ref.cpu()) < 1e-5
+    assert O.rel_l2(out_x2.cpu(), ref2.cpu()) < 1e-5
+
+
+def test_compiled_graph_holds_opaque_operators_only(hip_device):
+    """What Dynamo sees of a 2-layer model: one graph, the preprocess operator + one operator per block."""
+    import haet_amd
+
+    torch.manual_seed(4)
+    model = haet_amd.HAETransolver_Irregular_Mesh(space_dim=3, fun_dim=0, n_hidden=64, n_layers=2, n_head=4, out_dim=2,
+                                                  slice_num=16).eval().to(hip_device)
+    x = torch.randn(1, 1000, 3, device=hip_device)
+    with torch.no_grad():
+        ex = torch._dynamo.explain(model)(x, None)
+    assert ex.graph_break_count == 0, ex.break_reasons
+    names = [str(n.target) for g in ex.graphs for n in g.graph.nodes if n.op == "call_function"]
+    assert sum("haet.module_forward" in n for n in names) == 3, names
+    # an attention module compiled on its own is one operator too
+    att = model.blocks[0].Attn
+    with torch.no_grad():
+        ex = torch._dynamo.explain(att)(torch.randn(1, 1000, 64, device=hip_device))
+    assert ex.graph_break_count == 0 and ex.graph_count == 1
 
 
 def test_training_step_under_torch_compile(hip_device):
