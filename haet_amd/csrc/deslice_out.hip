@@ -30,12 +30,14 @@ namespace haet {
 
 constexpr int kDO = 256;  // outputs = H * C = 8 * 32
 
-template <int MB>
+template <int MB, bool RES>
 __global__ __launch_bounds__(512) void deslice_out_kernel(
     const float* __restrict__ x, const float* __restrict__ s_in, const float* __restrict__ Ws,
     const float* __restrict__ bs, float c0, const float* __restrict__ col_max, const float* __restrict__ col_sum,
     const float* __restrict__ S2, const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo,
-    const float* __restrict__ bias_out, const float* __restrict__ residual, int N, float* __restrict__ out) {
+    const float* __restrict__ bias_out, const float* __restrict__ residual, int N, float* __restrict__ out, int dbg) {
+    // dbg (HAET_DO_DBG, diagnostic runs only; 0 in production): 1 = no de-slice math, 2 = no GEMM MFMAs -- wave-uniform
+    // branches around matrix work only (none around a memory operation), results are wrong by construction
     constexpr int M = 32 * MB, H = 8;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hf = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y;
@@ -44,6 +46,8 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
     constexpr int XB = H * 2 * IMG;
     constexpr int sarr = XB, biasL = sarr + H * TN * 4, m2L = biasL + H * M * 4, boL = m2L + H * M * 4;
     constexpr int wimg = boL + kDO * 4, oimg0 = wimg + MB * 2 * IMG;
+    constexpr int sfL = oimg0 + XB;            // S'/l fragments [wave][gb][half][hi|lo][64 lanes] x 16 B
+    constexpr int SFW = MB * 2 * 2 * 1024;     // bytes per wave
     const float* xb = x + (size_t)b * N * H * kC;
     const float* sb = s_in + (size_t)b * N * H;
     float* ob = out + (size_t)b * N * kDO;
@@ -67,7 +71,8 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
         }
     }
     // S'/l fragments of this wave's head (A operand of the de-slice product: row c = l31, k = g in accumulator order)
-    Frag sf[MB][2];
+    // (kept in LDS, not in registers: with 128 registers of W_out the wave has none to spare, and a spilled
+    // register costs far more than the two ds_read_b128 per use)
     {
         const float* s2h = S2 + ((size_t)b * H + wave) * M * kC;
         const float* csh = col_sum + ((size_t)b * H + wave) * M;
@@ -81,7 +86,10 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
                     const int g = 32 * gb + 16 * s + 8 * (j >> 2) + 4 * hf + (j & 3);
                     v[j] = s2h[g * kC + l31] / csh[g];
                 }
-                sf[gb][s] = split8(v);
+                const Frag f = split8(v);
+                const int off = sfL + wave * SFW + (gb * 2 + s) * 2048 + lane * 16;
+                *reinterpret_cast<u32x4*>(smem + off) = f.hi;
+                *reinterpret_cast<u32x4*>(smem + off + 1024) = f.lo;
             }
         }
     }
@@ -93,21 +101,30 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
     // LDS byte offset of the hi half of cell i: rows 8 apart flip bit 1 of the chunk swizzle ((row >> 2) & 3)
     const int xoff0 = ximg + img_off(lr, lq >> 1) + ((lq & 1) << 3), xoff1 = ximg + img_off(lr + 8, lq >> 1) + ((lq & 1) << 3) - 512;
     auto xoff = [&](int i) { return ((i & 1) ? xoff1 : xoff0) + 512 * i; };
-    const unsigned x_voff = (unsigned)((lr * (H * kC) + wave * kC + 4 * lq) * 4);  // bytes from the tile's first row
     f32x4 xr[4];
     float sv = 1.f;
-    auto fetch = [&](int t) {  // rows past the end of the cloud read as zero cells (s = 1)
-        const int nvalid = N - t * TN;
-        const char* tb = reinterpret_cast<const char*>(xb) + (size_t)t * TN * (H * kC * 4);
+    // Every global load of the loop is UNCONDITIONAL (rows clamped to the cloud, tiles clamped to this workgroup's last
+    // one: a ghost fetch re-reads it): a load under a branch -- even a wave-uniform one -- makes hipcc's waitcnt pass give
+    // up counting and wait vmcnt(0) where the cells are staged, i.e. for the previous tile's output STORES as well
+    // (loads and stores share one in-order counter).  Rows past the end of the cloud read the last row again; their
+    // results are never stored.
+    auto fetch = [&](int t) {
+        const char* tb = reinterpret_cast<const char*>(xb);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (lr + 8 * i < nvalid) v = *reinterpret_cast<const f32x4*>(tb + x_voff + (unsigned)(8 * i * H * kC * 4));
-            xr[i] = v;
+            const int row = min(t * TN + lr + 8 * i, N - 1);
+            xr[i] = *reinterpret_cast<const f32x4*>(tb + (size_t)row * (H * kC * 4) + (wave * kC + 4 * lq) * 4);
         }
-        float s1 = 1.f;
-        if (lane < TN && lane < nvalid) s1 = sb[(size_t)(t * TN + lane) * H + wave];
-        sv = s1;
+        sv = sb[(size_t)min(t * TN + (lane & 31), N - 1) * H + wave];
+    };
+    // L2 touch two tiles ahead: one dword per 128-B line of this wave's block of a tile (32 rows x 128 B: two rows... one
+    // line per lane 0-31, the second half-wave the same lines), result folded into a word nothing reads.  The real 16-B
+    // loads of that tile, issued one iteration later, then find their lines in L2.
+    unsigned touch_acc = 0, touch_pend = 0;
+    auto touch = [&](int t) {
+        touch_acc ^= touch_pend;
+        const int row = min(t * TN + (lane & 31), N - 1);
+        touch_pend = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(xb) + (size_t)row * (H * kC * 4) + wave * (kC * 4));
     };
     auto stage = [&]() {
 #pragma unroll
@@ -117,23 +134,36 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
             *reinterpret_cast<u32x2*>(smem + xoff(i)) = hi;
             *reinterpret_cast<u32x2*>(smem + xoff(i) + IMG) = lo;
         }
-        if (lane < TN) *reinterpret_cast<float*>(smem + sarr + 4 * (wave * TN + lane)) = sv;
+        *reinterpret_cast<float*>(smem + sarr + 4 * (wave * TN + (lane & 31))) = sv;  // (both half-waves: same value)
     };
 
     const int t_begin = blockIdx.x;
     if (t_begin >= n_tiles) return;
+    const int t_last = t_begin + ((n_tiles - 1 - t_begin) / G) * G;  // this workgroup's last tile
     fetch(t_begin);
     stage();
-    if (t_begin + G < n_tiles) fetch(t_begin + G);
+    fetch(min(t_begin + G, t_last));
+    touch(min(t_begin + 2 * G, t_last));
+    {
+        // The loop's steady state has four output stores in flight behind these loads.  hipcc's waitcnt pass merges the
+        // loop-entry state with the back edge's conservatively: without the same four stores pending at the entry it
+        // waits, every iteration, for the previous tile's stores to drain before staging the cells (vmcnt(1) instead of
+        // vmcnt(5)).  So the prologue issues them too: zeros to this workgroup's first tile, overwritten by its [B].
+        const int rows0 = N - t_begin * TN < TN ? N - t_begin * TN : TN;
+        __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<char*>(ob) + (size_t)t_begin * TN * (kDO * 4), 0, rows0 * (kDO * 4), 0x00020000);
+        const int voff = l31 * (kDO * 4) + (32 * wave + 4 * hf) * 4;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(z, r0, voff + 32 * i, 0, 0);
+    }
     __syncthreads();  // constants (bias, m2, Ws images) staged by all threads
-    int cur = 0;
     // Tile t + G sits in registers while tile t is de-sliced; its cells go to LDS after [A], and the loads of tile
     // t + 2G are issued right then, so that they are in flight across the GEMM phase and the next de-slice phase
     // (a whole iteration) instead of across [A] alone.
     for (int t = t_begin; t < n_tiles; t += G) {
-        const bool more = t + G < n_tiles;
         const int nvalid = N - t * TN;
-        const int oimg = oimg0 + cur * XB;
+        const int oimg = oimg0;  // (single image: the second barrier below frees it for the next tile)
         // ---- [A] de-slice of head `wave`: Ot[c, n] (lane = point n, registers = channels)
         {
             const float sn = *reinterpret_cast<const float*>(smem + sarr + 4 * (wave * TN + l31));
@@ -142,6 +172,7 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
             for (int r = 0; r < 16; ++r) O[r] = 0.f;
 #pragma unroll
             for (int gb = 0; gb < MB; ++gb) {
+                if (dbg & 1) break;
                 // Short live ranges on purpose (the wave also holds 128 registers of W_out and the next tile's
                 // cells): the x fragments are re-read per column block, the column maxima read where they are used,
                 // and the column blocks are not interleaved.
@@ -168,7 +199,13 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
                         pv[j] = __builtin_amdgcn_exp2f(fmaf(Y[8 * half + j], sn, -ma[j]));
                         pv[4 + j] = __builtin_amdgcn_exp2f(fmaf(Y[8 * half + 4 + j], sn, -mb[j]));
                     }
-                    O = mfma3(sf[gb][half], split8(pv), O);
+                    Frag sfr;
+                    {
+                        const int off = sfL + wave * SFW + (gb * 2 + half) * 2048 + lane * 16;
+                        sfr.hi = *reinterpret_cast<const u32x4*>(smem + off);
+                        sfr.lo = *reinterpret_cast<const u32x4*>(smem + off + 1024);
+                    }
+                    O = mfma3(sfr, split8(pv), O);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -185,10 +222,9 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
                 *reinterpret_cast<u32x2*>(smem + off + IMG) = lo;
             }
         }
-        if (more) {
-            stage();  // this wave's own x block: nobody else reads it
-            if (t + 2 * G < n_tiles) fetch(t + 2 * G);
-        }
+        stage();  // this wave's own x block: nobody else reads it (after the last tile: a ghost)
+        fetch(min(t + 2 * G, t_last));
+        touch(min(t + 3 * G, t_last));
         __syncthreads();    // the tile's O image is complete
         // ---- [B] to_out: out^T[o, n] for o = 32 wave + (r&3) + 8 (r>>2) + 4 hf, n = l31
         {
@@ -202,13 +238,14 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
             // residual rows of this lane's point (the block's `Attn(ln_1(fx)) + fx`,
             // HAETransolver_Irregular_Mesh.py:125): requested before the 48 MFMAs, added after them
             f32x4 res[4];
-            if (rb) {  // (uniform; rows past the end: clamped, never stored)
+            if (RES) {  // (rows past the end: clamped, never stored)
                 const float* rrow = rb + (size_t)min(t * TN + l31, N - 1) * kDO + 32 * wave + 4 * hf;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) res[i] = *reinterpret_cast<const f32x4*>(rrow + 8 * i);
             }
 #pragma unroll
             for (int h = 0; h < H; ++h) {
+                if (dbg & 2) break;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const Frag of = read_rows(oimg + h * (2 * IMG), l31, 2 * s + hf);
@@ -218,18 +255,26 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
                     acc = mfma3(wf, of, acc);
                 }
             }
-            if (l31 < nvalid) {
-                float* orow = ob + (size_t)(t * TN + l31) * kDO + 32 * wave + 4 * hf;
+            // Stores through a buffer descriptor over THIS tile's valid rows: rows past the end of the cloud fall outside
+            // its range and the hardware drops them -- no branch around the stores (a conditional store, like a
+            // conditional load, costs the loop its counted waits), no per-lane address clamping.
+            {
+                const int rows = nvalid < TN ? nvalid : TN;
+                __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    reinterpret_cast<char*>(ob) + (size_t)t * TN * (kDO * 4), 0, rows * (kDO * 4), 0x00020000);
+                const int voff = l31 * (kDO * 4) + (32 * wave + 4 * hf) * 4;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     f32x4 v = {acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]};
-                    if (rb) v += res[i];
-                    *reinterpret_cast<f32x4*>(orow + 8 * i) = v;
+                    if (RES) v += res[i];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff + 32 * i, 0, 0);
                 }
             }
         }
-        cur ^= 1;
+        __syncthreads();  // every wave has read the O image
     }
+    touch_acc ^= touch_pend;
+    asm volatile("" ::"v"(touch_acc));
 }
 
 template <int MB>
@@ -238,19 +283,23 @@ static int deslice_out_launch(const float* x, const float* s_in, const float* Ws
                               const unsigned short* Wlo, const float* bias, const float* residual, int B, int N,
                               float* out, hipStream_t st) {
     constexpr int M = 32 * MB, H = 8;
-    const size_t lds = (size_t)3 * H * 2 * IMG + H * TN * 4 + 2 * H * M * 4 + kDO * 4 + MB * 2 * IMG;
-    auto kern = deslice_out_kernel<MB>;
+    const size_t lds = (size_t)2 * H * 2 * IMG + H * TN * 4 + 2 * H * M * 4 + kDO * 4 + MB * 2 * IMG + (size_t)H * MB * 4096;
+    auto kern = residual ? deslice_out_kernel<MB, true> : deslice_out_kernel<MB, false>;
     static PerDeviceOnce attr;
     if (!attr.done()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(HAET_E_LAUNCH, "deslice_out: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        for (const void* k : {reinterpret_cast<const void*>(deslice_out_kernel<MB, true>),
+                              reinterpret_cast<const void*>(deslice_out_kernel<MB, false>)}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail(HAET_E_LAUNCH, "deslice_out: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
         attr.set();
     }
     const int n_tiles = (N + TN - 1) / TN;
     int wgs = 256 / (B < 1 ? 1 : B);
     if (wgs < 1) wgs = 1;
     dim3 grid(n_tiles < wgs ? n_tiles : wgs, B);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, x, s_in, Ws, bs, c0, cm, cs, S2, Whi, Wlo, bias, residual, N, out);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, x, s_in, Ws, bs, c0, cm, cs, S2, Whi, Wlo, bias, residual, N, out,
+                       getenv("HAET_DO_DBG") ? atoi(getenv("HAET_DO_DBG")) : 0);
     return check_launch("deslice_out_kernel");
 }
 
