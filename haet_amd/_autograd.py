@@ -183,8 +183,13 @@ class PhysicsAttentionFunction(torch.autograd.Function):
                 parts = allgather_records(ops.merge_records(parts, B, H, C, G, finalize=False), mod.shard_group)
             col_max, col_sum, S = ops.merge_records(parts, B, H, C, G, finalize=True)
         ctx.inner = None
+        ctx.erwin_ctx = None
         with ev("erwin"):
-            if mod.training:  # batch-statistics BatchNorm: the restatement runs now and keeps its graph
+            if mod.erwin.hip_backward_supported(B * H, G):
+                # the stage on the HIP kernel in either mode (train: BatchNorm on batch statistics over all clouds,
+                # running statistics updated), with the tape its hand-written backward (haet_erwin_bwd) reads
+                S2, ctx.erwin_ctx = mod.erwin.forward_taped(S, B * H)
+            elif mod.training:  # batch-statistics BatchNorm: the restatement runs now and keeps its graph
                 with torch.enable_grad(), torch.autocast("cuda", enabled=False):
                     S_leaf = S.detach().requires_grad_(True)
                     S2_graph = _tokens_through_erwin(mod, S_leaf, B * H)
@@ -233,13 +238,18 @@ class PhysicsAttentionFunction(torch.autograd.Function):
 
         with ev("bwd_erwin"):
             erwin_params = [p for p in mod.erwin.parameters() if id(p) in wanted]
-            if ctx.inner is None:
+            if ctx.erwin_ctx is not None:  # hand-written backward of the whole stage, one launch
+                dS, by_param = mod.erwin.backward_hip(ctx.erwin_ctx, dS2)
+                ctx.erwin_ctx = None
+                got = [dS] + [by_param.get(id(p)) for p in erwin_params]
+            elif ctx.inner is None:
                 with torch.enable_grad(), torch.autocast("cuda", enabled=False):
                     S_leaf = S.detach().requires_grad_(True)
                     S2_graph = _tokens_through_erwin(mod, S_leaf, B * H)
+                got = torch.autograd.grad(S2_graph, [S_leaf] + erwin_params, dS2, allow_unused=True)
             else:
                 S_leaf, S2_graph = ctx.inner
-            got = torch.autograd.grad(S2_graph, [S_leaf] + erwin_params, dS2, allow_unused=True)
+                got = torch.autograd.grad(S2_graph, [S_leaf] + erwin_params, dS2, allow_unused=True)
             ctx.inner = None
             dS = got[0] if got[0] is not None else torch.zeros_like(S)
             for p, g in zip(erwin_params, got[1:]):  # replicated: each rank reports its additive share (sharding.py)

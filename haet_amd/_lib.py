@@ -44,11 +44,28 @@ class ErwinDesc(ctypes.Structure):
                 ("pool", ErwinResample * MAX_LEVELS), ("unpool", ErwinResample * MAX_LEVELS)]
 
 
+class ErwinBlockF32(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in (
+        "norm1", "norm2", "pe_w", "pe_b", "qkv_w", "qkv_wT", "qkv_b", "proj_w", "proj_wT", "proj_b",
+        "w1_w", "w1_wT", "w1_b", "w2_w", "w2_wT", "w2_b", "w3_w", "w3_wT", "w3_b")]
+
+
+class ErwinResampleF32(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in ("w", "wT", "b", "gamma", "beta", "rmean", "rvar")]
+
+
+class ErwinF32Layout(ctypes.Structure):
+    """haet_erwin_f32_layout (include/haet_hip.h): float offsets of the fp32 weight blob of haet_erwin_bwd."""
+    _fields_ = [("total", c_int32), ("pad", c_int32 * 3),
+                ("enc", (ErwinBlockF32 * MAX_DEPTH) * MAX_LEVELS), ("dec", (ErwinBlockF32 * MAX_DEPTH) * MAX_LEVELS),
+                ("pool", ErwinResampleF32 * MAX_LEVELS), ("unpool", ErwinResampleF32 * MAX_LEVELS)]
+
+
 class ErwinTrain(ctypes.Structure):
     """haet_erwin_train (include/haet_hip.h): device pointers of the train-mode BatchNorm state."""
     _fields_ = [("running_mean", c_void_p * (2 * MAX_LEVELS)), ("running_var", c_void_p * (2 * MAX_LEVELS)),
                 ("num_batches_tracked", c_void_p * (2 * MAX_LEVELS)), ("batch_stats", c_void_p),
-                ("workspace", c_void_p)]
+                ("workspace", c_void_p), ("tape", c_void_p), ("tape_op_floats", c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/haet_hip.h declares
@@ -103,6 +120,9 @@ SIGNATURES = {
     "haet_erwin_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, POINTER(ErwinDesc), POINTER(ErwinTrain), c_int, c_int, _P, _P]),
     "haet_deslice_out_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "haet_deslice_out_fwd_split": (c_int, [_P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P] + [c_int] * 6 + [_P, _P]),
+    "haet_erwin_tape_floats": (c_size_t, [POINTER(ErwinDesc), c_int, POINTER(c_int), POINTER(c_int)]),
+    "haet_erwin_bwd_supported": (c_int, [POINTER(ErwinDesc), c_int, c_int]),
+    "haet_erwin_bwd": (c_int, [_P] * 8 + [POINTER(ErwinDesc), _P, _P, c_int, c_int, _P, _P, _P]),
     "haet_erwin_train_workspace_bytes": (c_size_t, [POINTER(ErwinDesc), c_int]),
     "haet_token_stage_supported": (c_int, [POINTER(ErwinDesc), c_int, c_int]),
     "haet_token_stage_fwd": (c_int, [_P, c_int, c_int, c_float, _P, c_size_t, POINTER(ErwinDesc), POINTER(ErwinTrain),

@@ -214,6 +214,61 @@ class ErwinTransformer(nn.Module):
         self.__dict__["last_positions"] = node_positions if self.__dict__.get("keep_positions", True) else None
         return ops.erwin_fwd(node_features, node_positions, tree_idx, tree_mask, rot, blob, desc, n_clouds, M, train)
 
+    # ------------------------------------------------------------------ training: forward with a tape, HIP backward
+    def packed_f32(self):
+        """(fp32 blob, layout, [(parameter, offset)]) for haet_erwin_bwd, rebuilt only when a parameter changed."""
+        from .pack import pack_erwin_f32
+
+        key = self._pack_key()
+        hit = self.__dict__.get("_packed_f32")
+        if hit is None or hit[0] != key:
+            hit = (key,) + tuple(pack_erwin_f32(self))
+            self.__dict__["_packed_f32"] = hit
+        return hit[1], hit[2], hit[3]
+
+    def hip_backward_supported(self, n_clouds: int, M: int) -> bool:
+        if os.environ.get("HAET_TORCH_ERWIN_BWD") or not self.decode:
+            return False
+        _, desc = self.packed()
+        return ops.erwin_bwd_supported(desc, n_clouds, M)
+
+    def forward_taped(self, tokens: torch.Tensor, n_clouds: int):
+        """Forward of the stage (positions from the tokens, tree, Erwin; BatchNorm per self.training) that also records
+        what haet_erwin_bwd needs.  Returns (tokens', ctx)."""
+        T = tokens.shape[0]
+        M = T // n_clouds
+        blob, desc = self.packed()
+        st = self._train_state(desc, n_clouds, tokens.device)  # (eval: only its tape slot is used)
+        tape, opf = ops.erwin_tape(desc, n_clouds, M, tokens.device)
+        st.set_tape(tape, opf)
+        try:
+            if not os.environ.get("HAET_NO_TOKEN_STAGE") and ops.token_stage_supported(desc, n_clouds, M):
+                out, pos, tree_idx, tree_mask, rot, _ = ops.token_stage(tokens, blob, desc, n_clouds, M, self.dimensionality,
+                                                                        self.strides, float(self.rotate), st, want_tree=True)
+            else:
+                tree_idx, tree_mask, rot, _, pos = ops.balltree_build(None, n_clouds, M, self.strides, self.ball_sizes,
+                                                                      float(self.rotate), tokens=tokens, d=self.dimensionality)
+                out = ops.erwin_fwd(tokens, pos, tree_idx, tree_mask, rot, blob, desc, n_clouds, M, st)
+        finally:
+            st.set_tape(None)
+        stats = st.batch_stats.clone() if self.training else None
+        ctx = dict(tape=tape, pos=pos, tree_idx=tree_idx, tree_mask=tree_mask, rot=rot, blob=blob, desc=desc,
+                   n_clouds=n_clouds, M=M, stats=stats, workspace=st.workspace)
+        return out, ctx
+
+    def backward_hip(self, ctx, g_out: torch.Tensor):
+        """haet_erwin_bwd on a forward_taped context: (dL/d tokens, {parameter: gradient})."""
+        blob32, lay, pmap = self.packed_f32()
+
+        class _St:  # what ops.erwin_bwd reads of a train state
+            batch_stats, workspace = ctx["stats"], ctx["workspace"]
+
+        g_in, per_cloud = ops.erwin_bwd(g_out, ctx["tape"], ctx["pos"], ctx["tree_idx"], ctx["tree_mask"], ctx["rot"], blob32,
+                                        lay.total, ctx["blob"], ctx["desc"], ctx["n_clouds"], ctx["M"],
+                                        _St if ctx["stats"] is not None else None)
+        gsum = per_cloud.sum(dim=0)
+        return g_in, {id(p): gsum[off:off + p.numel()].view_as(p) for p, off in pmap}
+
     def _train_state(self, desc, n_clouds, device):
         """ops.ErwinTrainState for this (weights object set, cloud count): pointers to the BatchNorm running
         statistics (updated in place by the kernel), batch-statistics output, grid-barrier workspace."""

@@ -131,3 +131,62 @@ def pack_erwin(erwin):
         _fill_layer(desc.dec[lvl], layer, blob)
         _fill_resample(desc.unpool[lvl], layer.unpool, blob, train)
     return blob.tensor(desc), desc
+
+
+# --------------------------------------------------------------------------- fp32 blob of the backward kernel
+def pack_erwin_f32(erwin):
+    """(blob, layout, param_map) for haet_erwin_bwd: every tensor in fp32, Linear weights in PyTorch's [out][in]
+    layout AND transposed (the kernel reads whichever makes its loads coalesced); the blob BEGINS WITH the layout
+    (include/haet_hip.h haet_erwin_f32_layout).  `param_map`: [(parameter, offset)] -- where each parameter's gradient
+    sits in a cloud's slice of the kernel's `grads` output."""
+    from ..._lib import ErwinF32Layout
+
+    n_levels = len(erwin.encoder) + 1
+    device = next(erwin.parameters()).device
+    lay = ErwinF32Layout()
+    head = (ctypes.sizeof(ErwinF32Layout) + 15) // 16 * 4
+    chunks, pmap = [], []
+    state = {"n": head}
+
+    def add(t, param=None):
+        t = t.detach().float().reshape(-1)
+        off = state["n"]
+        chunks.append(t.to(device))
+        state["n"] += t.numel()
+        pad = (-state["n"]) % 4
+        if pad:
+            chunks.append(torch.zeros(pad, device=device))
+            state["n"] += pad
+        if param is not None:
+            pmap.append((param, off))
+        return off
+
+    def fill_block(dst, blk):
+        a = blk.BMSA
+        dst.norm1, dst.norm2 = add(blk.norm1.weight, blk.norm1.weight), add(blk.norm2.weight, blk.norm2.weight)
+        dst.pe_w, dst.pe_b = add(a.pe_proj.weight, a.pe_proj.weight), add(a.pe_proj.bias, a.pe_proj.bias)
+        for name, lin in (("qkv", a.qkv), ("proj", a.proj), ("w1", blk.swiglu.w1), ("w2", blk.swiglu.w2), ("w3", blk.swiglu.w3)):
+            setattr(dst, name + "_w", add(lin.weight, lin.weight))
+            setattr(dst, name + "_wT", add(lin.weight.detach().t().contiguous()))
+            setattr(dst, name + "_b", add(lin.bias, lin.bias))
+
+    def fill_resample(dst, mod):
+        dst.w, dst.wT = add(mod.proj.weight, mod.proj.weight), add(mod.proj.weight.detach().t().contiguous())
+        dst.b = add(mod.proj.bias, mod.proj.bias)
+        dst.gamma, dst.beta = add(mod.norm.weight, mod.norm.weight), add(mod.norm.bias, mod.norm.bias)
+        dst.rmean, dst.rvar = add(mod.norm.running_mean), add(mod.norm.running_var)
+
+    for i, layer in enumerate(erwin.encoder):
+        for j, blk in enumerate(layer.blocks):
+            fill_block(lay.enc[i][j], blk)
+        fill_resample(lay.pool[i], layer.pool)
+    for j, blk in enumerate(erwin.bottleneck.blocks):
+        fill_block(lay.enc[n_levels - 1][j], blk)
+    for k, layer in enumerate(erwin.decoder):
+        lvl = n_levels - 2 - k
+        for j, blk in enumerate(layer.blocks):
+            fill_block(lay.dec[lvl][j], blk)
+        fill_resample(lay.unpool[lvl], layer.unpool)
+    lay.total = state["n"]
+    hdr = torch.frombuffer(bytearray(bytes(lay)) + bytearray(head * 4 - ctypes.sizeof(lay)), dtype=torch.float32).to(device)
+    return torch.cat([hdr] + chunks).contiguous(), lay, pmap

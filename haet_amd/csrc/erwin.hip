@@ -733,6 +733,10 @@ struct ErwinTrain {
     unsigned* tmo;    // set to 1 if a barrier gave up (bounded spin)
     float* partial;   // [2*MAX_LEVELS][n_clouds][2][cmax]
     int cmax, on;
+    // tape for the backward kernel (erwin_bwd.hip), independent of `on`: the tokens of the op's input level at the
+    // start of every op, [n_clouds][n_ops][tape_op_floats] (rows of c floats, no padding); nullptr: not recorded
+    float* tape;
+    int tape_op_floats;
 };
 
 // Counter barrier over the workgroups of the launch (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md
@@ -1097,6 +1101,12 @@ __global__ __launch_bounds__(512) void erwin_kernel(
     for (int op = 0; op < nops; ++op) {
         int kind = 0, a = 0, b = 0;
         op_at(op, kind, a, b);
+        if (tr.tape) {  // (uniform) checkpoint for the backward: this op's input tokens
+            const int lv = kind == 2 ? a + 1 : a;
+            const int Xl = T(T_X + lv), nlv = T(T_N + lv), ldl = T(T_LD + lv), cl = D.enc[lv].c;
+            float* tp = tr.tape + ((size_t)cloud * nops + op) * tr.tape_op_floats;
+            for (int i = threadIdx.x; i < nlv * cl; i += kErwinThreads) tp[i] = F(Xl + 4 * ((i / cl) * ldl + i % cl));
+        }
         if (kind == 0) {
             const haet_erwin_layer& L = (b & 256) ? D.dec[a] : D.enc[a];
             const int j = b & 255;
@@ -1182,6 +1192,11 @@ extern "C" size_t haet_erwin_lds_bytes(const haet_erwin_desc* desc, int Mp) {
 static int erwin_train_args(const haet_erwin_desc* desc, const haet_erwin_train* train, int n_clouds,
                             hipStream_t stream, ErwinTrain* out) {
     ErwinTrain t = {};
+    if (train && train->tape) {
+        t.tape = train->tape;
+        t.tape_op_floats = train->tape_op_floats;
+        if (t.tape_op_floats < 1) return fail(HAET_E_ARG, "erwin: tape given without tape_op_floats");
+    }
     if (!desc->bn_train) {
         *out = t;
         return HAET_OK;

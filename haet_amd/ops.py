@@ -149,12 +149,19 @@ def balltree_build(pos: Optional[Tensor], n_clouds: int, M: int, strides: Sequen
 class ErwinTrainState:
     """Device plumbing of train-mode BatchNorm for haet_erwin_fwd / haet_token_stage_fwd (include/haet_hip.h
     haet_erwin_train): running statistics of the pool / unpool norms (updated in place by the kernel), the
-    batch statistics of the forward (kept for the backward) and the grid-barrier workspace."""
+    batch statistics of the forward (kept for the backward) and the grid-barrier workspace.  `set_tape` attaches
+    the tape the backward kernel reads (also used, without the BatchNorm part, in eval mode)."""
+
+    def set_tape(self, tape: Optional[Tensor], op_floats: int = 0):
+        self.tape = tape
+        self.c.tape = 0 if tape is None else tape.data_ptr()
+        self.c.tape_op_floats = int(op_floats)
 
     def __init__(self, erwin, desc, n_clouds: int, device):
         lib = _lib.load()
         self.c = _lib.ErwinTrain()
         self.keep = []
+        self.tape = None
         n_levels = len(erwin.encoder) + 1
         cmax = max(erwin.c_hidden)
         self.batch_stats = torch.zeros((2 * _lib.MAX_LEVELS, 2, cmax), dtype=torch.float32, device=device)
@@ -190,6 +197,34 @@ def erwin_fwd(tokens: Tensor, pos: Tensor, tree_idx: Tensor, tree_mask: Tensor, 
                              n_clouds, M, _p(out), _stream()),
           "haet_erwin_fwd")
     return out
+
+
+def erwin_tape(desc: "_lib.ErwinDesc", n_clouds: int, M: int, device):
+    """(tape tensor [n_clouds, n_ops * op_floats], op_floats) for the forward to record and haet_erwin_bwd to read."""
+    lib = _lib.load()
+    n_ops, opf = ctypes.c_int(0), ctypes.c_int(0)
+    per = lib.haet_erwin_tape_floats(ctypes.byref(desc), M, ctypes.byref(n_ops), ctypes.byref(opf))
+    return torch.empty((n_clouds, per), dtype=torch.float32, device=device), opf.value
+
+
+def erwin_bwd_supported(desc: "_lib.ErwinDesc", n_clouds: int, M: int) -> bool:
+    return bool(_lib.load().haet_erwin_bwd_supported(ctypes.byref(desc), n_clouds, M))
+
+
+def erwin_bwd(g_out: Tensor, tape: Tensor, pos: Tensor, tree_idx: Tensor, tree_mask: Tensor, rot: Optional[Tensor],
+              blob_f32: Tensor, total: int, blob_fwd: Tensor, desc: "_lib.ErwinDesc", n_clouds: int, M: int,
+              train: Optional[ErwinTrainState] = None):
+    """haet_erwin_bwd -> (dL/d tokens [n_clouds*M, c0], grads [n_clouds, total]: every parameter gradient per cloud,
+    at the offsets of the fp32 blob's layout)."""
+    lib = _lib.load()
+    g_out = _f32(g_out, "g_out")
+    g_in = torch.empty_like(g_out)
+    grads = torch.zeros((n_clouds, total), dtype=torch.float32, device=g_out.device)
+    check(lib.haet_erwin_bwd(_p(g_out), _p(tape), _p(pos), _p(tree_idx), _p(tree_mask), _p(rot), _p(blob_f32), _p(blob_fwd),
+                             ctypes.byref(desc), _p(train.batch_stats if train is not None else None),
+                             _p(train.workspace if train is not None else None), n_clouds, M, _p(g_in), _p(grads),
+                             _stream()), "haet_erwin_bwd")
+    return g_in, grads
 
 
 def token_stage_supported(desc: "_lib.ErwinDesc", n_clouds: int, M: int) -> bool:

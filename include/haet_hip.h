@@ -202,6 +202,11 @@ typedef struct {
     long long* num_batches_tracked[2 * HAET_ERWIN_MAX_LEVELS];
     float* batch_stats; /* out (may be NULL): [2*HAET_ERWIN_MAX_LEVELS][2][cmax] batch mean, 1/sqrt(var+eps); cmax = max channels */
     void* workspace;    /* device, haet_erwin_train_workspace_bytes() bytes, caller-owned scratch */
+    /* Tape for haet_erwin_bwd (also honoured with desc->bn_train == 0): the input tokens of every op of the stage
+     * (blocks, pools, unpools in execution order), [n_clouds][n_ops][tape_op_floats] fp32; NULL: not recorded.
+     * tape_op_floats >= max over the levels of tokens * channels (haet_erwin_tape_floats gives n_ops * that). */
+    float* tape;
+    int32_t tape_op_floats;
 } haet_erwin_train;
 
 size_t haet_erwin_train_workspace_bytes(const haet_erwin_desc* desc, int n_clouds);
@@ -223,6 +228,45 @@ int haet_token_stage_fwd(const float* S, int n_clouds, int M, float angle_deg, c
                          size_t weight_floats, const haet_erwin_desc* desc, const haet_erwin_train* train,
                          float* pos_out, int32_t* tree_idx, uint8_t* tree_mask, int32_t* rot, float* out,
                          haet_stream_t stream);
+
+/* ------------------------------------------------------------------ Erwin stage, backward
+ * Backward of haet_erwin_fwd / haet_token_stage_fwd (the training scripts call loss.backward(),
+ * exp_airfoil.py:249-255) in ONE launch, one workgroup per cloud: every block / pool / unpool is recomputed from its
+ * taped input (haet_erwin_train.tape) in fp32 and differentiated -- RMSNorm, rel-pos PE, QKV, per-ball softmax
+ * attention, proj, SwiGLU, BallPooling / BallUnpooling with eval- or train-mode BatchNorm (train: the cross-cloud
+ * terms of the BatchNorm backward meet at a grid barrier, <= 256 clouds).  Positions carry no gradient (the
+ * reference computes rel_pos / centres under no_grad: attention.py:35, pooling.py:29,59).
+ *
+ * Weights come as ONE fp32 blob that BEGINS WITH haet_erwin_f32_layout (offsets in floats of every tensor, original
+ * [out][in] layout `*_w` and its transpose `*_wT`), laid out by haet_amd/components/erwinflash/pack.py; `grads`
+ * [n_clouds][layout.total] receives every parameter gradient of each cloud at the SAME offsets (the caller sums over
+ * the clouds; the `*_wT` / statistics slots stay untouched). */
+typedef struct {
+    int32_t norm1, norm2, pe_w /* [c][d] */, pe_b, qkv_w, qkv_wT, qkv_b, proj_w, proj_wT, proj_b,
+            w1_w, w1_wT, w1_b, w2_w, w2_wT, w2_b, w3_w, w3_wT, w3_b;
+} haet_erwin_block_f32;
+typedef struct {
+    int32_t w, wT, b, gamma, beta, rmean, rvar;
+} haet_erwin_resample_f32;
+typedef struct {
+    int32_t total;  /* floats in the blob (header included) */
+    int32_t pad[3];
+    haet_erwin_block_f32 enc[HAET_ERWIN_MAX_LEVELS][HAET_ERWIN_MAX_DEPTH];
+    haet_erwin_block_f32 dec[HAET_ERWIN_MAX_LEVELS][HAET_ERWIN_MAX_DEPTH];
+    haet_erwin_resample_f32 pool[HAET_ERWIN_MAX_LEVELS];
+    haet_erwin_resample_f32 unpool[HAET_ERWIN_MAX_LEVELS];
+} haet_erwin_f32_layout;
+
+size_t haet_erwin_tape_floats(const haet_erwin_desc* desc, int M, int* n_ops, int* op_floats); /* per cloud */
+int haet_erwin_bwd_supported(const haet_erwin_desc* desc, int n_clouds, int M);
+int haet_erwin_bwd(const float* g_out /*[n_clouds*M, c0] dL/d tokens'*/, const float* tape, const float* pos,
+                   const int32_t* tree_idx, const uint8_t* tree_mask, const int32_t* rot,
+                   const float* weights_f32 /* begins with haet_erwin_f32_layout */,
+                   const float* weights_fwd /* the forward's blob (begins with the descriptor) */,
+                   const haet_erwin_desc* desc, const float* bn_batch_stats /* train: haet_erwin_train.batch_stats */,
+                   void* workspace /* train: haet_erwin_train_workspace_bytes() */, int n_clouds, int M,
+                   float* g_in /*[n_clouds*M, c0] dL/d tokens*/, float* grads /*[n_clouds][layout.total]*/,
+                   haet_stream_t stream);
 
 /* ------------------------------------------------------------------ de-slice + to_out in one pass
  * Replaces einsum('bhgc,bhng->bhnc') + rearrange + self.to_out[0] (models/PhysicsAttention/IrregularMesh.py:221-235)

@@ -50,7 +50,7 @@ def test_erwin_desc_struct_matches_header_size():
     # 5 ints + 8 layers of (5 + 4*16) ints + 8 resamples of 7 ints and 2 floats
     assert ctypes.sizeof(_lib.ErwinDesc) == 4 * (5 + 8 * (5 + 4 * 16) + 8 * 9)
     # haet_erwin_train: 3 pointer tables of 2 * MAX_LEVELS + 2 pointers
-    assert ctypes.sizeof(_lib.ErwinTrain) == 8 * (3 * 2 * _lib.MAX_LEVELS + 2)
+    assert ctypes.sizeof(_lib.ErwinTrain) == 8 * (3 * 2 * _lib.MAX_LEVELS + 4)  # + tape pointer, tape_op_floats (padded)
     assert _lib.load().haet_erwin_train_workspace_bytes(ctypes.byref(_lib.ErwinDesc()), 8) >= 64
     d = _lib.ErwinDesc()
     assert _lib.load().haet_erwin_lds_bytes(ctypes.byref(d), 64) == 0  # invalid desc -> 0

@@ -145,8 +145,11 @@ def test_module_gradients_vs_device_restatement(kind, train, hip_device):
             assert gp[name] is None or float(gp[name].abs().max()) == 0.0, name
             continue
         assert gp[name] is not None, name
-        err = float((gp[name] - g_ref).norm()) / max(float(g_ref.norm()), 1e-4 * scale)
-        assert err < 2e-3, (name, err)
+        diff = float((gp[name] - g_ref).norm())
+        err = diff / max(float(g_ref.norm()), 1e-4 * scale)
+        # (the Erwin stage's backward is the HIP kernel now, the reference side torch autograd: a gradient that cancels
+        # to ~0 -- a bias in front of a train-mode BatchNorm -- is fp32 noise on both sides, held to the largest gradient)
+        assert err < 2e-3 or diff < 2e-5 * scale, (name, err, diff / scale)
 
 
 def test_backward_never_materialises_the_slice_weights(hip_device):
@@ -237,3 +240,50 @@ def test_module_gradients_vs_reference_fixture(name, hip_device):
             assert err < 5e-3, (pn, err)
         else:
             assert pn in nograd and (p.grad is None or float(p.grad.abs().max()) == 0.0), pn
+
+
+@pytest.mark.parametrize("name", ["irr_small_amp", "irr_small_amp_train", "irr_b2_amp", "irr_b2_amp_train", "irr_norot_amp",
+                                  "irr_c3like_amp", "irr_c3like_amp_train", "irr_c2like_amp", "irr_stride1_amp",
+                                  "irr_stride1_amp_train", "irr_nonpow2_amp", "s2d_c1like_amp", "s3d_c5like_amp"])
+def test_erwin_backward_kernel_vs_autograd(name, hip_device):
+    """haet_erwin_bwd (the whole Erwin stage's backward in one launch, fp32) against torch autograd through the
+    restatement of the stage (haet_amd/_autograd.py: erwin_forward) on the reference's slice tokens: gradient w.r.t. the
+    tokens and every parameter, eval- and train-mode BatchNorm, rotated / unrotated / stride-1 / padded trees."""
+    from haet_amd import _autograd
+    from tests import golden_util as G
+    from tests.test_modules_cpu import CTOR
+
+    x, sd, meta, exp, rows = G.load_attn(name)
+    mod = CTOR[meta["kind"]](**meta["kw"])
+    mod.load_state_dict(sd)
+    mod = mod.to(hip_device).train(meta["train"])
+    er = mod.erwin
+    S = exp["eidetic_flat"].to(hip_device)
+    n_clouds = x.shape[0] * mod.heads
+    M = mod.slice_num
+    g = torch.Generator().manual_seed(7)
+    gout = torch.randn(S.shape, generator=g).to(hip_device)
+    state = {k: v.clone() for k, v in er.state_dict().items()}
+    # reference: autograd through the restatement (positions detached)
+    Sr = S.clone().requires_grad_(True)
+    er.zero_grad(set_to_none=True)
+    out_ref = _autograd._tokens_through_erwin(mod, Sr, n_clouds)
+    (out_ref * gout).sum().backward()
+    g_ref = {n: (None if p.grad is None else p.grad.clone()) for n, p in er.named_parameters()}
+    gS_ref = Sr.grad.clone()
+    er.load_state_dict(state)  # train mode: undo the running-statistics update
+    assert er.hip_backward_supported(n_clouds, M)
+    out, ctx = er.forward_taped(S, n_clouds)
+    assert O.rel_l2(out.cpu(), out_ref.detach().cpu()) < 5e-5
+    gS, by_param = er.backward_hip(ctx, gout)
+    assert O.rel_l2(gS.cpu(), gS_ref.cpu()) < 2e-4
+    scale = max(float(v.norm()) for v in g_ref.values() if v is not None)
+    for n, p in er.named_parameters():
+        if g_ref[n] is None:
+            assert id(p) not in by_param or float(by_param[id(p)].abs().max()) == 0.0, n
+            continue
+        diff = float((by_param[id(p)] - g_ref[n]).norm())
+        err = diff / max(float(g_ref[n].norm()), 1e-4 * scale)
+        # (a bias in front of a train-mode BatchNorm has a gradient that cancels to ~0: fp32 noise on both sides,
+        # measured against the largest gradient instead)
+        assert err < 5e-4 or diff < 2e-5 * scale, (n, err, diff / scale)

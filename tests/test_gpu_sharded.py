@@ -157,8 +157,11 @@ def test_two_rank_point_sharded_gradients(tmp_path, hip_device):
         scale = max(float(g.norm()) for g in ref.values())
         for name, g_ref in ref.items():
             total = res[0][train]["grads"][name] + res[1][train]["grads"][name]
-            err = float((total - g_ref).norm()) / max(float(g_ref.norm()), 1e-4 * scale)
-            assert err < 2e-3, (train, name, err)
+            diff = float((total - g_ref).norm())
+            err = diff / max(float(g_ref.norm()), 1e-4 * scale)
+            # (a bias in front of a train-mode BatchNorm has a gradient that cancels to ~0: fp32 noise, held to the
+            # largest gradient instead)
+            assert err < 2e-3 or diff < 2e-5 * scale, (train, name, err)
 
 
 def _structured_grad_worker(rank, world, port, tmp):
