@@ -68,6 +68,22 @@ def main():
         if "SQ_INSTS_MFMA" in k and "avg_us" in k:
             k["mfma_insts_per_us"] = k["SQ_INSTS_MFMA"] / k["avg_us"]
     json.dump(res, open(os.path.join(d, "pmc.json"), "w"), indent=1)
+    # bench.py's roofline.traffic source: FETCH_SIZE / WRITE_SIZE per kernel of THIS build (source hash)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    points = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+    alg = {"gemm_ws_split": 2 * 1024, "gemm_ws": 2 * 1024, "slice": 1024, "deslice": 2 * 1024, "deslice_out": 2 * 1024}
+    traffic = {"_comment": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py "
+                           "--steps 3 --warmup 1 --no-cpu-baseline; median per launch, KiB as reported.  On gfx950 FETCH_SIZE "
+                           "reports 1/2 of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM): corrected = 2 x raw; "
+                           "WRITE_SIZE is exact.", "points": points, "source_id": bench.kernel_source_id(), "kernels": {}}
+    for s_, k in res["kernels"].items():
+        if "fetch_kb_raw" in k and "write_kb" in k:
+            traffic["kernels"][s_] = {"fetch_kb_raw": k["fetch_kb_raw"], "write_kb": k["write_kb"]}
+            if s_ in alg:
+                traffic["kernels"][s_]["algorithmic_kb"] = alg[s_] * points / 1024.0
+    json.dump(traffic, open(os.path.join(d, "pmc_traffic.json"), "w"), indent=1)
     for s, k in res["kernels"].items():
         print(s, json.dumps({a: (round(b, 3) if isinstance(b, float) else b) for a, b in k.items()}))
 
