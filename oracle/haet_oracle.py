@@ -274,6 +274,71 @@ def erwin_forward(feat: Tensor, pos: Tensor, batch_idx: Tensor, sd, cfg: ErwinCf
     return x[tree_mask][torch.argsort(tree_idx[tree_mask])]
 
 
+# --------------------------------------------------------------------------- stand-alone ErwinFlash
+def radius_graph(pos: Tensor, r: float, batch_idx: Tensor, max_num_neighbors: int = 32) -> Tensor:
+    """torch_cluster.radius_graph(pos, r, batch=batch_idx, loop=True) as EF/erwin_flash.py:160-166 calls it
+    (third-party, not vendored, no version pinned).  Published behaviour of its brute-force device kernel: for every
+    centre i in index order, the first `max_num_neighbors` points j (index order, same cloud, i itself included)
+    with |x_j - x_i|^2 < r^2 in fp32; flow source_to_target -> edge_index = [[j ...], [i ...]]."""
+    n = pos.shape[0]
+    rows, cols = [], []
+    r2 = torch.tensor(r, dtype=torch.float32) ** 2
+    for s in range(0, n, 2048):  # blocks of centres: n x n booleans would not fit for big clouds
+        blk = pos[s:s + 2048]
+        d2 = torch.zeros(blk.shape[0], n)
+        for k in range(pos.shape[1]):  # the kernel's own accumulation order: dim 0, 1, 2
+            diff = pos[None, :, k] - blk[:, None, k]
+            d2 = d2 + diff * diff
+        ok = (d2 < r2) & (batch_idx[s:s + 2048, None] == batch_idx[None, :])
+        ok &= ok.long().cumsum(dim=1) <= max_num_neighbors
+        i, j = ok.nonzero(as_tuple=True)
+        rows.append(j)
+        cols.append(i + s)
+    return torch.stack([torch.cat(rows), torch.cat(cols)], dim=0)
+
+
+def scatter_mean(src: Tensor, idx: Tensor, n: int) -> Tensor:
+    """torch_scatter.scatter_mean(src, idx, dim=0, dim_size=n) (EF/components/utils/scatter_ops.py:5-18): mean of
+    the rows per receiver, zero rows for receivers nobody points at."""
+    acc = torch.zeros(n, src.shape[1], dtype=src.dtype).index_add_(0, idx, src)
+    cnt = torch.zeros(n, dtype=src.dtype).index_add_(0, idx, torch.ones(idx.shape[0], dtype=src.dtype))
+    return acc / cnt.clamp(min=1)[:, None]
+
+
+def mpnn_forward(h: Tensor, pos: Tensor, edge_index: Tensor, sd, pre: str, steps: int) -> Tensor:
+    """EF/components/mpnn.py:48-75: m_ij = LN(GELU(Linear([h_j', h_i', pos_j' - pos_i']))) with (j', i') =
+    edge_index rows (0, 1), mean over the edges that END in a node, h += LN(Linear([h, m]))."""
+    row, col = edge_index[0].long(), edge_index[1].long()
+    edge_attr = pos[row] - pos[col]
+    c = h.shape[1]
+    for t in range(steps):
+        m = _lin(torch.cat([h[row], h[col], edge_attr], dim=-1), sd, f"{pre}fused_message_update.{t}.0")
+        m = F.layer_norm(F.gelu(m), (c,))
+        agg = scatter_mean(m, col, h.shape[0])
+        u = F.layer_norm(_lin(torch.cat([h, agg], dim=-1), sd, f"{pre}update_fns.{t}.0"), (c,))
+        h = h + u
+    return h
+
+
+def erwinflash_forward(feat: Tensor, pos: Tensor, batch_idx: Tensor, sd, cfg: ErwinCfg, mp_steps: int,
+                       edge_index: Optional[Tensor] = None, radius: Optional[float] = None,
+                       embed: bool = True, training: bool = False, trace: Optional[dict] = None, tree=None) -> Tensor:
+    """ErwinTransformer.forward on a raw point cloud (EF/erwin_flash.py:138-195) with the embedding
+    (EF/components/embedding.py:9-20: Linear, then MPNN when mp_steps > 0)."""
+    if embed:
+        if edge_index is None and mp_steps > 0:
+            assert radius is not None
+            edge_index = radius_graph(pos, radius, batch_idx)
+        x = _lin(feat, sd, "embed.embed_fn")
+        if mp_steps > 0:
+            x = mpnn_forward(x, pos, edge_index, sd, "embed.mpnn.", mp_steps)
+    else:
+        x = feat
+    if trace is not None:
+        trace["embed"], trace["edge_index"] = x, edge_index
+    return erwin_forward(x, pos, batch_idx, sd, cfg, pre="", training=training, trace=trace, tree=tree)
+
+
 # --------------------------------------------------------------------------- slice / de-slice
 def project_points(x: Tensor, sd, cfg: AttnCfg) -> Tensor:
     """Per-point projection to [B, N, H*C] (PA/IrregularMesh.py:157-158,

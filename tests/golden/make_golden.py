@@ -51,13 +51,35 @@ def _install_import_stand_ins():
     fa.flash_attn_qkvpacked_func = flash_attn_qkvpacked_func
     sys.modules["flash_attn"] = fa
 
-    def _unreachable(*a, **k):
-        raise NotImplementedError("unreachable on the PhysicsAttention path (embed=False, mp_steps=0)")
+    # torch_scatter / torch_cluster (unpinned in the reference's requirements.txt files) are only reached by the
+    # stand-alone ErwinFlash fixtures (embed=True, mp_steps>0: SURVEY.md 8f-3).  Stand-ins restate their published
+    # contracts:  scatter_mean(src, index, dim=0, dim_size) = per-index mean of the rows, zero rows where no index
+    # points;  radius_graph(x, r, batch, loop, max_num_neighbors=32, flow='source_to_target') = torch_cluster's
+    # brute-force device kernel: for every centre i (ascending) the first 32 points j (ascending, same cloud)
+    # with |x_j - x_i|^2 < r^2, returned as [[j...], [i...]].
+    def scatter_mean(src, index, dim=0, out=None, dim_size=None):
+        assert dim == 0 and out is None
+        n = int(dim_size) if dim_size is not None else int(index.max()) + 1
+        acc = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype).index_add_(0, index, src)
+        cnt = torch.zeros(n, dtype=src.dtype).index_add_(0, index, torch.ones_like(index, dtype=src.dtype))
+        return acc / cnt.clamp(min=1).view(-1, *([1] * (src.dim() - 1)))
+
+    def radius_graph(x, r, batch=None, loop=False, max_num_neighbors=32, flow="source_to_target", num_workers=1):
+        assert flow == "source_to_target"
+        n = x.shape[0]
+        batch = torch.zeros(n, dtype=torch.long) if batch is None else batch
+        d2 = ((x[:, None, :] - x[None, :, :]) ** 2).sum(-1)  # fp32, like the device kernel
+        ok = (d2 < r * r) & (batch[:, None] == batch[None, :])
+        if not loop:
+            ok &= ~torch.eye(n, dtype=torch.bool)
+        ok &= ok.long().cumsum(dim=1) <= max_num_neighbors  # first 32 neighbours by index
+        i, j = ok.nonzero(as_tuple=True)  # row-major: centre i ascending, neighbour j ascending
+        return torch.stack([j, i], dim=0)
 
     tc = types.ModuleType("torch_cluster")
-    tc.radius_graph = _unreachable
+    tc.radius_graph = radius_graph
     ts = types.ModuleType("torch_scatter")
-    ts.scatter_mean = _unreachable
+    ts.scatter_mean = scatter_mean
     sys.modules.update({"torch_cluster": tc, "torch_scatter": ts})
 
 
@@ -342,6 +364,102 @@ def _xlin_rows(raw, kind, B, N):
     return raw.permute(0, 2, 3, 4, 1).reshape(B, N, -1)
 
 
+# Stand-alone ErwinFlash on raw point clouds (benchmarks/02.1-Car-Design-ShapeNetCar/main.py:50-99):
+# embed=True, mp_steps>0, clouds of unequal size that are not powers of two (padded tree, tree_mask).
+EF_CASES = [
+    # name, ctor kwargs, cloud sizes, edges ("radius" r | "given" r), train
+    ("car_like", dict(c_in=7, c_hidden=[128, 128], ball_sizes=[64, 32], enc_num_heads=[8, 8], enc_depths=[4, 4],
+                      dec_num_heads=[8], dec_depths=[4], strides=[2], rotate=45, decode=True, mlp_ratio=4,
+                      dimensionality=3, mp_steps=3), [700], ("given", 0.15), False),
+    ("two_clouds", dict(c_in=5, c_hidden=[64, 128], ball_sizes=[32, 16], enc_num_heads=[4, 8], enc_depths=[2, 2],
+                        dec_num_heads=[4], dec_depths=[2], strides=[2], rotate=45, decode=True, mlp_ratio=2,
+                        dimensionality=3, mp_steps=2), [300, 500], ("radius", 0.2), False),
+    ("two_clouds_train", dict(c_in=5, c_hidden=[64, 128], ball_sizes=[32, 16], enc_num_heads=[4, 8], enc_depths=[2, 2],
+                              dec_num_heads=[4], dec_depths=[2], strides=[2], rotate=45, decode=True, mlp_ratio=2,
+                              dimensionality=3, mp_steps=2), [260, 410], ("radius", 0.2), True),
+    ("planar_norot", dict(c_in=4, c_hidden=[32, 64, 64], ball_sizes=[32, 16, 8], enc_num_heads=[2, 4, 4],
+                          enc_depths=[2, 2, 2], dec_num_heads=[2, 4], dec_depths=[1, 2], strides=[2, 2], rotate=0,
+                          decode=True, mlp_ratio=4, dimensionality=2, mp_steps=1), [512, 200], ("radius", 0.1), False),
+    ("no_mpnn", dict(c_in=6, c_hidden=[64, 64], ball_sizes=[64, 16], enc_num_heads=[4, 4], enc_depths=[2, 2],
+                     dec_num_heads=[4], dec_depths=[2], strides=[4], rotate=30, decode=True, mlp_ratio=4,
+                     dimensionality=3, mp_steps=0), [1000], ("none", 0.0), False),
+]
+
+
+def amplify_erwinflash(mod, gen, scale=6.0):
+    with torch.no_grad():
+        for name, p in mod.named_parameters():
+            if p.dim() == 2 and not name.startswith("embed."):
+                p.mul_(scale)
+            elif p.dim() == 2:
+                p.mul_(3.0)
+            elif name.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=gen))
+            elif "norm" in name and name.endswith("weight"):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=gen))
+        for name, b in mod.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn(b.shape, generator=gen))
+            elif name.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=gen))
+
+
+def gen_erwinflash_fixtures(models, tree_store, only=None):
+    import torch_cluster
+    from models.components.erwinflash import ErwinTransformer
+
+    for ci, (name, kw, sizes, (edges, r), train) in enumerate(EF_CASES):
+        if only and ("ef_" + name) not in only:
+            continue
+        torch.manual_seed(500 + ci)
+        gen = torch.Generator().manual_seed(5000 + ci)
+        mod = ErwinTransformer(**kw)
+        amplify_erwinflash(mod, gen)
+        mod.train(train)
+        q8 = {}
+        if name == "car_like":  # 3.3M matrix entries: kept on an int8 * 2^-k grid, one byte each in the file
+            with torch.no_grad():
+                for pn, p in mod.named_parameters():
+                    if p.dim() == 2:
+                        k = math.floor(math.log2(127.0 / float(p.abs().max())))
+                        q = torch.clamp(torch.round(p * 2.0 ** k), -127, 127).to(torch.int8)
+                        p.copy_(q.float() * 2.0 ** -k)
+                        q8[pn] = (q.numpy(), np.float32(2.0 ** -k))
+        n, d = sum(sizes), kw["dimensionality"]
+        pos = torch.rand(n, d, generator=gen)  # full fp32 mantissas: no equal coordinates
+        feat = torch.randn(n, kw["c_in"], generator=gen).half().float()
+        batch_idx = torch.cat([torch.full((s,), i, dtype=torch.long) for i, s in enumerate(sizes)])
+        edge_index = torch_cluster.radius_graph(pos, r, batch=batch_idx, loop=True) if edges != "none" else None
+        sd = {k: v.clone() for k, v in mod.state_dict().items()}
+        cap, hooks = {}, []
+        if kw.get("embed", True):
+            hooks.append(mod.embed.register_forward_hook(lambda m, i, o: cap.update(embed=o.detach().clone())))
+        tree_store.clear()
+        with torch.no_grad():
+            if edges == "given":
+                out = mod(feat, pos, batch_idx, edge_index=edge_index)
+            else:
+                out = mod(feat, pos, batch_idx, radius=r)
+        for h in hooks:
+            h.remove()
+        arrays = {"pos": pos.numpy(), "feat": feat.half().numpy(), "batch_idx": batch_idx.numpy(), "exp/out": out.numpy()}
+        if edge_index is not None:
+            arrays["edge_index"] = edge_index.numpy().astype(np.int32)
+        arrays.update({"exp/" + k: v.numpy() for k, v in cap.items()})
+        arrays.update({"exp/" + k: v.numpy() for k, v in tree_store.items()})
+        arrays.update({"sd/" + k: v for k, v in to_np(sd).items() if k not in q8})
+        for k, (q, sc) in q8.items():
+            arrays["sdq/" + k], arrays["sdscale/" + k] = q, sc
+        if train:
+            arrays.update({"sd_after/" + k: v for k, v in to_np(mod.state_dict()).items() if "running" in k or "tracked" in k})
+        meta = dict(kw=kw, sizes=sizes, edges=edges, radius=r, train=train)
+        arrays["meta"] = np.frombuffer(repr(meta).encode(), dtype=np.uint8)
+        path = os.path.join(HERE, f"ef_{name}.npz")
+        np.savez_compressed(path, **arrays)
+        print(f"{path}: {os.path.getsize(path)/1e6:.2f} MB  out_norm={out.norm():.4f}  edges="
+              f"{0 if edge_index is None else edge_index.shape[1]}")
+
+
 MODEL_CASES = [
     ("irr", "HAETransolver_Irregular_Mesh", dict(space_dim=3, fun_dim=4, n_hidden=64, n_layers=2, n_head=4, mlp_ratio=2, out_dim=4, slice_num=16), 500, True),
     ("irr_nofx", "HAETransolver_Irregular_Mesh", dict(space_dim=3, fun_dim=0, n_hidden=64, n_layers=1, n_head=4, mlp_ratio=1, out_dim=1, slice_num=8), 300, False),
@@ -430,3 +548,4 @@ if __name__ == "__main__":
     gen_attention_fixtures(models, store, only)
     gen_big_fixtures(models, store, only)
     gen_grad_fixtures(models, only)
+    gen_erwinflash_fixtures(models, store, only)

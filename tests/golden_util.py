@@ -47,6 +47,25 @@ def load_grad(name):
     return torch.from_numpy(z["gout"].astype(np.float32)), torch.from_numpy(z["gx"]), grads, nograd
 
 
+def ef_fixture_names():
+    return sorted(f[3:-4] for f in os.listdir(GOLDEN) if f.startswith("ef_") and f.endswith(".npz"))
+
+
+def load_ef(name):
+    """Stand-alone ErwinFlash fixture: dict with feat, pos, batch_idx, edge_index (or None), sd,
+    sd_after (train: BatchNorm statistics after the forward), meta, exp."""
+    z = np.load(os.path.join(GOLDEN, f"ef_{name}.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    for k in z.files:
+        if k.startswith("sdq/"):  # matrices stored on an int8 * 2^-k grid
+            sd[k[4:]] = torch.from_numpy(z[k].astype(np.float32) * float(z["sdscale/" + k[4:]]))
+    return dict(feat=torch.from_numpy(z["feat"].astype(np.float32)), pos=torch.from_numpy(z["pos"]),
+                batch_idx=torch.from_numpy(z["batch_idx"]),
+                edge_index=torch.from_numpy(z["edge_index"].astype(np.int64)) if "edge_index" in z.files else None,
+                sd=sd, sd_after={k[9:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd_after/")},
+                meta=_meta(z), exp={k[4:]: torch.from_numpy(np.asarray(z[k])) for k in z.files if k.startswith("exp/")})
+
+
 def _meta(z):
     return ast.literal_eval(bytes(z["meta"]).decode())
 
@@ -89,3 +108,11 @@ def oracle_cfg_from_meta(meta):
         if kw.get(k) is not None:
             setattr(cfg.erwin, k, kw[k])
     return cfg
+
+
+def ef_cfg(meta):
+    from oracle import haet_oracle as O
+
+    kw = meta["kw"]
+    return O.ErwinCfg(**{k: kw[k] for k in ("c_in", "c_hidden", "ball_sizes", "enc_num_heads", "enc_depths", "dec_num_heads",
+                                            "dec_depths", "strides", "rotate", "decode", "mlp_ratio", "dimensionality")})

@@ -136,3 +136,22 @@ def test_oracle_gradients_match_reference_autograd(name):
         err = float((g - g_ref[k]).norm()) / max(float(g_ref[k].norm()), 1e-4 * scale)
         assert err < 5e-4, (k, err)
     assert set(nograd) == {k for k in leaves if k not in g_ref}, nograd
+
+
+@pytest.mark.parametrize("name", G.ef_fixture_names())
+def test_standalone_erwinflash_oracle_matches_reference(name):
+    """Stand-alone ErwinFlash on raw clouds: embedding + MPNN + padded trees of unequal clouds, against
+    the imported reference's output; the radius graph against the edges the fixture was generated with."""
+    f = G.load_ef(name)
+    kw, meta, exp = f["meta"]["kw"], f["meta"], f["exp"]
+    trace = {}
+    out = O.erwinflash_forward(f["feat"], f["pos"], f["batch_idx"], f["sd"], G.ef_cfg(meta), kw["mp_steps"],
+                               edge_index=f["edge_index"] if meta["edges"] == "given" else None, radius=meta["radius"],
+                               training=meta["train"], trace=trace)
+    assert torch.equal(trace["tree_idx"], exp["tree_idx"]) and torch.equal(trace["tree_mask"], exp["tree_mask"])
+    if f["edge_index"] is not None:
+        assert torch.equal(trace["edge_index"], f["edge_index"])
+        assert torch.equal(O.radius_graph(f["pos"], meta["radius"], f["batch_idx"]), f["edge_index"])
+    if "embed" in exp:
+        assert O.rel_l2(trace["embed"], exp["embed"]) < 1e-6
+    assert O.rel_l2(out, exp["out"]) < 1e-5
