@@ -86,6 +86,12 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
             dec_depths = [2]
         if strides is None:
             strides = [2]
+        if embed or mp_steps:
+            raise NotImplementedError(
+                "ErwinEmbedding / MPNN inside PhysicsAttention (embed=True or mp_steps>0): the slice-token stage is one fused "
+                "launch without an embedding -- every Physics_Attention_* default passes embed=False, mp_steps=0, and the "
+                "reference's own forward gives the MPNN no radius / edge_index (IrregularMesh.py:211-218).  The embedding "
+                "exists on the stand-alone ErwinTransformer (haet_amd.components.erwinflash).")
         self.erwin = ErwinTransformer(
             c_in=dim_head, c_hidden=c_hidden, ball_sizes=ball_sizes, enc_num_heads=enc_num_heads,
             enc_depths=enc_depths, dec_num_heads=dec_num_heads, dec_depths=dec_depths, strides=strides,

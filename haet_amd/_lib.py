@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import c_longlong, POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhaet_hip.so")
@@ -129,6 +129,28 @@ SIGNATURES = {
                                      _P, _P, _P, _P, _P, _P]),
     "haet_deslice_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P]
                          + [c_int] * 5 + [_P, _P]),
+    # stand-alone ErwinFlash on raw point clouds (include/haet_hip.h, last section)
+    "haet_balltree_big_slots": (c_size_t, [_P, c_int]),
+    "haet_balltree_big_workspace_bytes": (c_size_t, [_P, c_int, c_int]),
+    "haet_balltree_big_build": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, c_size_t, _P]),
+    "haet_pc_radius_neighbours": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_int, _P, _P, _P]),
+    "haet_pc_radius_fill": (c_int, [_P, _P, _P, c_int, c_int, c_longlong, _P, _P]),
+    "haet_pc_mpnn_message": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_longlong, c_int, c_float, _P, c_int, _P]),
+    "haet_pc_ln_residual": (c_int, [_P, c_int, c_longlong, c_int, c_float, _P, c_int, _P, c_int, _P]),
+    "haet_pc_gather_rows": (c_int, [_P, c_int, _P, c_longlong, c_int, _P, c_int, _P]),
+    "haet_pc_scatter_masked": (c_int, [_P, c_int, _P, _P, c_longlong, c_int, _P, c_int, _P]),
+    "haet_pc_rows_add": (c_int, [_P, c_int, _P, _P, c_int, c_longlong, c_int, _P]),
+    "haet_pc_ball_rel": (c_int, [_P, _P, c_longlong, c_int, c_int, _P, _P]),
+    "haet_pc_rms_pe": (c_int, [_P, c_int, _P, _P, c_longlong, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "haet_pc_ball_attention_supported": (c_int, [c_int, c_int, c_int]),
+    "haet_pc_ball_attention": (c_int, [_P, c_int, c_longlong, c_int, c_int, c_int, _P, c_int, _P]),
+    "haet_pc_swiglu": (c_int, [_P, c_int, c_longlong, c_int, _P, c_int, _P]),
+    "haet_pc_pool_gather": (c_int, [_P, c_int, _P, c_longlong, c_int, c_int, c_int, _P, c_int, _P, _P]),
+    "haet_pc_unpool_input": (c_int, [_P, c_int, _P, _P, c_longlong, c_int, c_int, c_int, _P, c_int, _P]),
+    "haet_pc_unpool_merge": (c_int, [_P, c_int, _P, c_int, c_longlong, c_int, c_int, _P, c_int, _P]),
+    "haet_pc_bn_blocks": (c_int, [c_longlong]),
+    "haet_pc_bn_stats": (c_int, [_P, c_int, c_longlong, c_int, c_float, _P, _P, _P, _P, _P, _P]),
+    "haet_pc_bn_apply": (c_int, [_P, c_int, c_longlong, c_int, _P, _P, c_float, _P, _P, _P]),
 }
 
 _lib = None
@@ -189,8 +211,8 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
             fn.restype, fn.argtypes = res, args
-        if lib.haet_abi_version() != 4:
-            raise HaetError(f"libhaet_hip.so ABI {lib.haet_abi_version()} != 4")
+        if lib.haet_abi_version() != 5:
+            raise HaetError(f"libhaet_hip.so ABI {lib.haet_abi_version()} != 5")
         _lib = lib
     return _lib
 

@@ -6,8 +6,9 @@ components/mlp.py, BallPooling / BallUnpooling components/pooling.py).
 The module tree exists to own the parameters under the reference's exact state_dict
 keys; the arithmetic of the whole stage is ONE fused HIP kernel (haet_erwin_fwd) fed by
 the device ball-tree builder (haet_balltree_build), instead of ~100 small launches and
-a host round trip per forward.  Only the configuration every PhysicsAttention module
-uses is supported (embed=False, mp_steps=0, decode=True).
+a host round trip per forward.  That is the configuration every PhysicsAttention module
+uses (embed=False, mp_steps=0, decode=True, <= a few hundred tokens per cloud); raw point clouds (embedding, MPNN,
+clouds of any size) take the streaming path of pointcloud.py.
 """
 from __future__ import annotations
 
@@ -91,6 +92,34 @@ class BasicLayer(nn.Module):
             self.unpool = BallUnpooling(in_dim, hidden_dim, stride, dimensionality)
 
 
+def _equal_clouds(batch_idx: torch.Tensor, n_clouds: int) -> bool:
+    M = batch_idx.shape[0] // n_clouds
+    return bool((batch_idx.view(n_clouds, M) == torch.arange(n_clouds, device=batch_idx.device)[:, None]).all())
+
+
+class MPNN(nn.Module):
+    """Parameters of the message-passing embedding (components/mpnn.py:21-46): per step a message Linear(2 dim + d -> dim)
+    [+ GELU + LayerNorm without affine] and an update Linear(2 dim -> dim) [+ LayerNorm without affine]."""
+
+    def __init__(self, dim: int, mp_steps: int, dimensionality: int = 3):
+        super().__init__()
+        self.fused_message_update = nn.ModuleList(
+            [nn.Sequential(nn.Linear(2 * dim + dimensionality, dim), nn.GELU(), nn.LayerNorm(dim, elementwise_affine=False))
+             for _ in range(mp_steps)])
+        self.update_fns = nn.ModuleList(
+            [nn.Sequential(nn.Linear(2 * dim, dim), nn.LayerNorm(dim, elementwise_affine=False)) for _ in range(mp_steps)])
+
+
+class ErwinEmbedding(nn.Module):
+    """Linear projection -> MPNN (components/embedding.py:9-20), parameters only."""
+
+    def __init__(self, in_dim: int, dim: int, mp_steps: int, dimensionality: int = 3):
+        super().__init__()
+        self.mp_steps = mp_steps
+        self.embed_fn = nn.Linear(in_dim, dim)
+        self.mpnn = MPNN(dim, mp_steps, dimensionality)
+
+
 class ErwinTransformer(nn.Module):
     """Same constructor and state_dict as the reference (erwin_flash.py:41-136)."""
 
@@ -102,15 +131,13 @@ class ErwinTransformer(nn.Module):
         assert len(enc_num_heads) == len(enc_depths) == len(ball_sizes)
         assert len(dec_num_heads) == len(dec_depths) == len(strides)
         assert len(strides) == len(ball_sizes) - 1
-        if embed or mp_steps:
-            raise NotImplementedError(
-                "ErwinEmbedding / MPNN (embed=True or mp_steps>0) are outside the PhysicsAttention "
-                "hot path: every Physics_Attention_* module passes embed=False, mp_steps=0")
         self.rotate, self.decode = rotate, decode
         self.ball_sizes, self.strides = list(ball_sizes), list(strides)
         self.mp_steps, self.use_embedding = mp_steps, embed
         self.dimensionality = dimensionality
         self.c_hidden = list(c_hidden)
+        if embed:  # raw point clouds (stand-alone use, erwin_flash.py:69-71): Linear + MPNN in front of the tree
+            self.embed = ErwinEmbedding(c_in, c_hidden[0], mp_steps, dimensionality)
         num_layers = len(enc_depths) - 1
         self.encoder = nn.ModuleList()
         for i in range(num_layers):
@@ -179,21 +206,51 @@ class ErwinTransformer(nn.Module):
         return self._packed[1], self._packed[2]
 
     # ------------------------------------------------------------------ forward
+    def _token_kernel_fits(self, T: int, n_clouds: int) -> bool:
+        """The one-launch LDS-resident kernel (csrc/erwin.hip): equally sized clouds whose whole hierarchy fits one CU."""
+        if self.use_embedding or not self.decode or T % n_clouds:
+            return False
+        _, desc = self.packed()
+        memo = self.__dict__.get("_fits_memo")
+        if memo is None or memo[0] is not desc:  # (a new desc object = repacked weights)
+            memo = (desc, {})
+            self.__dict__["_fits_memo"] = memo
+        hit = memo[1].get((T, n_clouds))
+        if hit is None:
+            need = _lib.load().haet_erwin_lds_bytes(desc, ops.tree_slots(T // n_clouds))
+            hit = memo[1][(T, n_clouds)] = 0 < need <= 160 * 1024
+        return hit
+
     def forward(self, node_features: torch.Tensor, node_positions: Optional[torch.Tensor],
-                batch_idx: Optional[torch.Tensor] = None, n_clouds: Optional[int] = None, **kwargs):
-        """tokens [T, c], positions [T, d]; the T tokens are n_clouds equally sized clouds in
-        order (what PhysicsAttention builds: batch_idx = arange(B*H).repeat_interleave(G)).
-        node_positions=None: positions = min-max normalised first `dimensionality` channels of the
-        tokens (IrregularMesh.py:204-209), computed inside the tree launch; kept in `last_positions`."""
-        if not self.decode:
-            raise NotImplementedError("decode=False is outside the PhysicsAttention hot path")
+                batch_idx: Optional[torch.Tensor] = None, n_clouds: Optional[int] = None,
+                edge_index: Optional[torch.Tensor] = None, tree_idx=None, tree_mask=None, radius: Optional[float] = None,
+                **kwargs):
+        """Two regimes behind the reference's signature (erwin_flash.py:138-148):
+        * slice tokens (what PhysicsAttention passes: `n_clouds` equally sized clouds of <= a few hundred tokens, no
+          embedding): tokens [T, c], positions [T, d] or None (= min-max normalised first `dimensionality` channels of
+          the tokens, IrregularMesh.py:204-209, computed inside the launch; kept in `last_positions`) -> ONE launch;
+        * raw point clouds (embed / MPNN, clouds of any and unequal size, decode=False): node_features [N, c_in],
+          node_positions [N, d], batch_idx [N] (+ edge_index or radius) -> the streaming path of pointcloud.py.
+        A caller-made tree (tree_idx / tree_mask) is not accepted: the reference itself fails on it (its rotated
+        partitions are only defined on the path that builds the tree, erwin_flash.py:151-157,184)."""
+        if tree_idx is not None or tree_mask is not None:
+            raise NotImplementedError("tree_idx / tree_mask from the caller: the tree is always built on the device")
         T = node_features.shape[0]
         if n_clouds is None:
             if batch_idx is None:
                 raise HaetError("either batch_idx or n_clouds is required")
-            n_clouds = int(batch_idx[-1].item()) + 1  # sync; PhysicsAttention passes n_clouds
-        if T % n_clouds:
-            raise HaetError("the HIP Erwin stage needs equally sized clouds")
+            if node_positions is None or self.use_embedding or not self.decode:
+                n_clouds = -1
+            else:
+                n_clouds = int(batch_idx[-1].item()) + 1  # sync; PhysicsAttention passes n_clouds
+        if n_clouds < 0 or not self._token_kernel_fits(T, n_clouds) or (
+                batch_idx is not None and node_positions is not None and n_clouds > 1
+                and kwargs.get("check_cloud_sizes", True) and not _equal_clouds(batch_idx, n_clouds)):
+            from . import pointcloud
+
+            if node_positions is None or batch_idx is None:
+                raise HaetError("the point-cloud path needs node_positions and batch_idx")
+            return pointcloud.forward(self, node_features, node_positions, batch_idx, edge_index, radius)
         M = T // n_clouds
         blob, desc = self.packed()
         train = None

@@ -1,0 +1,264 @@
+"""ErwinTransformer.forward on RAW point clouds -- host side.
+
+What the reference does here (models/components/erwinflash/erwin_flash.py:138-195 with embed=True / mp_steps>0;
+benchmarks/02.1-Car-Design-ShapeNetCar/main.py:50-99): ball tree + rotated re-partitions on the HOST, radius graph,
+Linear embedding + MPNN steps, gather into tree order, encoder / bottleneck / decoder of ball-attention blocks with
+BallPooling / BallUnpooling in between, scatter back to the input order.  Here every one of those stages is a HIP
+launch on the current stream (haet_amd/pc_ops.py -> csrc/balltree_big.hip, csrc/pointcloud.hip, and the split-bf16
+GEMMs of csrc/gemm_x3.hip for the Linears); the state stays in HBM as [tree slots][channels] fp32.
+
+Gradients: with autograd recording, the same stages run as differentiable torch device ops on the HIP-built tree and
+radius graph (`_forward_autograd`); the hand-written backward exists only for the slice-token configuration
+(csrc/erwin_bwd.hip).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from ... import _lib, ops, pc_ops
+from ..._lib import HaetError
+
+Tensor = torch.Tensor
+
+
+def supported(erwin) -> Optional[str]:
+    """None when the HIP point-cloud path covers this configuration, else the reason."""
+    if erwin.dimensionality not in (2, 3):
+        return f"dimensionality {erwin.dimensionality}"
+    layers = list(erwin.encoder) + [erwin.bottleneck] + (list(erwin.decoder) if erwin.decode else [])
+    for L in layers:
+        c = L.hidden_dim
+        if c % 32 or c > 1024 or c * L.mlp_ratio > 1024:
+            return f"width {c} (multiple of 32, hidden <= 1024)"
+        if not pc_ops.ball_attention_supported(c, L.num_heads, L.ball_size):
+            return f"ball attention c={c} heads={L.num_heads} ball={L.ball_size}"
+    return None
+
+
+class _Weights:
+    """Split-bf16 operands of every Linear, rebuilt when a parameter changes (same key as the packed token path)."""
+
+    def __init__(self, erwin):
+        P = pc_ops.PaddedLinear
+        self.blocks = {}
+        layers = list(erwin.encoder) + [erwin.bottleneck] + (list(erwin.decoder) if erwin.decode else [])
+        for L in layers:
+            for blk in L.blocks:
+                a, s = blk.BMSA, blk.swiglu
+                self.blocks[id(blk)] = dict(
+                    qkv=P(a.qkv.weight, a.qkv.bias), proj=P(a.proj.weight, a.proj.bias),
+                    w12=P(torch.cat([s.w1.weight, s.w2.weight], 0), torch.cat([s.w1.bias, s.w2.bias], 0)),
+                    w3=P(s.w3.weight, s.w3.bias),
+                    norm1=blk.norm1.weight.detach().float().contiguous(), norm2=blk.norm2.weight.detach().float().contiguous(),
+                    pe_w=a.pe_proj.weight.detach().float().contiguous(), pe_b=a.pe_proj.bias.detach().float().contiguous())
+            for name in ("pool", "unpool"):
+                m = getattr(L, name, None)
+                if m is not None:
+                    self.blocks[id(m)] = P(m.proj.weight, m.proj.bias)
+        if erwin.use_embedding:
+            e = erwin.embed
+            self.embed = P(e.embed_fn.weight, e.embed_fn.bias) if not ops.linear_narrow_supported(*e.embed_fn.weight.shape[::-1]) else None
+            c = e.embed_fn.weight.shape[0]
+            self.mp = []
+            for msg, upd in zip(e.mpnn.fused_message_update, e.mpnn.update_fns):
+                W = msg[0].weight
+                self.mp.append(dict(ab=P(torch.cat([W[:, :c], W[:, c:2 * c]], 0), None), wc=W[:, 2 * c:].detach().float().contiguous(),
+                                    b=msg[0].bias.detach().float().contiguous(), upd=P(upd[0].weight, upd[0].bias)))
+
+
+def _weights(erwin) -> _Weights:
+    key = erwin._pack_key()
+    hit = erwin.__dict__.get("_pc_weights")
+    if hit is None or hit[0] != key:
+        hit = (key, _Weights(erwin))
+        erwin.__dict__["_pc_weights"] = hit
+    return hit[1]
+
+
+def cloud_sizes(batch_idx: Tensor) -> List[int]:
+    """Points per cloud (batch_idx is sorted, contiguous from 0 like balltree.pyx:459-470 requires); one host read."""
+    return torch.bincount(batch_idx.to(torch.long)).tolist()
+
+
+def build_structures(erwin, pos: Tensor, batch_idx: Tensor, edge_index: Optional[Tensor], radius: Optional[float]):
+    sizes = cloud_sizes(batch_idx)
+    tree_idx, tree_mask, rots = pc_ops.balltree_big(pos, sizes, erwin.strides, erwin.ball_sizes, float(erwin.rotate))
+    if edge_index is None and erwin.use_embedding and erwin.mp_steps > 0:
+        if radius is None:
+            raise AssertionError("radius (float) must be provided if edge_index is not given to build radius graph")
+        edge_index = pc_ops.radius_graph(pos, radius, batch_idx, sizes)
+    return sizes, tree_idx, tree_mask, rots, edge_index
+
+
+# --------------------------------------------------------------------------- HIP forward
+def _embed(erwin, W: _Weights, feat: Tensor, pos: Tensor, edge_index: Optional[Tensor]) -> Tensor:
+    e = erwin.embed
+    c = e.embed_fn.weight.shape[0]
+    if W.embed is None:
+        h = ops.linear_narrow(feat, e.embed_fn.weight, e.embed_fn.bias)
+    else:
+        h = W.embed.compact(W.embed(F.pad(feat, (0, W.embed.Kp - feat.shape[1]))))
+    if erwin.mp_steps == 0:
+        return h
+    N = feat.shape[0]
+    rowptr, src = pc_ops.edges_to_csr(edge_index, N)
+    hcat = torch.empty((N, 2 * c), dtype=torch.float32, device=feat.device)
+    hcat[:, :c] = h
+    for st in W.mp:
+        AB = st["ab"](h)
+        pc_ops.mpnn_message(AB, pos, rowptr, src, st["wc"], st["b"], c, hcat[:, c:])
+        u = st["upd"](hcat)
+        pc_ops.ln_residual(u, h, hcat, c)
+    return h
+
+
+def _block(X: Tensor, P: Tensor, perm: Optional[Tensor], blk, w: dict, d: int):
+    c, ball, heads = X.shape[1], blk.ball_size, blk.BMSA.num_heads
+    rel = pc_ops.ball_rel(P, perm, ball)
+    Y = pc_ops.rms_pe(X, perm, rel, w["norm1"], w["pe_w"], w["pe_b"], c)
+    A = pc_ops.ball_attention(w["qkv"](Y), c, heads, ball)
+    pc_ops.rows_add(X, perm, w["proj"](A), c)
+    Y = pc_ops.rms_pe(X, None, None, w["norm2"], None, None, c)
+    H = pc_ops.swiglu(w["w12"](Y), w["w3"].K)
+    pc_ops.rows_add(X, None, w["w3"](H), c)
+
+
+def _layer(X, P, rot, L, W: _Weights, d):
+    use_rot = any(L.rotate) and rot is not None
+    for j, blk in enumerate(L.blocks):
+        _block(X, P, rot if (use_rot and L.rotate[j]) else None, blk, W.blocks[id(blk)], d)
+
+
+def forward_hip(erwin, feat: Tensor, pos: Tensor, batch_idx: Tensor, edge_index: Optional[Tensor], radius: Optional[float]):
+    why = supported(erwin)
+    if why is not None:
+        raise HaetError(f"stand-alone ErwinFlash outside the HIP point-cloud path: {why}")
+    feat, pos = ops._f32(feat, "node_features"), ops._f32(pos, "node_positions")
+    d = erwin.dimensionality
+    W = _weights(erwin)
+    sizes, tree_idx, tree_mask, rots, edge_index = build_structures(erwin, pos, batch_idx, edge_index, radius)
+    x = _embed(erwin, W, feat, pos, edge_index) if erwin.use_embedding else feat
+    c0 = x.shape[1]
+    X = pc_ops.gather_rows(x, tree_idx, c0)
+    P = pos.index_select(0, tree_idx.to(torch.long))
+    train = erwin.training
+    stack = []
+    for i, L in enumerate(erwin.encoder):
+        _layer(X, P, rots[i], L, W, d)
+        stack.append((X, P, rots[i]))
+        st = L.pool.stride
+        if st != 1:  # (stride 1: the node passes through, pooling.py:26-27)
+            pl = W.blocks[id(L.pool)]
+            Y, Pc = pc_ops.pool_gather(X, P, X.shape[1], st, pl.Kp)
+            X = pl.compact(pl(Y))
+            pc_ops.batch_norm_(X, X.shape[1], L.pool.norm, train)
+            P = Pc
+        else:
+            X = X.clone()
+    _layer(X, P, rots[len(erwin.encoder)], erwin.bottleneck, W, d)
+    if not erwin.decode:
+        b = batch_idx[tree_idx.to(torch.long)]
+        for s in erwin.strides:
+            b = b[::s]
+        return X, b
+    for k, L in enumerate(erwin.decoder):
+        cx, cp, crot = stack[len(erwin.encoder) - 1 - k]
+        st = L.unpool.stride
+        ul = W.blocks[id(L.unpool)]
+        Y = pc_ops.unpool_input(X, P, cp, X.shape[1], st, ul.Kp)
+        X = pc_ops.unpool_merge(cx, ul(Y), cx.shape[1], st)
+        pc_ops.batch_norm_(X, X.shape[1], L.unpool.norm, train)
+        P = cp
+        _layer(X, P, crot, L, W, d)
+    return pc_ops.scatter_masked(X, tree_idx, tree_mask, X.shape[1], feat.shape[0])
+
+
+# --------------------------------------------------------------------------- differentiable restatement (training)
+def _rms(x, w):
+    return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + torch.finfo(x.dtype).eps) * w
+
+
+def _block_autograd(x, pos, blk):
+    c, ball, heads = x.shape[1], blk.ball_size, blk.BMSA.num_heads
+    a, s = blk.BMSA, blk.swiglu
+    with torch.no_grad():
+        p = pos.view(-1, ball, pos.shape[1])
+        rel = (p - p.mean(1, keepdim=True)).reshape(-1, pos.shape[1])
+    y = _rms(x, blk.norm1.weight) + F.linear(rel, a.pe_proj.weight, a.pe_proj.bias)
+    qkv = F.linear(y, a.qkv.weight, a.qkv.bias).view(-1, ball, 3, heads, c // heads)
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    o = F.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(-1, c)
+    x = x + F.linear(o, a.proj.weight, a.proj.bias)
+    y = _rms(x, blk.norm2.weight)
+    return x + F.linear(F.linear(y, s.w2.weight, s.w2.bias) * F.silu(F.linear(y, s.w1.weight, s.w1.bias)), s.w3.weight, s.w3.bias)
+
+
+def _layer_autograd(x, pos, rot, L):
+    use_rot = any(L.rotate) and rot is not None
+    inv = torch.argsort(rot) if use_rot else None
+    for j, blk in enumerate(L.blocks):
+        if use_rot and L.rotate[j]:
+            x = _block_autograd(x[rot], pos[rot], blk)[inv]
+        else:
+            x = _block_autograd(x, pos, blk)
+    return x
+
+
+def forward_autograd(erwin, feat, pos, batch_idx, edge_index, radius):
+    pos = pos.detach()
+    d = erwin.dimensionality
+    sizes, tree_idx, tree_mask, rots, edge_index = build_structures(erwin, pos.float(), batch_idx, edge_index, radius)
+    tree_idx = tree_idx.to(torch.long)
+    rots = [None if r is None else r.to(torch.long) for r in rots]
+    x = feat
+    if erwin.use_embedding:
+        e = erwin.embed
+        x = F.linear(feat, e.embed_fn.weight, e.embed_fn.bias)
+        if erwin.mp_steps > 0:
+            row, col = edge_index[0].to(torch.long), edge_index[1].to(torch.long)
+            attr = pos[row] - pos[col]
+            c = x.shape[1]
+            cnt = torch.zeros(x.shape[0], device=x.device).index_add_(0, col, torch.ones(col.shape[0], device=x.device)).clamp(min=1)
+            for msg, upd in zip(e.mpnn.fused_message_update, e.mpnn.update_fns):
+                m = F.layer_norm(F.gelu(F.linear(torch.cat([x[row], x[col], attr], -1), msg[0].weight, msg[0].bias)), (c,))
+                agg = torch.zeros_like(x).index_add_(0, col, m) / cnt[:, None]
+                x = x + F.layer_norm(F.linear(torch.cat([x, agg], -1), upd[0].weight, upd[0].bias), (c,))
+    x, p = x[tree_idx], pos[tree_idx]
+    stack = []
+    for i, L in enumerate(erwin.encoder):
+        x = _layer_autograd(x, p, rots[i], L)
+        stack.append((x, p, rots[i]))
+        st = L.pool.stride
+        if st != 1:
+            with torch.no_grad():
+                ctr = p.view(-1, st, d).mean(1)
+                rel = (p.view(-1, st, d) - ctr[:, None]).reshape(-1, st * d)
+            x = L.pool.norm(F.linear(torch.cat([x.reshape(-1, st * x.shape[1]), rel], 1), L.pool.proj.weight, L.pool.proj.bias))
+            p = ctr
+    x = _layer_autograd(x, p, rots[len(erwin.encoder)], erwin.bottleneck)
+    if not erwin.decode:
+        b = batch_idx[tree_idx]
+        for s in erwin.strides:
+            b = b[::s]
+        return x, b
+    for k, L in enumerate(erwin.decoder):
+        cx, cp, crot = stack[len(erwin.encoder) - 1 - k]
+        st = L.unpool.stride
+        with torch.no_grad():
+            rel = (cp.view(-1, st, d) - p[:, None]).reshape(-1, st * d)
+        y = F.linear(torch.cat([x, rel], -1), L.unpool.proj.weight, L.unpool.proj.bias).reshape(cx.shape[0], -1)
+        x = L.unpool.norm(cx + y)
+        p = cp
+        x = _layer_autograd(x, p, crot, L)
+    mask = tree_mask.bool()
+    return x[mask][torch.argsort(tree_idx[mask])]
+
+
+def forward(erwin, feat, pos, batch_idx, edge_index=None, radius=None):
+    needs_grad = torch.is_grad_enabled() and (feat.requires_grad or any(p.requires_grad for p in erwin.parameters()))
+    if needs_grad:
+        return forward_autograd(erwin, feat, pos, batch_idx, edge_index, radius)
+    return forward_hip(erwin, feat, pos, batch_idx, edge_index, radius)

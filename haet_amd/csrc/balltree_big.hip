@@ -1,0 +1,497 @@
+// Ball tree of RAW point clouds (32k .. 1M+ points per cloud, clouds of unequal size) -- the tree the stand-alone
+// ErwinFlash model builds on the host every forward (models/components/erwinflash/erwin_flash.py:149-157 ->
+// models/components/balltree/balltree.pyx:542-662; benchmarks/02.1-Car-Design-ShapeNetCar/main.py:50-99).
+//
+// The permutation has to be the one libstdc++'s std::nth_element leaves behind (balltree.h:91-100): BallPooling
+// concatenates the two points of a leaf in that order (pooling.py:35-38), and the order a node is left in is the input
+// of its children's selects.  So the introselect is followed step for step, but its one O(n)
+// part -- the unguarded Hoare partition around the median-of-three pivot -- runs data-parallel:
+//   the k-th swap of the sequential loop exchanges the k-th "left stopper" (k-th position from the left whose key is
+//   not < pivot) with the k-th "right stopper" (k-th position from the right whose key is not > pivot; the pivot's own
+//   slot in front of the range is the last of them), for as long as the former lies left of the latter.  Both
+//   sequences are prefix counts of the ORIGINAL array, the number of swaps K is where the monotone predicate
+//   L_k < R_k flips, and the cut the loop returns is min(L_{K+1}, R_K).
+// Levels whose nodes are larger than kSubT items run one workgroup per node on global memory (a launch per level);
+// every node of at most kSubT items is finished -- all remaining levels -- by one wave in LDS with the per-lane
+// select of balltree_select_dev.h (nodes of a level are independent: one lane each).
+// Keys are the fp32 coordinates (the reference's float64 conversion is exact and order preserving); spreads are
+// differenced in double like the reference.
+#include "common.h"
+#include "balltree_select_dev.h"
+
+#include <cmath>
+#include <vector>
+
+namespace haet {
+
+void rotation_matrix_f32(float angle_deg, int d, float* r);  // balltree.hip
+
+constexpr int kSubT = 1024;       // nodes of at most this many items are finished inside one wave's LDS
+constexpr int kTopThreads = 1024;
+constexpr int kTopWaves = kTopThreads / 64;
+
+struct BigCloud {
+    int off;     // first item of the cloud
+    int n;       // items
+    int levels;  // split levels
+    int top;     // levels [0, top) run as grid launches; at level `top` every node has <= kSubT items
+};
+
+// ----------------------------------------------------------------------------------------------- top levels
+__global__ __launch_bounds__(kTopThreads) void big_top_kernel(
+    const float* __restrict__ keys, int d, const BigCloud* __restrict__ tab, const int2* __restrict__ work, int level,
+    int* __restrict__ idx, int* __restrict__ gid, float* __restrict__ knode, int* __restrict__ w,
+    int* __restrict__ LS, int* __restrict__ RS) {
+    __shared__ float sh_lo[3][kTopWaves], sh_hi[3][kTopWaves];
+    __shared__ int sh_cl[kTopWaves], sh_cr[kTopWaves], sh_k[kTopWaves];
+    __shared__ int sh_dim;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int2 wk = work[blockIdx.x];
+    const BigCloud C = tab[wk.x];
+    int s, e;
+    node_range(C.n, level, wk.y, s, e);
+    const int m = e - s;
+    if (m <= 1) return;
+    const size_t base = (size_t)C.off + s;
+    int* const W = w + base;
+    float* const KD = knode + base;
+    int* const ls = LS + base;
+    int* const rs = RS + base;
+
+    // split dimension: largest max - min (first one on ties), balltree.h:32-66
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) lo[k] = INFINITY, hi[k] = -INFINITY;
+    for (int p = tid; p < m; p += kTopThreads) {
+        const int g = idx[base + p];
+        for (int k = 0; k < d; ++k) {
+            const float v = keys[((size_t)C.off + g) * d + k];
+            lo[k] = fminf(lo[k], v);
+            hi[k] = fmaxf(hi[k], v);
+        }
+    }
+    for (int k = 0; k < d; ++k) {
+        lo[k] = wave_min(lo[k]);
+        hi[k] = wave_max(hi[k]);
+        if (lane == 0) sh_lo[k][wave] = lo[k], sh_hi[k][wave] = hi[k];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int best = 0;
+        double best_spread = 0.0;
+        for (int k = 0; k < d; ++k) {
+            float a = sh_lo[k][0], b = sh_hi[k][0];
+            for (int q = 1; q < kTopWaves; ++q) a = fminf(a, sh_lo[k][q]), b = fmaxf(b, sh_hi[k][q]);
+            const double spread = (double)b - (double)a;
+            if (spread > best_spread) best_spread = spread, best = k;
+        }
+        sh_dim = best;
+    }
+    __syncthreads();
+    const int dim = sh_dim;
+    // the node's own frame: keys by ENTRY position, working array of entry positions
+    for (int p = tid; p < m; p += kTopThreads) {
+        const int g = idx[base + p];
+        gid[base + p] = g;
+        KD[p] = keys[((size_t)C.off + g) * d + dim];
+        W[p] = p;
+    }
+    __syncthreads();
+
+    int first = 0, last = m;
+    const int nth = m / 2;  // (s + e) / 2 - s
+    int depth = 2 * (31 - __clz(m));
+    while (last - first > 3) {
+        if (depth == 0) {  // introselect's budget is spent: heap select, one lane (adversarial inputs only)
+            if (tid == 0) {
+                heap_select_(W + first, W + nth + 1, W + last, KD);
+                swp(W + first, W + nth);
+            }
+            first = last;  // done
+            break;
+        }
+        --depth;
+        if (tid == 0) {  // median of (first+1, mid, last-1) to the front
+            int *a = W + first + 1, *b = W + first + (last - first) / 2, *c = W + last - 1, *f = W + first;
+            if (lt(KD, *a, *b)) {
+                if (lt(KD, *b, *c)) swp(f, b);
+                else if (lt(KD, *a, *c)) swp(f, c);
+                else swp(f, a);
+            } else if (lt(KD, *a, *c)) swp(f, a);
+            else if (lt(KD, *b, *c)) swp(f, c);
+            else swp(f, b);
+        }
+        __syncthreads();
+        const float v = KD[W[first]];
+        const int f1 = first + 1, len = last - f1;
+        // every wave owns a contiguous chunk (multiple of 64 positions) of [f1, last)
+        const int chunk = ((len + kTopWaves - 1) / kTopWaves + 63) & ~63;
+        const int c0 = f1 + wave * chunk, c1 = min(c0 + chunk, last);
+        int nl = 0, nr = 0;
+        for (int p0 = c0; p0 < c1; p0 += 64) {
+            const int p = p0 + lane;
+            const float x = p < c1 ? KD[W[p]] : 0.f;
+            nl += __popcll(__ballot(p < c1 && !(x < v)));
+            nr += __popcll(__ballot(p < c1 && !(v < x)));
+        }
+        if (lane == 0) sh_cl[wave] = nl, sh_cr[wave] = nr;
+        __syncthreads();
+        int bl = 0, br = 0, nL = 0, nR = 0;
+        for (int q = 0; q < kTopWaves; ++q) {
+            if (q < wave) bl += sh_cl[q], br += sh_cr[q];
+            nL += sh_cl[q], nR += sh_cr[q];
+        }
+        // stopper lists: ls[k] = k-th left stopper from the left, rs[k] = k-th right stopper from the right
+        // (the pivot's slot `first` is the last right stopper)
+        for (int p0 = c0; p0 < c1; p0 += 64) {
+            const int p = p0 + lane;
+            const float x = p < c1 ? KD[W[p]] : 0.f;
+            const bool isl = p < c1 && !(x < v), isr = p < c1 && !(v < x);
+            const unsigned long long ml = __ballot(isl), mr = __ballot(isr);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (isl) ls[bl + __popcll(ml & below)] = p;
+            if (isr) rs[nR - 1 - (br + __popcll(mr & below))] = p;
+            bl += __popcll(ml);
+            br += __popcll(mr);
+        }
+        if (tid == 0) rs[nR] = first;
+        __syncthreads();
+        const int kmax = min(nL, nR + 1);
+        int kc = 0;
+        for (int k = tid; k < kmax; k += kTopThreads) kc += ls[k] < rs[k] ? 1 : 0;
+        kc = (int)wave_sum((float)kc);  // (< 2^24 per wave: exact)
+        if (lane == 0) sh_k[wave] = kc;
+        __syncthreads();
+        int K = 0;
+        for (int q = 0; q < kTopWaves; ++q) K += sh_k[q];
+        int cut;
+        {
+            const int bound = K > 0 ? rs[K - 1] : last;
+            cut = bound;
+            if (K < nL) {
+                const int Lk = ls[K];
+                cut = Lk < bound ? Lk : bound;
+            }
+        }
+        __syncthreads();  // every lane has read ls / rs before the next round rewrites them
+        for (int k = tid; k < K; k += kTopThreads) {
+            const int a = ls[k], b = rs[k];
+            const int t = W[a];
+            W[a] = W[b];
+            W[b] = t;
+        }
+        __syncthreads();
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    if (tid == 0 && last - first > 0) insertion_sort_(W + first, W + last, KD);
+    __syncthreads();
+    for (int p = tid; p < m; p += kTopThreads) idx[base + p] = gid[base + W[p]];
+}
+
+// ----------------------------------------------------------------------------------------------- sub-trees
+__global__ __launch_bounds__(64) void big_sub_kernel(const float* __restrict__ keys, int d,
+                                                     const BigCloud* __restrict__ tab,
+                                                     const int2* __restrict__ work, int* __restrict__ idx) {
+    __shared__ float lkey[3 * kSubT];
+    __shared__ int lidx[kSubT];
+    __shared__ int lgid[kSubT];
+    const int lane = threadIdx.x;
+    const int2 wk = work[blockIdx.x];
+    const BigCloud C = tab[wk.x];
+    int s, e;
+    node_range(C.n, C.top, wk.y, s, e);
+    const int m = e - s, r = C.levels - C.top;
+    if (m <= 1 || r <= 0) return;
+    const size_t base = (size_t)C.off + s;
+    for (int i = lane; i < m; i += 64) {
+        const int g = idx[base + i];
+        lgid[i] = g;
+        lidx[i] = i;
+        for (int k = 0; k < d; ++k) lkey[k * kSubT + i] = keys[((size_t)C.off + g) * d + k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int L = 0; L < r; ++L) {
+        for (int node = lane; node < (1 << L); node += 64) {
+            int ns, ne;
+            node_range(m, L, node, ns, ne);
+            if (ne - ns > 1) {
+                const int dim = split_dim(lkey, kSubT, d, lidx, ns, ne);
+                select_nth(lidx + ns, lidx + (ns + ne) / 2, lidx + ne, lkey + dim * kSubT);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int i = lane; i < m; i += 64) idx[base + i] = lgid[lidx[i]];
+}
+
+__global__ void big_iota_kernel(const BigCloud* __restrict__ tab, int n_clouds, int total, int* __restrict__ idx) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    int lo = 0, hi = n_clouds - 1;  // cloud of position p
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (tab[mid].off <= p) lo = mid;
+        else hi = mid - 1;
+    }
+    idx[p] = p - tab[lo].off;
+}
+
+// leaves of the main tree -> two slots each (balltree.h:137-155); slot_off[c] = first slot of cloud c
+__global__ void big_emit_kernel(const BigCloud* __restrict__ tab, const int* __restrict__ slot_off, int n_clouds,
+                                int total_leaves, const int* __restrict__ idx, int32_t* __restrict__ tree_idx,
+                                uint8_t* __restrict__ tree_mask) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_leaves) return;
+    int lo = 0, hi = n_clouds - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (slot_off[mid] <= 2 * t) lo = mid;
+        else hi = mid - 1;
+    }
+    const BigCloud C = tab[lo];
+    const int j = t - slot_off[lo] / 2;
+    int s, e;
+    node_range(C.n, C.levels, j, s, e);
+    const int a = idx[(size_t)C.off + s], b = (e - s == 1) ? a : idx[(size_t)C.off + s + 1];
+    tree_idx[2 * (size_t)t] = C.off + a;
+    tree_idx[2 * (size_t)t + 1] = C.off + b;
+    tree_mask[2 * (size_t)t] = 1;
+    tree_mask[2 * (size_t)t + 1] = (e - s == 1) ? 0 : 1;
+}
+
+struct Rot9 {
+    float r[9];
+};
+// rotated leaves (balltree.pyx:639-646): fp32 leaves @ R, leaves in tree-slot order
+__global__ void big_rotate_kernel(const float* __restrict__ pos, const int32_t* __restrict__ tree_idx, int total, int d,
+                                  Rot9 R, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float* p = pos + (size_t)tree_idx[i] * d;
+    for (int j = 0; j < d; ++j) {
+        float acc = p[0] * R.r[j];
+        for (int k = 1; k < d; ++k) acc = fmaf(p[k], R.r[k * d + j], acc);
+        out[(size_t)i * d + j] = acc;
+    }
+}
+// mean over `st` consecutive leaves (balltree.pyx:658-660)
+__global__ void big_pool_kernel(const float* __restrict__ cur, int n2, int d, int st, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    for (int j = 0; j < d; ++j) {
+        float sum = cur[((size_t)i * st) * d + j];
+        for (int q = 1; q < st; ++q) sum += cur[((size_t)i * st + q) * d + j];
+        out[(size_t)i * d + j] = sum / (float)st;
+    }
+}
+__global__ void big_rot_out_kernel(const BigCloud* __restrict__ tab, int n_clouds, int total, const int* __restrict__ idx,
+                                   int32_t* __restrict__ rot) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    int lo = 0, hi = n_clouds - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (tab[mid].off <= p) lo = mid;
+        else hi = mid - 1;
+    }
+    rot[p] = tab[lo].off + idx[p];
+}
+
+// ----------------------------------------------------------------------------------------------- host side
+struct BigWs {  // carve-up of the caller's workspace
+    int *idx, *gid, *w, *LS, *RS;
+    float* knode;
+    float *rk_a, *rk_b;
+    BigCloud* tab;
+    int* slot_off;
+    int2* work;
+    size_t work_cap;
+};
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int ceil_log2(long long n) {  // ceil(log2(n)), n >= 1
+    int b = 0;
+    while ((1ll << b) < n) ++b;
+    return b;
+}
+static size_t big_slots(const int32_t* sizes, int n_clouds) {
+    size_t t = 0;
+    for (int c = 0; c < n_clouds; ++c) t += (size_t)1 << ceil_log2(sizes[c] < 2 ? 2 : sizes[c]);
+    return t;
+}
+static size_t big_work_cap(size_t nmax, int n_clouds) { return 4 * (nmax / kSubT + 1) + 4 * (size_t)n_clouds + 64; }
+
+static size_t big_carve(char* p, size_t nmax, size_t nt, int d, int n_clouds, BigWs* ws) {
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        char* r = p ? p + o : nullptr;
+        o += align256(bytes);
+        return r;
+    };
+    int* a = (int*)take(nmax * 4);
+    int* b = (int*)take(nmax * 4);
+    int* c = (int*)take(nmax * 4);
+    int* e = (int*)take((nmax + 1) * 4);
+    int* f = (int*)take((nmax + 1) * 4);
+    float* k = (float*)take(nmax * 4);
+    float* ra = (float*)take(nt * d * 4);
+    float* rb = (float*)take(nt * d * 4);
+    BigCloud* tab = (BigCloud*)take((size_t)n_clouds * sizeof(BigCloud));
+    int* so = (int*)take((size_t)n_clouds * 4);
+    const size_t cap = big_work_cap(nmax, n_clouds);
+    int2* wk = (int2*)take(cap * sizeof(int2));
+    if (ws) *ws = BigWs{a, b, c, e, f, k, ra, rb, tab, so, wk, cap};
+    return o;
+}
+
+// One partition run: clouds (off, n, levels) over item keys [total][d]; leaves the permutation in ws.idx.
+static int big_partition(const float* keys, int d, std::vector<BigCloud>& clouds, int total, const BigWs& ws,
+                         hipStream_t st) {
+    const int nc = (int)clouds.size();
+    int max_top = 0;
+    for (auto& C : clouds) {
+        int top = 0;
+        while (top < C.levels && ((C.n + (1 << top) - 1) >> top) > kSubT) ++top;  // ceil(n / 2^top) bounds every node
+        C.top = top;
+        max_top = top > max_top ? top : max_top;
+    }
+    if (hipMemcpyAsync(ws.tab, clouds.data(), nc * sizeof(BigCloud), hipMemcpyHostToDevice, st) != hipSuccess)
+        return fail(HAET_E_LAUNCH, "balltree_big: table upload failed");
+    hipLaunchKernelGGL(big_iota_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws.tab, nc, total, ws.idx);
+    std::vector<int2> work;
+    std::vector<size_t> lvl_off(max_top + 2, 0);
+    for (int L = 0; L <= max_top; ++L) {  // levels [0, max_top): top launches; entry max_top: the sub-tree roots
+        lvl_off[L] = work.size();
+        for (int c = 0; c < nc; ++c) {
+            const BigCloud& C = clouds[c];
+            if (L < max_top) {
+                if (C.top > L)
+                    for (int j = 0; j < (1 << L); ++j) work.push_back(int2{c, j});
+            } else if (C.levels > C.top) {
+                for (int j = 0; j < (1 << C.top); ++j) work.push_back(int2{c, j});
+            }
+        }
+    }
+    lvl_off[max_top + 1] = work.size();
+    if (work.size() > ws.work_cap) return fail(HAET_E_ARG, "balltree_big: work list %zu > %zu", work.size(), ws.work_cap);
+    if (!work.empty() &&
+        hipMemcpyAsync(ws.work, work.data(), work.size() * sizeof(int2), hipMemcpyHostToDevice, st) != hipSuccess)
+        return fail(HAET_E_LAUNCH, "balltree_big: work list upload failed");
+    for (int L = 0; L < max_top; ++L) {
+        const int nb = (int)(lvl_off[L + 1] - lvl_off[L]);
+        if (nb > 0)
+            hipLaunchKernelGGL(big_top_kernel, dim3(nb), dim3(kTopThreads), 0, st, keys, d, ws.tab, ws.work + lvl_off[L], L,
+                               ws.idx, ws.gid, ws.knode, ws.w, ws.LS, ws.RS);
+    }
+    const int nsub = (int)(lvl_off[max_top + 1] - lvl_off[max_top]);
+    if (nsub > 0)
+        hipLaunchKernelGGL(big_sub_kernel, dim3(nsub), dim3(64), 0, st, keys, d, ws.tab, ws.work + lvl_off[max_top], ws.idx);
+    // the uploads above read host vectors that die with this frame
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(HAET_E_LAUNCH, "balltree_big: %s", hipGetErrorString(hipGetLastError()));
+    return check_launch("balltree_big partition");
+}
+
+}  // namespace haet
+
+using namespace haet;
+
+extern "C" size_t haet_balltree_big_slots(const int32_t* cloud_sizes, int n_clouds) {
+    if (!cloud_sizes || n_clouds < 1) return 0;
+    return big_slots(cloud_sizes, n_clouds);
+}
+
+extern "C" size_t haet_balltree_big_workspace_bytes(const int32_t* cloud_sizes, int n_clouds, int d) {
+    if (!cloud_sizes || n_clouds < 1) return 0;
+    const size_t nt = big_slots(cloud_sizes, n_clouds);
+    return big_carve(nullptr, nt, nt, d, n_clouds, nullptr);
+}
+
+extern "C" int haet_balltree_big_build(const float* pos, const int32_t* cloud_sizes, int n_clouds, int d, int n_levels,
+                                       const int32_t* strides, const int32_t* ball_sizes, float angle_deg,
+                                       int32_t* tree_idx, uint8_t* tree_mask, int32_t* rot, void* workspace,
+                                       size_t workspace_bytes, haet_stream_t stream) {
+    if (!pos || !cloud_sizes || !tree_idx || !tree_mask || !workspace || n_clouds < 1)
+        return fail(HAET_E_ARG, "balltree_big: null pointer");
+    if (d != 2 && d != 3) return fail(HAET_E_ARG, "balltree_big: d=%d", d);
+    if (n_levels < 1 || n_levels > HAET_ERWIN_MAX_LEVELS) return fail(HAET_E_ARG, "balltree_big: n_levels=%d", n_levels);
+    long long N = 0;
+    for (int c = 0; c < n_clouds; ++c) {
+        if (cloud_sizes[c] < 2) return fail(HAET_E_ARG, "balltree_big: cloud %d has %d points (at least 2)", c, cloud_sizes[c]);
+        N += cloud_sizes[c];
+    }
+    const size_t nt = big_slots(cloud_sizes, n_clouds);
+    if (nt > (size_t)1 << 30) return fail(HAET_E_ARG, "balltree_big: %zu tree slots", nt);
+    BigWs ws;
+    const size_t need = big_carve((char*)workspace, nt, nt, d, n_clouds, &ws);
+    if (workspace_bytes < need) return fail(HAET_E_ARG, "balltree_big: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+
+    // main tree: ceil(log2 n) - 1 levels of median splits, then leaves of one or two points (balltree.pyx:55-60)
+    std::vector<BigCloud> clouds(n_clouds);
+    std::vector<int> slot_off(n_clouds);
+    {
+        int off = 0;
+        size_t so = 0;
+        for (int c = 0; c < n_clouds; ++c) {
+            const int lv = ceil_log2(cloud_sizes[c]) - 1;
+            clouds[c] = BigCloud{off, cloud_sizes[c], lv, 0};
+            slot_off[c] = (int)so;
+            off += cloud_sizes[c];
+            so += (size_t)2 << lv;
+        }
+    }
+    int rc = big_partition(pos, d, clouds, (int)N, ws, st);
+    if (rc != HAET_OK) return rc;
+    if (hipMemcpyAsync(ws.slot_off, slot_off.data(), n_clouds * 4, hipMemcpyHostToDevice, st) != hipSuccess)
+        return fail(HAET_E_LAUNCH, "balltree_big: upload failed");
+    hipLaunchKernelGGL(big_emit_kernel, dim3((unsigned)((nt / 2 + 255) / 256)), dim3(256), 0, st, ws.tab, ws.slot_off, n_clouds,
+                       (int)(nt / 2), ws.idx, tree_idx, tree_mask);
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(HAET_E_LAUNCH, "balltree_big: emit failed");
+    if (!(angle_deg > 0.f)) return check_launch("balltree_big");
+
+    // rotated re-partitions (balltree.pyx:636-660)
+    if (!rot || !ball_sizes || (n_levels > 1 && !strides)) return fail(HAET_E_ARG, "balltree_big: rot/ball_sizes/strides missing");
+    Rot9 R;
+    rotation_matrix_f32(angle_deg, d, R.r);
+    hipLaunchKernelGGL(big_rotate_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, pos, tree_idx, (int)nt, d, R, ws.rk_a);
+    float *cur = ws.rk_a, *nxt = ws.rk_b;
+    size_t rot_off = 0;
+    long long div = 1;
+    for (int lev = 0; lev < n_levels; ++lev) {
+        if (ball_sizes[lev] < 1) return fail(HAET_E_ARG, "balltree_big: ball size %d", ball_sizes[lev]);
+        // NB: the TOTAL level-0 leaf count over all clouds enters (reference quirk, balltree.pyx:643)
+        const double ratio = (double)nt / (double)ball_sizes[lev];
+        int target = (int)std::log2(ratio);
+        if (target < 0) target = 0;
+        int off = 0;
+        for (int c = 0; c < n_clouds; ++c) {
+            const long long slots = ((long long)2 << (ceil_log2(cloud_sizes[c]) - 1));
+            if (slots % div) return fail(HAET_E_ARG, "balltree_big: strides do not divide cloud %d's %lld slots", c, slots);
+            const int n = (int)(slots / div);
+            int lg = 0;
+            while ((1 << (lg + 1)) <= n) ++lg;
+            // partition_ball_tree stops at the target level or at single points (balltree.h:221-229); n is a power of two
+            clouds[c] = BigCloud{off, n, target < lg ? target : lg, 0};
+            off += n;
+        }
+        const int total = off;
+        rc = big_partition(cur, d, clouds, total, ws, st);
+        if (rc != HAET_OK) return rc;
+        hipLaunchKernelGGL(big_rot_out_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws.tab, n_clouds, total, ws.idx,
+                           rot + rot_off);
+        rot_off += total;
+        if (lev < n_levels - 1) {
+            const int stv = strides[lev];
+            if (stv < 1 || total % stv) return fail(HAET_E_ARG, "balltree_big: stride %d", stv);
+            hipLaunchKernelGGL(big_pool_kernel, dim3((total / stv + 255) / 256), dim3(256), 0, st, cur, total / stv, d, stv, nxt);
+            float* t = cur;
+            cur = nxt;
+            nxt = t;
+            div *= stv;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(HAET_E_LAUNCH, "balltree_big: rotated level %d failed", lev);
+    }
+    return check_launch("balltree_big");
+}

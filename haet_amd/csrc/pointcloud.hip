@@ -1,0 +1,659 @@
+// Stand-alone ErwinFlash on RAW point clouds (models/components/erwinflash/erwin_flash.py:138-195 with
+// embed=True / mp_steps>0, benchmarks/02.1-Car-Design-ShapeNetCar/main.py:50-99): tens of thousands to millions of
+// points instead of <= 512 slice tokens, so the state lives in HBM ([tree slots][channels] fp32, tree order) and every
+// stage is a streaming pass over it -- the Linears are the split-bf16 GEMMs of gemm_x3.hip, everything in between is
+// here: radius graph, MPNN message / aggregate / update, RMSNorm + positional term, per-ball attention, SwiGLU gate,
+// BallPooling / BallUnpooling gathers, BatchNorm1d (batch statistics or running statistics), gathers / scatters of
+// the tree order.  One wave per row, 16-B accesses, fp32 arithmetic throughout.
+#include "common.h"
+
+#include <cfloat>
+
+namespace haet {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int kRowsPerBlock = 4;  // 256 threads = 4 waves = 4 rows
+
+__device__ __forceinline__ float pc_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float pc_silu(float v) { return v / (1.0f + expf(-v)); }
+
+// a row of c floats (c % 4 == 0, c <= 256 NV) spread over the wave: lane holds chunks lane, lane + 64, ...
+template <int NV>
+struct Row {
+    f32x4 v[NV];
+    __device__ __forceinline__ void load(const float* p, int c, int lane) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int ch = 4 * (lane + 64 * i);
+            v[i] = ch < c ? *reinterpret_cast<const f32x4*>(p + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __device__ __forceinline__ void store(float* p, int c, int lane) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int ch = 4 * (lane + 64 * i);
+            if (ch < c) *reinterpret_cast<f32x4*>(p + ch) = v[i];
+        }
+    }
+    __device__ __forceinline__ float sum() const {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        return wave_sum(s);
+    }
+    __device__ __forceinline__ float sumsq() const {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s = fmaf(v[i][q], v[i][q], s);
+        return wave_sum(s);
+    }
+};
+
+#define PC_ROW_PROLOGUE(ROWS)                                          \
+    const int lane = threadIdx.x & 63;                                 \
+    const long long row = (long long)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6); \
+    if (row >= (ROWS)) return;
+
+// dispatch on the row width (c <= 1024, c % 4 == 0)
+#define PC_DISPATCH(c, KERNEL, ...)                                                            \
+    do {                                                                                       \
+        if ((c) <= 256) hipLaunchKernelGGL((KERNEL<1>), __VA_ARGS__);                          \
+        else if ((c) <= 512) hipLaunchKernelGGL((KERNEL<2>), __VA_ARGS__);                     \
+        else hipLaunchKernelGGL((KERNEL<4>), __VA_ARGS__);                                     \
+    } while (0)
+
+static inline dim3 row_grid(long long rows) { return dim3((unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock)); }
+static inline bool width_ok(int c) { return c >= 4 && c % 4 == 0 && c <= 1024; }
+
+// ------------------------------------------------------------------------------------------------ gathers
+template <int NV>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, int ldx, const int32_t* __restrict__ idx,
+                                                         long long rows, int c, float* __restrict__ out, int ldo) {
+    PC_ROW_PROLOGUE(rows)
+    Row<NV> r;
+    r.load(x + (size_t)idx[row] * ldx, c, lane);
+    r.store(out + (size_t)row * ldo, c, lane);
+}
+
+// out[tree_idx[s]] = X[s] for the slots that hold an original point (erwin_flash.py:193)
+template <int NV>
+__global__ __launch_bounds__(256) void scatter_masked_kernel(const float* __restrict__ X, int ldx, const int32_t* __restrict__ tree_idx,
+                                                            const uint8_t* __restrict__ mask, long long rows, int c,
+                                                            float* __restrict__ out, int ldo) {
+    PC_ROW_PROLOGUE(rows)
+    if (!mask[row]) return;
+    Row<NV> r;
+    r.load(X + (size_t)row * ldx, c, lane);
+    r.store(out + (size_t)tree_idx[row] * ldo, c, lane);
+}
+
+// X[perm[p]] (or X[p]) += R[p]
+template <int NV>
+__global__ __launch_bounds__(256) void rows_add_kernel(float* __restrict__ X, int ldx, const int32_t* __restrict__ perm,
+                                                      const float* __restrict__ R, int ldr, long long rows, int c) {
+    PC_ROW_PROLOGUE(rows)
+    const long long slot = perm ? perm[row] : row;
+    Row<NV> a, b;
+    a.load(X + (size_t)slot * ldx, c, lane);
+    b.load(R + (size_t)row * ldr, c, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a.v[i] += b.v[i];
+    a.store(X + (size_t)slot * ldx, c, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ Erwin block pieces
+// rel[p] = P[slot(p)] - mean over p's ball (attention.py:35-40); one wave per ball, sequence order
+__global__ __launch_bounds__(256) void ball_rel_kernel(const float* __restrict__ P, const int32_t* __restrict__ perm, long long n_balls,
+                                                      int ball, int d, float* __restrict__ rel) {
+    PC_ROW_PROLOGUE(n_balls)
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int q = lane; q < ball; q += 64) {
+        const long long p = row * ball + q, slot = perm ? perm[p] : p;
+        for (int k = 0; k < d; ++k) s[k] += P[(size_t)slot * d + k];
+    }
+    for (int k = 0; k < d; ++k) s[k] = wave_sum(s[k]) / (float)ball;
+    for (int q = lane; q < ball; q += 64) {
+        const long long p = row * ball + q, slot = perm ? perm[p] : p;
+        for (int k = 0; k < d; ++k) rel[(size_t)p * d + k] = P[(size_t)slot * d + k] - s[k];
+    }
+}
+
+// Y[p] = RMSNorm(X[slot(p)]) * w (+ pe_w rel[p] + pe_b)   (layers.py:25-32, attention.py:59-61; nn.RMSNorm eps=None
+// -> machine epsilon)
+template <int NV>
+__global__ __launch_bounds__(256) void rms_pe_kernel(const float* __restrict__ X, int ldx, const int32_t* __restrict__ perm,
+                                                    const float* __restrict__ rel, long long rows, int c, int d,
+                                                    const float* __restrict__ w, const float* __restrict__ pe_w,
+                                                    const float* __restrict__ pe_b, float* __restrict__ Y, int ldy) {
+    PC_ROW_PROLOGUE(rows)
+    const long long slot = perm ? perm[row] : row;
+    Row<NV> r;
+    r.load(X + (size_t)slot * ldx, c, lane);
+    const float rstd = rsqrtf(r.sumsq() / (float)c + FLT_EPSILON);
+    float rp[3] = {0.f, 0.f, 0.f};
+    if (pe_w)
+        for (int k = 0; k < d; ++k) rp[k] = rel[(size_t)row * d + k];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int ch = 4 * (lane + 64 * i);
+        if (ch < c) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + ch);
+            f32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                o[q] = r.v[i][q] * rstd * wv[q];
+                if (pe_w) {
+                    float pe = pe_b[ch + q];
+                    for (int k = 0; k < d; ++k) pe = fmaf(pe_w[(size_t)(ch + q) * d + k], rp[k], pe);
+                    o[q] += pe;
+                }
+            }
+            *reinterpret_cast<f32x4*>(Y + (size_t)row * ldy + ch) = o;
+        }
+    }
+}
+
+// softmax(Q K^T / sqrt(hd)) V inside every ball, per head (attention.py:63-91; flash_attn_qkvpacked_func's contract).
+// One workgroup per ball: K and V of all heads in LDS, one (query, head) pair per thread at a time, online softmax.
+extern __shared__ __attribute__((aligned(16))) float pc_lds[];
+template <int HD>
+__global__ __launch_bounds__(256) void ball_attention_kernel(const float* __restrict__ qkv, int ldq, int c, int heads, int ball,
+                                                            float scale, float* __restrict__ out, int ldo) {
+    float* const Ks = pc_lds;
+    float* const Vs = pc_lds + (size_t)ball * c;
+    const size_t r0 = (size_t)blockIdx.x * ball;
+    for (int i = threadIdx.x; i < ball * (c / 4); i += 256) {
+        const int j = i / (c / 4), ch = 4 * (i % (c / 4));
+        *reinterpret_cast<f32x4*>(Ks + (size_t)j * c + ch) = *reinterpret_cast<const f32x4*>(qkv + (r0 + j) * ldq + c + ch);
+        *reinterpret_cast<f32x4*>(Vs + (size_t)j * c + ch) = *reinterpret_cast<const f32x4*>(qkv + (r0 + j) * ldq + 2 * c + ch);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ball * heads; t += 256) {
+        const int h = t / ball, i = t % ball;
+        float q[HD], acc[HD];
+#pragma unroll
+        for (int e = 0; e < HD; e += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(qkv + (r0 + i) * ldq + h * HD + e);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[e + u] = v[u] * scale, acc[e + u] = 0.f;
+        }
+        float mx = -INFINITY, l = 0.f;
+        for (int j = 0; j < ball; ++j) {
+            const float* kj = Ks + (size_t)j * c + h * HD;
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < HD; ++e) s = fmaf(q[e], kj[e], s);
+            const float nm = fmaxf(mx, s);
+            const float corr = expf(mx - nm), pj = expf(s - nm);
+            const float* vj = Vs + (size_t)j * c + h * HD;
+            l = fmaf(l, corr, pj);
+#pragma unroll
+            for (int e = 0; e < HD; ++e) acc[e] = fmaf(acc[e], corr, pj * vj[e]);
+            mx = nm;
+        }
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int e = 0; e < HD; e += 4) {
+            const f32x4 o = {acc[e] * inv, acc[e + 1] * inv, acc[e + 2] * inv, acc[e + 3] * inv};
+            *reinterpret_cast<f32x4*>(out + (r0 + i) * ldo + h * HD + e) = o;
+        }
+    }
+}
+
+// H[p][j] = U[p][hid + j] * silu(U[p][j])   (mlp.py:17-18 with w1 | w2 as one GEMM)
+template <int NV>
+__global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ U, int ldu, long long rows, int hid,
+                                                    float* __restrict__ H, int ldh) {
+    PC_ROW_PROLOGUE(rows)
+    Row<NV> a, b;
+    a.load(U + (size_t)row * ldu, hid, lane);
+    b.load(U + (size_t)row * ldu + hid, hid, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a.v[i][q] = b.v[i][q] * pc_silu(a.v[i][q]);
+    a.store(H + (size_t)row * ldh, hid, lane);
+}
+
+// BallPooling input (pooling.py:28-37): Y[i] = [x of the stride children | their positions relative to the centre | 0 pad],
+// centre[i] = mean of the children's positions
+template <int NV>
+__global__ __launch_bounds__(256) void pool_gather_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ P,
+                                                         long long rows, int c, int d, int st, float* __restrict__ Y, int ldy,
+                                                         float* __restrict__ Pc) {
+    PC_ROW_PROLOGUE(rows)
+    for (int q = 0; q < st; ++q) {
+        Row<NV> r;
+        r.load(X + (size_t)(row * st + q) * ldx, c, lane);
+        r.store(Y + (size_t)row * ldy + (size_t)q * c, c, lane);
+    }
+    float ctr[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < d; ++k) {
+        float s = P[(size_t)(row * st) * d + k];
+        for (int q = 1; q < st; ++q) s += P[(size_t)(row * st + q) * d + k];
+        ctr[k] = s / (float)st;
+    }
+    const int tail0 = st * c, tail = ldy - tail0;
+    for (int t = lane; t < tail; t += 64) {
+        float v = 0.f;
+        if (t < st * d) v = P[(size_t)(row * st + t / d) * d + t % d] - ctr[t % d];
+        Y[(size_t)row * ldy + tail0 + t] = v;
+    }
+    if (lane < d) Pc[(size_t)row * d + lane] = ctr[lane];
+}
+
+// BallUnpooling input (pooling.py:58-66): Y[i] = [x_parent | child positions relative to the parent | 0 pad]
+template <int NV>
+__global__ __launch_bounds__(256) void unpool_input_kernel(const float* __restrict__ Xp, int ldx, const float* __restrict__ Pp,
+                                                          const float* __restrict__ Pchild, long long rows, int c, int d, int st,
+                                                          float* __restrict__ Y, int ldy) {
+    PC_ROW_PROLOGUE(rows)
+    Row<NV> r;
+    r.load(Xp + (size_t)row * ldx, c, lane);
+    r.store(Y + (size_t)row * ldy, c, lane);
+    const int tail = ldy - c;
+    for (int t = lane; t < tail; t += 64) {
+        float v = 0.f;
+        if (t < st * d) v = Pchild[(size_t)(row * st + t / d) * d + t % d] - Pp[(size_t)row * d + t % d];
+        Y[(size_t)row * ldy + c + t] = v;
+    }
+}
+
+// child[t] = child_skip[t] + Yp[t / st][(t % st) c ...]   (pooling.py:67)
+template <int NV>
+__global__ __launch_bounds__(256) void unpool_merge_kernel(const float* __restrict__ skip, int lds_, const float* __restrict__ Yp, int ldy,
+                                                          long long rows, int c, int st, float* __restrict__ out, int ldo) {
+    PC_ROW_PROLOGUE(rows)
+    Row<NV> a, b;
+    a.load(skip + (size_t)row * lds_, c, lane);
+    b.load(Yp + (size_t)(row / st) * ldy + (size_t)(row % st) * c, c, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a.v[i] += b.v[i];
+    a.store(out + (size_t)row * ldo, c, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm1d
+// per-workgroup (count, mean, M2) of every channel over a chunk of rows; combined by bn_finalize_kernel (Chan et al.)
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ X, int ldx, long long rows, int c,
+                                                        long long rows_per_block, float* __restrict__ part /*[blocks][2][c]*/) {
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    const float n = (float)(r1 - r0);
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        float s = 0.f;
+        for (long long r = r0; r < r1; ++r) s += X[(size_t)r * ldx + ch];
+        const float mean = s / n;
+        float m2 = 0.f;
+        for (long long r = r0; r < r1; ++r) {
+            const float dlt = X[(size_t)r * ldx + ch] - mean;
+            m2 = fmaf(dlt, dlt, m2);
+        }
+        part[((size_t)blockIdx.x * 2) * c + ch] = mean;
+        part[((size_t)blockIdx.x * 2 + 1) * c + ch] = m2;
+    }
+}
+// stats[0][ch] = mean, stats[1][ch] = biased variance; running statistics updated like nn.BatchNorm1d in train mode
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int blocks, long long rows,
+                                                         long long rows_per_block, int c, float momentum,
+                                                         float* __restrict__ stats, float* __restrict__ run_mean,
+                                                         float* __restrict__ run_var, long long* __restrict__ nbt) {
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch == 0 && nbt) *nbt += 1;
+    if (ch >= c) return;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int b = 0; b < blocks; ++b) {
+        const long long r0 = (long long)b * rows_per_block;
+        const double nb = (double)((r0 + rows_per_block < rows ? r0 + rows_per_block : rows) - r0);
+        const double mb = part[((size_t)b * 2) * c + ch], m2b = part[((size_t)b * 2 + 1) * c + ch];
+        const double dlt = mb - mean, nn = n + nb;
+        mean += dlt * nb / nn;
+        m2 += m2b + dlt * dlt * n * nb / nn;
+        n = nn;
+    }
+    const float var = (float)(m2 / n);
+    stats[ch] = (float)mean;
+    stats[c + ch] = var;
+    if (run_mean) {
+        run_mean[ch] = (1.f - momentum) * run_mean[ch] + momentum * (float)mean;
+        run_var[ch] = (1.f - momentum) * run_var[ch] + momentum * (float)(m2 / (n > 1.0 ? n - 1.0 : 1.0));
+    }
+}
+template <int NV>
+__global__ __launch_bounds__(256) void bn_apply_kernel(float* __restrict__ X, int ldx, long long rows, int c,
+                                                      const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta) {
+    PC_ROW_PROLOGUE(rows)
+    Row<NV> r;
+    r.load(X + (size_t)row * ldx, c, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int ch = 4 * (lane + 64 * i);
+        if (ch < c) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                r.v[i][q] = (r.v[i][q] - mean[ch + q]) * rsqrtf(var[ch + q] + eps) * gamma[ch + q] + beta[ch + q];
+        }
+    }
+    r.store(X + (size_t)row * ldx, c, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ MPNN (mpnn.py:48-75)
+// Linear([h_j, h_i, pos_j - pos_i]) = A[j] + B[i] + Wc (pos_j - pos_i) + b with A = h Wa^T, B = h Wb^T computed ONCE PER
+// NODE (AB = [A | B], one GEMM over N rows instead of one over E edges); this kernel finishes the message per edge --
+// GELU, LayerNorm without affine -- and averages the messages that END in node i (scatter_mean over edge_index[1]):
+// one wave per receiving node over its CSR segment, no atomics.
+template <int NV>
+__global__ __launch_bounds__(256) void mpnn_message_kernel(const float* __restrict__ AB, int ldab, const float* __restrict__ pos, int d,
+                                                          const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
+                                                          const float* __restrict__ Wc /*[c][d]*/, const float* __restrict__ bias,
+                                                          long long rows, int c, float eps, float* __restrict__ out, int ldo) {
+    PC_ROW_PROLOGUE(rows)
+    Row<NV> b, acc;
+    b.load(AB + (size_t)row * ldab + c, c, lane);
+    f32x4 wc[NV][3];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int ch = 4 * (lane + 64 * i);
+        acc.v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (ch < c) b.v[i][q] += bias[ch + q];
+            for (int k = 0; k < 3; ++k) wc[i][k][q] = (ch < c && k < d) ? Wc[(size_t)(ch + q) * d + k] : 0.f;
+        }
+    }
+    float pi[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < d; ++k) pi[k] = pos[(size_t)row * d + k];
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    for (int e = e0; e < e1; ++e) {
+        const int j = src[e];
+        float dp[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < d; ++k) dp[k] = pos[(size_t)j * d + k] - pi[k];
+        Row<NV> m;
+        m.load(AB + (size_t)j * ldab, c, lane);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = m.v[i][q] + b.v[i][q];
+                v = fmaf(wc[i][0][q], dp[0], v);
+                v = fmaf(wc[i][1][q], dp[1], v);
+                v = fmaf(wc[i][2][q], dp[2], v);
+                m.v[i][q] = (4 * (lane + 64 * i) < c) ? pc_gelu(v) : 0.f;
+            }
+        const float mean = m.sum() / (float)c;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float dv = (4 * (lane + 64 * i) < c) ? m.v[i][q] - mean : 0.f;
+                m.v[i][q] = dv;
+                ss = fmaf(dv, dv, ss);
+            }
+        const float rstd = rsqrtf(wave_sum(ss) / (float)c + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc.v[i] += m.v[i] * rstd;
+    }
+    const float inv = 1.0f / (float)(e1 > e0 ? e1 - e0 : 1);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc.v[i] *= inv;
+    acc.store(out + (size_t)row * ldo, c, lane);
+}
+
+// h += LayerNorm_noaffine(u); h is also mirrored into a second buffer (the left half of the update GEMM's input)
+template <int NV>
+__global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restrict__ u, int ldu, long long rows, int c, float eps,
+                                                         float* __restrict__ h, int ldh, float* __restrict__ h2, int ldh2) {
+    PC_ROW_PROLOGUE(rows)
+    Row<NV> r, hv;
+    r.load(u + (size_t)row * ldu, c, lane);
+    hv.load(h + (size_t)row * ldh, c, lane);
+    const float mean = r.sum() / (float)c;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float dv = (4 * (lane + 64 * i) < c) ? r.v[i][q] - mean : 0.f;
+            r.v[i][q] = dv;
+            ss = fmaf(dv, dv, ss);
+        }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)c + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) hv.v[i] += r.v[i] * rstd;
+    hv.store(h + (size_t)row * ldh, c, lane);
+    if (h2) hv.store(h2 + (size_t)row * ldh2, c, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ radius graph
+// torch_cluster.radius_graph(pos, r, batch, loop=True, max_num_neighbors=32) as erwin_flash.py:160-166 calls it: for
+// every centre i the first `max_nbrs` points j of the same cloud, in index order, with |x_j - x_i|^2 < r^2 (fp32,
+// squared differences summed dimension by dimension, no fused multiply-add).  One thread per centre; the candidates of
+// the workgroup's cloud range are staged through LDS in tiles.
+constexpr int kRadTile = 1024;
+__global__ __launch_bounds__(256) void radius_kernel(const float* __restrict__ pos, const int32_t* __restrict__ cloud_lo,
+                                                    const int32_t* __restrict__ cloud_hi, int N, int d, float r2, int max_nbrs,
+                                                    int32_t* __restrict__ nbr, int32_t* __restrict__ cnt) {
+    __shared__ float tile[3 * kRadTile];
+    __shared__ int s_lo, s_hi, s_live;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool have = i < N;
+    const int lo = have ? cloud_lo[i] : 0x7fffffff, hi = have ? cloud_hi[i] : 0;
+    float xi[3] = {0.f, 0.f, 0.f};
+    if (have)
+        for (int k = 0; k < d; ++k) xi[k] = pos[(size_t)i * d + k];
+    if (threadIdx.x == 0) s_lo = 0x7fffffff, s_hi = 0;
+    __syncthreads();
+    atomicMin(&s_lo, lo);
+    atomicMax(&s_hi, hi);
+    __syncthreads();
+    const int blo = s_lo, bhi = s_hi;
+    int count = 0;
+    for (int t0 = blo; t0 < bhi; t0 += kRadTile) {
+        const int tn = min(kRadTile, bhi - t0);
+        __syncthreads();
+        if (threadIdx.x == 0) s_live = 0;
+        for (int q = threadIdx.x; q < tn * d; q += 256) tile[(q % d) * kRadTile + q / d] = pos[(size_t)t0 * d + q];
+        __syncthreads();
+        if (have && count < max_nbrs) {
+            const int j0 = max(lo, t0) - t0, j1 = min(hi, t0 + tn) - t0;
+            for (int j = j0; j < j1; ++j) {
+                float d2 = 0.f;
+                for (int k = 0; k < d; ++k) {
+                    const float df = __fsub_rn(tile[k * kRadTile + j], xi[k]);
+                    d2 = __fadd_rn(d2, __fmul_rn(df, df));
+                }
+                if (d2 < r2) {
+                    nbr[(size_t)i * max_nbrs + count] = t0 + j;
+                    if (++count >= max_nbrs) break;
+                }
+            }
+            if (count < max_nbrs && hi > t0 + tn) s_live = 1;
+        }
+        __syncthreads();
+        if (!s_live) break;  // every centre of this workgroup is full or past its cloud
+    }
+    if (have) cnt[i] = count;
+}
+// edge_index [2][E] (int64): row 0 = neighbour j, row 1 = centre i, grouped by centre (flow source_to_target)
+__global__ __launch_bounds__(256) void radius_fill_kernel(const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt,
+                                                         const int64_t* __restrict__ rowptr, int N, int max_nbrs, long long E,
+                                                         int64_t* __restrict__ edge_index) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const long long e0 = rowptr[i];
+    for (int q = 0; q < cnt[i]; ++q) {
+        edge_index[e0 + q] = nbr[(size_t)i * max_nbrs + q];
+        edge_index[E + e0 + q] = i;
+    }
+}
+
+}  // namespace haet
+
+using namespace haet;
+
+#define PC_CHECK_WIDTH(name, c) \
+    if (!width_ok(c)) return fail(HAET_E_ARG, name ": width %d (multiple of 4, <= 1024)", c)
+
+extern "C" int haet_pc_gather_rows(const float* x, int ldx, const int32_t* idx, long long rows, int c, float* out, int ldo,
+                                   haet_stream_t stream) {
+    if (!x || !idx || !out || rows < 1) return fail(HAET_E_ARG, "pc_gather_rows: bad arguments");
+    PC_CHECK_WIDTH("pc_gather_rows", c);
+    PC_DISPATCH(c, gather_rows_kernel, row_grid(rows), dim3(256), 0, as_stream(stream), x, ldx, idx, rows, c, out, ldo);
+    return check_launch("gather_rows_kernel");
+}
+
+extern "C" int haet_pc_scatter_masked(const float* X, int ldx, const int32_t* tree_idx, const uint8_t* mask, long long rows, int c,
+                                      float* out, int ldo, haet_stream_t stream) {
+    if (!X || !tree_idx || !mask || !out || rows < 1) return fail(HAET_E_ARG, "pc_scatter_masked: bad arguments");
+    PC_CHECK_WIDTH("pc_scatter_masked", c);
+    PC_DISPATCH(c, scatter_masked_kernel, row_grid(rows), dim3(256), 0, as_stream(stream), X, ldx, tree_idx, mask, rows, c, out, ldo);
+    return check_launch("scatter_masked_kernel");
+}
+
+extern "C" int haet_pc_rows_add(float* X, int ldx, const int32_t* perm, const float* R, int ldr, long long rows, int c,
+                                haet_stream_t stream) {
+    if (!X || !R || rows < 1) return fail(HAET_E_ARG, "pc_rows_add: bad arguments");
+    PC_CHECK_WIDTH("pc_rows_add", c);
+    PC_DISPATCH(c, rows_add_kernel, row_grid(rows), dim3(256), 0, as_stream(stream), X, ldx, perm, R, ldr, rows, c);
+    return check_launch("rows_add_kernel");
+}
+
+extern "C" int haet_pc_ball_rel(const float* P, const int32_t* perm, long long rows, int ball, int d, float* rel, haet_stream_t stream) {
+    if (!P || !rel || rows < 1 || ball < 1 || rows % ball || (d != 2 && d != 3)) return fail(HAET_E_ARG, "pc_ball_rel: bad arguments");
+    hipLaunchKernelGGL(ball_rel_kernel, row_grid(rows / ball), dim3(256), 0, as_stream(stream), P, perm, rows / ball, ball, d, rel);
+    return check_launch("ball_rel_kernel");
+}
+
+extern "C" int haet_pc_rms_pe(const float* X, int ldx, const int32_t* perm, const float* rel, long long rows, int c, int d,
+                              const float* w, const float* pe_w, const float* pe_b, float* Y, int ldy, haet_stream_t stream) {
+    if (!X || !w || !Y || rows < 1 || (pe_w && (!pe_b || !rel))) return fail(HAET_E_ARG, "pc_rms_pe: bad arguments");
+    PC_CHECK_WIDTH("pc_rms_pe", c);
+    PC_DISPATCH(c, rms_pe_kernel, row_grid(rows), dim3(256), 0, as_stream(stream), X, ldx, perm, rel, rows, c, d, w, pe_w, pe_b, Y, ldy);
+    return check_launch("rms_pe_kernel");
+}
+
+extern "C" int haet_pc_ball_attention_supported(int c, int heads, int ball) {
+    if (c < 8 || heads < 1 || c % heads || c % 4) return 0;
+    const int hd = c / heads;
+    if (hd != 8 && hd != 16 && hd != 32 && hd != 64) return 0;
+    return (ball >= 1 && (size_t)ball * c * 8 <= 144 * 1024) ? 1 : 0;
+}
+
+extern "C" int haet_pc_ball_attention(const float* qkv, int ldq, long long rows, int c, int heads, int ball, float* out, int ldo,
+                                      haet_stream_t stream) {
+    if (!qkv || !out || rows < 1 || ball < 1 || rows % ball) return fail(HAET_E_ARG, "pc_ball_attention: bad arguments");
+    if (!haet_pc_ball_attention_supported(c, heads, ball))
+        return fail(HAET_E_ARG, "pc_ball_attention: c=%d heads=%d ball=%d unsupported", c, heads, ball);
+    const int hd = c / heads;
+    const size_t lds = (size_t)ball * c * 8;
+    const float scale = 1.0f / sqrtf((float)hd);
+    auto go = [&](auto kern) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(rows / ball)), dim3(256), lds, as_stream(stream), qkv, ldq, c, heads, ball, scale, out, ldo);
+    };
+    switch (hd) {
+        case 8: go(ball_attention_kernel<8>); break;
+        case 16: go(ball_attention_kernel<16>); break;
+        case 32: go(ball_attention_kernel<32>); break;
+        default: go(ball_attention_kernel<64>); break;
+    }
+    return check_launch("ball_attention_kernel");
+}
+
+extern "C" int haet_pc_swiglu(const float* U, int ldu, long long rows, int hid, float* H, int ldh, haet_stream_t stream) {
+    if (!U || !H || rows < 1) return fail(HAET_E_ARG, "pc_swiglu: bad arguments");
+    PC_CHECK_WIDTH("pc_swiglu", hid);
+    PC_DISPATCH(hid, swiglu_kernel, row_grid(rows), dim3(256), 0, as_stream(stream), U, ldu, rows, hid, H, ldh);
+    return check_launch("swiglu_kernel");
+}
+
+extern "C" int haet_pc_pool_gather(const float* X, int ldx, const float* P, long long rows, int c, int d, int st, float* Y, int ldy,
+                                   float* Pc, haet_stream_t stream) {
+    if (!X || !P || !Y || !Pc || rows < 1 || st < 1 || ldy < st * (c + d)) return fail(HAET_E_ARG, "pc_pool_gather: bad arguments");
+    PC_CHECK_WIDTH("pc_pool_gather", c);
+    PC_DISPATCH(c, pool_gather_kernel, row_grid(rows), dim3(256), 0, as_stream(stream), X, ldx, P, rows, c, d, st, Y, ldy, Pc);
+    return check_launch("pool_gather_kernel");
+}
+
+extern "C" int haet_pc_unpool_input(const float* Xp, int ldx, const float* Pp, const float* Pchild, long long rows, int c, int d, int st,
+                                    float* Y, int ldy, haet_stream_t stream) {
+    if (!Xp || !Pp || !Pchild || !Y || rows < 1 || st < 1 || ldy < c + st * d) return fail(HAET_E_ARG, "pc_unpool_input: bad arguments");
+    PC_CHECK_WIDTH("pc_unpool_input", c);
+    PC_DISPATCH(c, unpool_input_kernel, row_grid(rows), dim3(256), 0, as_stream(stream), Xp, ldx, Pp, Pchild, rows, c, d, st, Y, ldy);
+    return check_launch("unpool_input_kernel");
+}
+
+extern "C" int haet_pc_unpool_merge(const float* skip, int lds_, const float* Yp, int ldy, long long rows, int c, int st, float* out,
+                                    int ldo, haet_stream_t stream) {
+    if (!skip || !Yp || !out || rows < 1 || st < 1 || rows % st) return fail(HAET_E_ARG, "pc_unpool_merge: bad arguments");
+    PC_CHECK_WIDTH("pc_unpool_merge", c);
+    PC_DISPATCH(c, unpool_merge_kernel, row_grid(rows), dim3(256), 0, as_stream(stream), skip, lds_, Yp, ldy, rows, c, st, out, ldo);
+    return check_launch("unpool_merge_kernel");
+}
+
+extern "C" int haet_pc_bn_blocks(long long rows) {
+    const long long b = (rows + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+extern "C" int haet_pc_bn_stats(const float* X, int ldx, long long rows, int c, float momentum, float* part, float* stats,
+                                float* run_mean, float* run_var, long long* nbt, haet_stream_t stream) {
+    if (!X || !part || !stats || rows < 1 || c < 1) return fail(HAET_E_ARG, "pc_bn_stats: bad arguments");
+    const int blocks = haet_pc_bn_blocks(rows);
+    const long long rpb = (rows + blocks - 1) / blocks;
+    const int used = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(used), dim3(256), 0, as_stream(stream), X, ldx, rows, c, rpb, part);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), part, used, rows, rpb, c, momentum,
+                       stats, run_mean, run_var, nbt);
+    return check_launch("bn_stats");
+}
+
+extern "C" int haet_pc_bn_apply(float* X, int ldx, long long rows, int c, const float* mean, const float* var, float eps,
+                                const float* gamma, const float* beta, haet_stream_t stream) {
+    if (!X || !mean || !var || !gamma || !beta || rows < 1) return fail(HAET_E_ARG, "pc_bn_apply: bad arguments");
+    PC_CHECK_WIDTH("pc_bn_apply", c);
+    PC_DISPATCH(c, bn_apply_kernel, row_grid(rows), dim3(256), 0, as_stream(stream), X, ldx, rows, c, mean, var, eps, gamma, beta);
+    return check_launch("bn_apply_kernel");
+}
+
+extern "C" int haet_pc_mpnn_message(const float* AB, int ldab, const float* pos, int d, const int32_t* rowptr, const int32_t* src,
+                                    const float* Wc, const float* bias, long long rows, int c, float eps, float* out, int ldo,
+                                    haet_stream_t stream) {
+    if (!AB || !pos || !rowptr || !src || !Wc || !bias || !out || rows < 1 || (d != 2 && d != 3))
+        return fail(HAET_E_ARG, "pc_mpnn_message: bad arguments");
+    PC_CHECK_WIDTH("pc_mpnn_message", c);
+    PC_DISPATCH(c, mpnn_message_kernel, row_grid(rows), dim3(256), 0, as_stream(stream), AB, ldab, pos, d, rowptr, src, Wc, bias, rows,
+                c, eps, out, ldo);
+    return check_launch("mpnn_message_kernel");
+}
+
+extern "C" int haet_pc_ln_residual(const float* u, int ldu, long long rows, int c, float eps, float* h, int ldh, float* h2, int ldh2,
+                                   haet_stream_t stream) {
+    if (!u || !h || rows < 1) return fail(HAET_E_ARG, "pc_ln_residual: bad arguments");
+    PC_CHECK_WIDTH("pc_ln_residual", c);
+    PC_DISPATCH(c, ln_residual_kernel, row_grid(rows), dim3(256), 0, as_stream(stream), u, ldu, rows, c, eps, h, ldh, h2, ldh2);
+    return check_launch("ln_residual_kernel");
+}
+
+extern "C" int haet_pc_radius_neighbours(const float* pos, const int32_t* cloud_lo, const int32_t* cloud_hi, int N, int d, float r,
+                                         int max_nbrs, int32_t* nbr, int32_t* cnt, haet_stream_t stream) {
+    if (!pos || !cloud_lo || !cloud_hi || !nbr || !cnt || N < 1 || (d != 2 && d != 3) || max_nbrs < 1)
+        return fail(HAET_E_ARG, "pc_radius_neighbours: bad arguments");
+    hipLaunchKernelGGL(radius_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), pos, cloud_lo, cloud_hi, N, d, r * r,
+                       max_nbrs, nbr, cnt);
+    return check_launch("radius_kernel");
+}
+
+extern "C" int haet_pc_radius_fill(const int32_t* nbr, const int32_t* cnt, const int64_t* rowptr, int N, int max_nbrs, long long E,
+                                   int64_t* edge_index, haet_stream_t stream) {
+    if (!nbr || !cnt || !rowptr || !edge_index || N < 1 || E < 0) return fail(HAET_E_ARG, "pc_radius_fill: bad arguments");
+    if (E == 0) return HAET_OK;
+    hipLaunchKernelGGL(radius_fill_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), nbr, cnt, rowptr, N, max_nbrs, E,
+                       edge_index);
+    return check_launch("radius_fill_kernel");
+}

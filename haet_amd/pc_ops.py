@@ -1,0 +1,232 @@
+"""Torch-tensor front-ends of the stand-alone ErwinFlash entry points (include/haet_hip.h, last section): the ball tree
+of raw point clouds, the radius graph, the MPNN stages and the streaming stages of the Erwin body.  Like ops.py these
+only validate, allocate outputs and pass raw pointers to libhaet_hip.so on the current HIP stream; no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import HaetError, check
+from .ops import SplitLinear, _f32, _p, _stream, linear
+
+Tensor = torch.Tensor
+
+
+def _i32_host(values: Sequence[int]):
+    return (ctypes.c_int32 * len(values))(*[int(v) for v in values])
+
+
+def round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+# --------------------------------------------------------------------------- tree
+def balltree_big(pos: Tensor, cloud_sizes: Sequence[int], strides: Sequence[int], ball_sizes: Sequence[int], angle: float):
+    """build_balltree_with_rotations (balltree.pyx:598-662) on the device for clouds of any size.
+    Returns (tree_idx int32 [slots], tree_mask uint8 [slots], [rot_i int32 | None per layer])."""
+    lib = _lib.load()
+    pos = _f32(pos, "pos")
+    N, d = pos.shape
+    if sum(cloud_sizes) != N:
+        raise HaetError(f"cloud sizes sum to {sum(cloud_sizes)}, positions have {N} rows")
+    if len(strides) != len(ball_sizes) - 1:
+        raise AssertionError("Strides must be one less than ball sizes")
+    nc = len(cloud_sizes)
+    sizes = _i32_host(cloud_sizes)
+    slots = lib.haet_balltree_big_slots(sizes, nc)
+    dev = pos.device
+    tree_idx = torch.empty(slots, dtype=torch.int32, device=dev)
+    tree_mask = torch.empty(slots, dtype=torch.uint8, device=dev)
+    level_sizes, n = [], slots
+    for i in range(len(ball_sizes)):
+        level_sizes.append(n)
+        if i < len(strides):
+            if n % strides[i]:
+                raise HaetError(f"stride {strides[i]} does not divide {n} tree slots")
+            n //= strides[i]
+    rot = torch.empty(sum(level_sizes), dtype=torch.int32, device=dev) if angle > 0 else None
+    ws = torch.empty(lib.haet_balltree_big_workspace_bytes(sizes, nc, d), dtype=torch.uint8, device=dev)
+    check(lib.haet_balltree_big_build(_p(pos), sizes, nc, d, len(ball_sizes), _i32_host(strides) if strides else None,
+                                      _i32_host(ball_sizes), float(angle), _p(tree_idx), _p(tree_mask), _p(rot), _p(ws),
+                                      ws.numel(), _stream()), "haet_balltree_big_build")
+    rots: List[Optional[Tensor]] = []
+    off = 0
+    for n in level_sizes:
+        rots.append(rot[off:off + n] if rot is not None else None)
+        off += n
+    return tree_idx, tree_mask, rots
+
+
+# --------------------------------------------------------------------------- radius graph / MPNN
+def radius_graph(pos: Tensor, r: float, batch_idx: Tensor, cloud_sizes: Sequence[int], max_num_neighbors: int = 32) -> Tensor:
+    """torch_cluster.radius_graph(pos, r, batch=batch_idx, loop=True) -> edge_index int64 [2, E] (erwin_flash.py:160-166)."""
+    lib = _lib.load()
+    pos = _f32(pos, "pos")
+    N, d = pos.shape
+    dev = pos.device
+    offs = torch.zeros(len(cloud_sizes) + 1, dtype=torch.int32, device=dev)
+    offs[1:] = torch.tensor(list(cloud_sizes), dtype=torch.int32, device=dev).cumsum(0)
+    b = batch_idx.to(torch.long)
+    lo, hi = offs[b].contiguous(), offs[b + 1].contiguous()
+    nbr = torch.empty((N, max_num_neighbors), dtype=torch.int32, device=dev)
+    cnt = torch.empty(N, dtype=torch.int32, device=dev)
+    check(lib.haet_pc_radius_neighbours(_p(pos), _p(lo), _p(hi), N, d, float(r), max_num_neighbors, _p(nbr), _p(cnt), _stream()),
+          "haet_pc_radius_neighbours")
+    rowptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = cnt.to(torch.int64).cumsum(0)
+    E = int(rowptr[-1].item())  # the edge list's size is data dependent: one host read, like the reference's own sync
+    edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
+    check(lib.haet_pc_radius_fill(_p(nbr), _p(cnt), _p(rowptr), N, max_num_neighbors, E, _p(edge_index), _stream()),
+          "haet_pc_radius_fill")
+    return edge_index
+
+
+def edges_to_csr(edge_index: Tensor, N: int):
+    """(rowptr int32 [N+1], src int32 [E]): the senders of every receiver's edges (receiver = edge_index[1])."""
+    row, col = edge_index[0].to(torch.long), edge_index[1].to(torch.long)
+    if col.numel() > 1 and not bool((col[1:] >= col[:-1]).all()):
+        col, order = torch.sort(col, stable=True)
+        row = row[order]
+    rowptr = torch.zeros(N + 1, dtype=torch.int32, device=edge_index.device)
+    rowptr[1:] = torch.bincount(col, minlength=N).cumsum(0).to(torch.int32)
+    return rowptr, row.to(torch.int32).contiguous()
+
+
+def mpnn_message(AB: Tensor, pos: Tensor, rowptr: Tensor, src: Tensor, Wc: Tensor, bias: Tensor, c: int, out: Tensor, eps: float = 1e-5):
+    lib = _lib.load()
+    N = pos.shape[0]
+    check(lib.haet_pc_mpnn_message(_p(AB), AB.stride(0), _p(pos), pos.shape[1], _p(rowptr), _p(src), _p(Wc), _p(bias), N, c, eps,
+                                   _p(out), out.stride(0), _stream()), "haet_pc_mpnn_message")
+
+
+def ln_residual(u: Tensor, h: Tensor, h2: Optional[Tensor], c: int, eps: float = 1e-5):
+    lib = _lib.load()
+    check(lib.haet_pc_ln_residual(_p(u), u.stride(0), h.shape[0], c, eps, _p(h), h.stride(0), _p(h2), 0 if h2 is None else h2.stride(0),
+                                  _stream()), "haet_pc_ln_residual")
+
+
+# --------------------------------------------------------------------------- Erwin body stages
+def gather_rows(x: Tensor, idx: Tensor, c: int) -> Tensor:
+    lib = _lib.load()
+    out = torch.empty((idx.numel(), c), dtype=torch.float32, device=x.device)
+    check(lib.haet_pc_gather_rows(_p(x), x.stride(0), _p(idx), idx.numel(), c, _p(out), c, _stream()), "haet_pc_gather_rows")
+    return out
+
+
+def scatter_masked(X: Tensor, tree_idx: Tensor, mask: Tensor, c: int, n_out: int) -> Tensor:
+    lib = _lib.load()
+    out = torch.empty((n_out, c), dtype=torch.float32, device=X.device)
+    check(lib.haet_pc_scatter_masked(_p(X), X.stride(0), _p(tree_idx), _p(mask), X.shape[0], c, _p(out), c, _stream()),
+          "haet_pc_scatter_masked")
+    return out
+
+
+def rows_add(X: Tensor, perm: Optional[Tensor], R: Tensor, c: int):
+    lib = _lib.load()
+    check(lib.haet_pc_rows_add(_p(X), X.stride(0), _p(perm), _p(R), R.stride(0), X.shape[0], c, _stream()), "haet_pc_rows_add")
+
+
+def ball_rel(P: Tensor, perm: Optional[Tensor], ball: int) -> Tensor:
+    lib = _lib.load()
+    rel = torch.empty_like(P)
+    check(lib.haet_pc_ball_rel(_p(P), _p(perm), P.shape[0], ball, P.shape[1], _p(rel), _stream()), "haet_pc_ball_rel")
+    return rel
+
+
+def rms_pe(X: Tensor, perm: Optional[Tensor], rel: Optional[Tensor], w: Tensor, pe_w: Optional[Tensor], pe_b: Optional[Tensor], c: int) -> Tensor:
+    lib = _lib.load()
+    Y = torch.empty((X.shape[0], c), dtype=torch.float32, device=X.device)
+    d = 0 if rel is None else rel.shape[1]
+    check(lib.haet_pc_rms_pe(_p(X), X.stride(0), _p(perm), _p(rel), X.shape[0], c, d, _p(w), _p(pe_w), _p(pe_b), _p(Y), c, _stream()),
+          "haet_pc_rms_pe")
+    return Y
+
+
+def ball_attention_supported(c: int, heads: int, ball: int) -> bool:
+    return bool(_lib.load().haet_pc_ball_attention_supported(int(c), int(heads), int(ball)))
+
+
+def ball_attention(qkv: Tensor, c: int, heads: int, ball: int) -> Tensor:
+    lib = _lib.load()
+    out = torch.empty((qkv.shape[0], c), dtype=torch.float32, device=qkv.device)
+    check(lib.haet_pc_ball_attention(_p(qkv), qkv.stride(0), qkv.shape[0], c, heads, ball, _p(out), c, _stream()),
+          "haet_pc_ball_attention")
+    return out
+
+
+def swiglu(U: Tensor, hid: int) -> Tensor:
+    lib = _lib.load()
+    H = torch.empty((U.shape[0], hid), dtype=torch.float32, device=U.device)
+    check(lib.haet_pc_swiglu(_p(U), U.stride(0), U.shape[0], hid, _p(H), hid, _stream()), "haet_pc_swiglu")
+    return H
+
+
+def pool_gather(X: Tensor, P: Tensor, c: int, st: int, ldy: int):
+    lib = _lib.load()
+    rows = X.shape[0] // st
+    Y = torch.empty((rows, ldy), dtype=torch.float32, device=X.device)
+    Pc = torch.empty((rows, P.shape[1]), dtype=torch.float32, device=X.device)
+    check(lib.haet_pc_pool_gather(_p(X), X.stride(0), _p(P), rows, c, P.shape[1], st, _p(Y), ldy, _p(Pc), _stream()), "haet_pc_pool_gather")
+    return Y, Pc
+
+
+def unpool_input(Xp: Tensor, Pp: Tensor, Pchild: Tensor, c: int, st: int, ldy: int) -> Tensor:
+    lib = _lib.load()
+    Y = torch.empty((Xp.shape[0], ldy), dtype=torch.float32, device=Xp.device)
+    check(lib.haet_pc_unpool_input(_p(Xp), Xp.stride(0), _p(Pp), _p(Pchild), Xp.shape[0], c, Pp.shape[1], st, _p(Y), ldy, _stream()),
+          "haet_pc_unpool_input")
+    return Y
+
+
+def unpool_merge(skip: Tensor, Yp: Tensor, c: int, st: int) -> Tensor:
+    lib = _lib.load()
+    out = torch.empty((skip.shape[0], c), dtype=torch.float32, device=skip.device)
+    check(lib.haet_pc_unpool_merge(_p(skip), skip.stride(0), _p(Yp), Yp.stride(0), skip.shape[0], c, st, _p(out), c, _stream()),
+          "haet_pc_unpool_merge")
+    return out
+
+
+def batch_norm_(X: Tensor, c: int, bn: torch.nn.BatchNorm1d, training: bool):
+    """nn.BatchNorm1d in place over the rows of X (batch statistics + running-statistics update when training)."""
+    lib = _lib.load()
+    rows = X.shape[0]
+    if training:
+        part = torch.empty((lib.haet_pc_bn_blocks(rows), 2, c), dtype=torch.float32, device=X.device)
+        stats = torch.empty((2, c), dtype=torch.float32, device=X.device)
+        mom = 0.1 if bn.momentum is None else float(bn.momentum)
+        track = bn.track_running_stats and bn.running_mean is not None
+        check(lib.haet_pc_bn_stats(_p(X), X.stride(0), rows, c, mom, _p(part), _p(stats),
+                                   _p(bn.running_mean if track else None), _p(bn.running_var if track else None),
+                                   _p(bn.num_batches_tracked if track else None), _stream()), "haet_pc_bn_stats")
+        mean, var = stats[0], stats[1]
+    else:
+        mean, var = bn.running_mean, bn.running_var
+    check(lib.haet_pc_bn_apply(_p(X), X.stride(0), rows, c, _p(mean), _p(var), float(bn.eps), _p(bn.weight.detach()), _p(bn.bias.detach()),
+                               _stream()), "haet_pc_bn_apply")
+
+
+class PaddedLinear:
+    """A Linear [O, K] for the split-bf16 GEMM (haet_linear_fwd: K % 32 = 0, O % 128 = 0): zero-padded to that envelope
+    once per weight version; inputs carry Kp columns (zeros past K), outputs Op columns (zeros past O)."""
+
+    def __init__(self, weight: Tensor, bias: Optional[Tensor]):
+        O, K = weight.shape
+        self.O, self.K, self.Op, self.Kp = O, K, round_up(O, 128), round_up(K, 32)
+        W = torch.zeros((self.Op, self.Kp), dtype=torch.float32, device=weight.device)
+        W[:O, :K] = weight.detach()
+        b = torch.zeros(self.Op, dtype=torch.float32, device=weight.device)
+        if bias is not None:
+            b[:O] = bias.detach()
+        self.w = SplitLinear(W, b)
+
+    def __call__(self, x: Tensor) -> Tensor:
+        if x.shape[-1] != self.Kp or not x.is_contiguous():
+            raise HaetError(f"PaddedLinear: input width {tuple(x.shape)} != padded K {self.Kp}")
+        return linear(x, self.w)
+
+    def compact(self, y: Tensor) -> Tensor:
+        return y if self.Op == self.O else y[:, :self.O].contiguous()

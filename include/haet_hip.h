@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HAET_ABI_VERSION 4  /* 2: + haet_tokens_tree_build, haet_project_split_fwd, haet_*_fwd_split; 4: train-mode
+#define HAET_ABI_VERSION 5  /* 2: + haet_tokens_tree_build, haet_project_split_fwd, haet_*_fwd_split; 4: train-mode
                              BatchNorm (haet_erwin_train), haet_token_stage_fwd */
 
 #define HAET_OK 0
@@ -402,6 +402,68 @@ int haet_conv_project_supported(int Cin, int O);
 int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
                           int B, int gH, int gW, int gD, int Cin, int O, int kH, int kW, int kD,
                           float* out, haet_stream_t stream);
+
+/* ------------------------------------------------------------------ stand-alone ErwinFlash on raw point clouds
+ * (ErwinTransformer.forward with embed=True / mp_steps>0 on 32k..1M-point clouds,
+ * models/components/erwinflash/erwin_flash.py:138-195, benchmarks/02.1-Car-Design-ShapeNetCar/main.py:50-99).
+ *
+ * haet_balltree_big_build replaces build_balltree_with_rotations (balltree.pyx:598-662) for clouds of any size
+ * (>= 2 points each, unequal sizes, padded trees): cloud_sizes is a HOST array; tree_idx / tree_mask have
+ * haet_balltree_big_slots() entries (cloud after cloud, 2^ceil(log2 n) slots each), rot holds the rotated
+ * re-partitions of the n_levels layers one after the other (slots, slots / stride0, ...), written only when
+ * angle_deg > 0.  Same permutation as the reference (libstdc++ introselect followed step for step, its Hoare
+ * partition data-parallel).  The call synchronises the stream (the reference synchronises through the host too). */
+size_t haet_balltree_big_slots(const int32_t* cloud_sizes, int n_clouds);
+size_t haet_balltree_big_workspace_bytes(const int32_t* cloud_sizes, int n_clouds, int d);
+int haet_balltree_big_build(const float* pos, const int32_t* cloud_sizes, int n_clouds, int d, int n_levels,
+                            const int32_t* strides, const int32_t* ball_sizes, float angle_deg, int32_t* tree_idx,
+                            uint8_t* tree_mask, int32_t* rot, void* workspace, size_t workspace_bytes,
+                            haet_stream_t stream);
+/* torch_cluster.radius_graph(pos, r, batch, loop=True, max_num_neighbors) (erwin_flash.py:160-166): cloud_lo / cloud_hi
+ * [N] = first / one-past-last point of each centre's cloud; nbr [N][max_nbrs], cnt [N]; then, with rowptr = exclusive
+ * prefix sum of cnt, edge_index [2][E] int64 = [[neighbour j ...], [centre i ...]] grouped by centre.          */
+int haet_pc_radius_neighbours(const float* pos, const int32_t* cloud_lo, const int32_t* cloud_hi, int N, int d, float r,
+                              int max_nbrs, int32_t* nbr, int32_t* cnt, haet_stream_t stream);
+int haet_pc_radius_fill(const int32_t* nbr, const int32_t* cnt, const int64_t* rowptr, int N, int max_nbrs, long long E,
+                        int64_t* edge_index, haet_stream_t stream);
+/* MPNN step (components/mpnn.py:48-68): AB [N][ldab] = [h Wa^T | h Wb^T] (Wa, Wb = the h_j and h_i column blocks of the
+ * message Linear), Wc [c][d] its position columns; out[i] = mean over the edges (src[e] -> i), e in
+ * [rowptr[i], rowptr[i+1]), of LayerNorm(GELU(A[src] + B[i] + Wc (pos[src] - pos[i]) + bias)); zero without edges. */
+int haet_pc_mpnn_message(const float* AB, int ldab, const float* pos, int d, const int32_t* rowptr, const int32_t* src,
+                         const float* Wc, const float* bias, long long rows, int c, float eps, float* out, int ldo,
+                         haet_stream_t stream);
+/* h += LayerNorm_noaffine(u) (mpnn.py:64-66); the new h is also written to h2 when given                       */
+int haet_pc_ln_residual(const float* u, int ldu, long long rows, int c, float eps, float* h, int ldh, float* h2, int ldh2,
+                        haet_stream_t stream);
+/* streaming stages of the Erwin body over the tree-ordered state X [slots][ld] (layers.py, attention.py, mlp.py,
+ * pooling.py); perm = rotated order of a block (NULL: tree order); widths are multiples of 4, <= 1024          */
+int haet_pc_gather_rows(const float* x, int ldx, const int32_t* idx, long long rows, int c, float* out, int ldo,
+                        haet_stream_t stream);
+int haet_pc_scatter_masked(const float* X, int ldx, const int32_t* tree_idx, const uint8_t* mask, long long rows, int c,
+                           float* out, int ldo, haet_stream_t stream);
+int haet_pc_rows_add(float* X, int ldx, const int32_t* perm, const float* R, int ldr, long long rows, int c,
+                     haet_stream_t stream);
+int haet_pc_ball_rel(const float* P, const int32_t* perm, long long rows, int ball, int d, float* rel, haet_stream_t stream);
+int haet_pc_rms_pe(const float* X, int ldx, const int32_t* perm, const float* rel, long long rows, int c, int d,
+                   const float* w, const float* pe_w /*[c][d] or NULL*/, const float* pe_b, float* Y, int ldy,
+                   haet_stream_t stream);
+int haet_pc_ball_attention_supported(int c, int heads, int ball);
+int haet_pc_ball_attention(const float* qkv, int ldq, long long rows, int c, int heads, int ball, float* out, int ldo,
+                           haet_stream_t stream);
+int haet_pc_swiglu(const float* U, int ldu, long long rows, int hid, float* H, int ldh, haet_stream_t stream);
+int haet_pc_pool_gather(const float* X, int ldx, const float* P, long long rows, int c, int d, int st, float* Y, int ldy,
+                        float* Pc, haet_stream_t stream);
+int haet_pc_unpool_input(const float* Xp, int ldx, const float* Pp, const float* Pchild, long long rows, int c, int d, int st,
+                         float* Y, int ldy, haet_stream_t stream);
+int haet_pc_unpool_merge(const float* skip, int lds_, const float* Yp, int ldy, long long rows, int c, int st, float* out,
+                         int ldo, haet_stream_t stream);
+/* nn.BatchNorm1d over rows (pooling.py:23,38,56,68): batch statistics (stats [2][c] = mean, biased variance; part
+ * [haet_pc_bn_blocks(rows)][2][c] scratch; running statistics / num_batches_tracked updated when given), then apply */
+int haet_pc_bn_blocks(long long rows);
+int haet_pc_bn_stats(const float* X, int ldx, long long rows, int c, float momentum, float* part, float* stats,
+                     float* run_mean, float* run_var, long long* nbt, haet_stream_t stream);
+int haet_pc_bn_apply(float* X, int ldx, long long rows, int c, const float* mean, const float* var, float eps,
+                     const float* gamma, const float* beta, haet_stream_t stream);
 
 #ifdef __cplusplus
 }
