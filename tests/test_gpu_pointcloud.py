@@ -44,13 +44,39 @@ def test_big_tree_matches_reference_fixture(name, hip_device):
             assert r is None
 
 
+def _oracle_rots_on_device_keys(pos, bidx, tree_idx, strides, balls, angle):
+    """The oracle's rotated re-partitions on rotated leaves computed the way the device computes them: fp32
+    x0 r0j, then fused multiply-adds for the further coordinates (csrc/balltree_big.hip big_rotate_kernel).  The
+    reference takes torch.matmul's result, whose rounding depends on the BLAS behind it (on this image's CPU it equals
+    the FMA chain for small inputs -- the reference fixtures -- and differs in ~1/4 of the entries at 10^5 rows)."""
+    import math
+
+    from oracle import balltree as obt
+
+    d = pos.shape[1]
+    L64, R64 = pos[tree_idx].double(), O.rotation_matrix(angle, d).double()
+    keys = (L64[:, 0:1] * R64[0:1, :]).float()
+    for k in range(1, d):
+        keys = (L64[:, k:k + 1] * R64[k:k + 1, :] + keys.double()).float()
+    cb, rots = bidx[tree_idx], []
+    for i, bs in enumerate(balls):
+        target = max(0, int(math.log2(tree_idx.numel() / bs)))
+        rots.append(torch.from_numpy(obt.partition_balltree(keys.double().numpy(), cb.numpy(), target)))
+        if i < len(strides):
+            keys = keys.view(-1, strides[i], d).mean(dim=1)
+            cb = cb[::strides[i]]
+    return rots
+
+
 @pytest.mark.parametrize("sizes,d,kind", [
     ([33000], 3, "rand"), ([5000, 70001, 1234], 3, "rand"), ([4, 7, 1025, 4097], 2, "rand"), ([40000], 3, "ties"),
-    ([9000, 9000], 2, "grid"), ([262144], 3, "rand"), ([300001], 3, "line"),
+    ([9000, 9000], 2, "grid"), ([262144], 3, "rand"), ([300001], 3, "line"), ([1048576], 3, "rand"),
 ])
 def test_big_tree_matches_oracle(sizes, d, kind, hip_device):
     """Clouds far beyond the sub-tree size (the data-parallel Hoare partition of csrc/balltree_big.hip), with exact
-    coordinate ties (every tie is resolved by the introselect's own moves, so the permutation must still be identical)."""
+    coordinate ties (every tie is resolved by the introselect's own moves, so the permutation must still be identical).
+    Main tree: bit-exact against the oracle.  Rotated re-partitions: bit-exact against the oracle run on the same
+    rotated keys; against the oracle's torch.matmul keys the BALLS (sets of 64+ slots) agree on tie-free clouds."""
     from haet_amd import pc_ops
 
     rng = np.random.default_rng(sum(sizes) + d)
@@ -71,8 +97,12 @@ def test_big_tree_matches_oracle(sizes, d, kind, hip_device):
     ti, tm, rots = pc_ops.balltree_big(pos.to(hip_device), sizes, strides, balls, 45.0)
     assert torch.equal(ti.cpu().long(), eti)
     assert torch.equal(tm.cpu().bool(), etm)
+    want = _oracle_rots_on_device_keys(pos, bidx, eti, strides, balls, 45.0)
     for i, r in enumerate(rots):
-        assert torch.equal(r.cpu().long(), erots[i]), f"rotated partition {i}"
+        assert torch.equal(r.cpu().long(), want[i]), f"rotated partition {i}"
+        if kind == "rand" and len(sizes) == 1:  # (one cloud: the partition depth is the ball size's, see rot_targets)
+            g = balls[i]
+            assert torch.equal(torch.sort(r.cpu().long().view(-1, g), dim=1)[0], torch.sort(erots[i].view(-1, g), dim=1)[0])
 
 
 def test_radius_graph_matches_oracle(hip_device):
@@ -118,7 +148,9 @@ def test_standalone_forward_vs_reference(name, hip_device):
     with torch.no_grad():
         out = m(f["feat"].to(hip_device), f["pos"].to(hip_device), f["batch_idx"].to(hip_device), **args)
     assert out.shape == f["exp"]["out"].shape
-    assert O.rel_l2(out.cpu(), f["exp"]["out"]) < FP32_TOL
+    # (train-mode BatchNorm divides by batch deviations: the same fp32 perturbation shows ~5x larger, also in the
+    # oracle -- 2.9e-6 against 5.6e-7 on the eval fixtures)
+    assert O.rel_l2(out.cpu(), f["exp"]["out"]) < (1e-4 if meta["train"] else FP32_TOL)
     if meta["train"]:  # BatchNorm running statistics moved like the reference's
         sd = m.state_dict()
         for k, v in f["sd_after"].items():
@@ -138,6 +170,9 @@ def test_autograd_restatement_matches_hip_forward_and_oracle_gradients(name, hip
     feat = f["feat"].to(hip_device).requires_grad_(True)
     out = m(feat, f["pos"].to(hip_device), f["batch_idx"].to(hip_device), radius=meta["radius"])
     assert O.rel_l2(out.detach().cpu(), f["exp"]["out"]) < FP32_TOL
+    with torch.no_grad():  # (the HIP stages on the same inputs; a fresh module: train mode moves the BatchNorm statistics)
+        assert O.rel_l2(_module(f, hip_device)(feat.detach(), f["pos"].to(hip_device), f["batch_idx"].to(hip_device), radius=meta["radius"]).cpu(),
+                        out.detach().cpu()) < (1e-4 if meta["train"] else FP32_TOL)
     gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(3))
     (out * gout.to(hip_device)).sum().backward()
     sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in f["sd"].items()}
