@@ -134,6 +134,8 @@ SIGNATURES = {
     "haet_balltree_big_workspace_bytes": (c_size_t, [_P, c_int, c_int]),
     "haet_balltree_big_build": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, c_size_t, _P]),
     "haet_pc_radius_neighbours": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_int, _P, _P, _P]),
+    "haet_pc_radius_cell_keys": (c_int, [_P, _P, c_int, c_int, _P, c_float, _P, _P, _P]),
+    "haet_pc_radius_neighbours_grid": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, c_float, _P, c_float, c_int, _P, _P, _P]),
     "haet_pc_radius_fill": (c_int, [_P, _P, _P, c_int, c_int, c_longlong, _P, _P]),
     "haet_pc_mpnn_message": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_longlong, c_int, c_float, _P, c_int, _P]),
     "haet_pc_ln_residual": (c_int, [_P, c_int, c_longlong, c_int, c_float, _P, c_int, _P, c_int, _P]),

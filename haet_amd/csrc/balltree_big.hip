@@ -189,12 +189,108 @@ __global__ __launch_bounds__(kTopThreads) void big_top_kernel(
 }
 
 // ----------------------------------------------------------------------------------------------- sub-trees
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// std::nth_element(W, W + nth, W + n) by ONE WAVE on LDS arrays: the rounds of big_top_kernel with ballots instead of
+// workgroup scans.  ls / rsl: scratch of n ints each.
+__device__ void wave_select(int* W, int nth, int n, const float* kd, int* ls, int* rsl, int lane) {
+    int first = 0, last = n;
+    int depth = 2 * (31 - __clz(n));
+    while (last - first > 3) {
+        if (depth == 0) {
+            if (lane == 0) {
+                heap_select_(W + first, W + nth + 1, W + last, kd);
+                swp(W + first, W + nth);
+            }
+            wave_sync();
+            return;
+        }
+        --depth;
+        if (lane == 0) {
+            int *a = W + first + 1, *b = W + first + (last - first) / 2, *c = W + last - 1, *f = W + first;
+            if (lt(kd, *a, *b)) {
+                if (lt(kd, *b, *c)) swp(f, b);
+                else if (lt(kd, *a, *c)) swp(f, c);
+                else swp(f, a);
+            } else if (lt(kd, *a, *c)) swp(f, a);
+            else if (lt(kd, *b, *c)) swp(f, c);
+            else swp(f, b);
+        }
+        wave_sync();
+        const float v = kd[W[first]];
+        int nL = 0, nR = 0;  // stoppers inside [first + 1, last), ranked from the left
+        for (int p0 = first + 1; p0 < last; p0 += 64) {
+            const int p = p0 + lane;
+            const float x = p < last ? kd[W[p]] : 0.f;
+            const bool isl = p < last && !(x < v), isr = p < last && !(v < x);
+            const unsigned long long ml = __ballot(isl), mr = __ballot(isr), below = (1ull << lane) - 1ull;
+            if (isl) ls[nL + __popcll(ml & below)] = p;
+            if (isr) rsl[nR + __popcll(mr & below)] = p;
+            nL += __popcll(ml);
+            nR += __popcll(mr);
+        }
+        wave_sync();
+        // k-th right stopper from the right; the pivot's slot is the last one
+        auto Rk = [&](int k) { return k < nR ? rsl[nR - 1 - k] : first; };
+        const int kmax = min(nL, nR + 1);
+        int K = 0;
+        for (int k0 = 0; k0 < kmax; k0 += 64) {
+            const int k = k0 + lane;
+            K += __popcll(__ballot(k < kmax && ls[k] < Rk(k)));
+        }
+        const int bound = K > 0 ? Rk(K - 1) : last;
+        int cut = bound;
+        if (K < nL) {
+            const int Lk = ls[K];
+            cut = Lk < bound ? Lk : bound;
+        }
+        for (int k = lane; k < K; k += 64) {
+            const int a = ls[k], b = Rk(k);
+            const int t = W[a];
+            W[a] = W[b];
+            W[b] = t;
+        }
+        wave_sync();
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    if (lane == 0) insertion_sort_(W + first, W + last, kd);
+    wave_sync();
+}
+
+// balltree.h:32-66 by one wave
+__device__ int wave_split_dim(const float* keys, int kstride, int nd, const int* idx, int s, int e, int lane) {
+    int best = 0;
+    double best_spread = 0.0;
+    for (int k = 0; k < nd; ++k) {
+        const float* kd = keys + k * kstride;
+        float lo = INFINITY, hi = -INFINITY;
+        for (int i = s + lane; i < e; i += 64) {
+            const float v = kd[idx[i]];
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+        const double spread = (double)hi - (double)lo;
+        if (spread > best_spread) best_spread = spread, best = k;
+    }
+    return best;
+}
+
+constexpr int kCoop = 96;  // nodes larger than this are selected by the whole wave, smaller ones by one lane each
 __global__ __launch_bounds__(64) void big_sub_kernel(const float* __restrict__ keys, int d,
                                                      const BigCloud* __restrict__ tab,
                                                      const int2* __restrict__ work, int* __restrict__ idx) {
     __shared__ float lkey[3 * kSubT];
     __shared__ int lidx[kSubT];
     __shared__ int lgid[kSubT];
+    __shared__ int ls[kSubT];
+    __shared__ int rsl[kSubT];
     const int lane = threadIdx.x;
     const int2 wk = work[blockIdx.x];
     const BigCloud C = tab[wk.x];
@@ -209,19 +305,27 @@ __global__ __launch_bounds__(64) void big_sub_kernel(const float* __restrict__ k
         lidx[i] = i;
         for (int k = 0; k < d; ++k) lkey[k * kSubT + i] = keys[((size_t)C.off + g) * d + k];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     for (int L = 0; L < r; ++L) {
+        if (((m + (1 << L) - 1) >> L) > kCoop) {  // (an upper bound of every node size of this level)
+            for (int node = 0; node < (1 << L); ++node) {
+                int ns, ne;
+                node_range(m, L, node, ns, ne);
+                if (ne - ns > kCoop) {
+                    const int dim = wave_split_dim(lkey, kSubT, d, lidx, ns, ne, lane);
+                    wave_select(lidx + ns, (ns + ne) / 2 - ns, ne - ns, lkey + dim * kSubT, ls, rsl, lane);
+                }
+            }
+        }
         for (int node = lane; node < (1 << L); node += 64) {
             int ns, ne;
             node_range(m, L, node, ns, ne);
-            if (ne - ns > 1) {
+            if (ne - ns > 1 && ne - ns <= kCoop) {
                 const int dim = split_dim(lkey, kSubT, d, lidx, ns, ne);
                 select_nth(lidx + ns, lidx + (ns + ne) / 2, lidx + ne, lkey + dim * kSubT);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        wave_sync();
     }
     for (int i = lane; i < m; i += 64) idx[base + i] = lgid[lidx[i]];
 }

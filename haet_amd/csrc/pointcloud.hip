@@ -491,6 +491,72 @@ __global__ __launch_bounds__(256) void radius_fill_kernel(const int32_t* __restr
     }
 }
 
+// The same edge list through a uniform grid (cells of edge >= r, keyed by (cloud, cell); points sorted by key, so a cell
+// lists its points in index order): a centre only looks at the 3^d cells around its own and keeps the max_nbrs SMALLEST
+// neighbour indices -- which is what "the first max_nbrs in index order" selects.  O(N * neighbours) instead of O(N^2).
+struct RadGrid {
+    float mn[3];
+    float inv_cell;
+    int G[3];
+};
+__device__ __forceinline__ int rad_cell(float x, float mn, float inv_cell, int G) {
+    const int c = (int)floorf((x - mn) * inv_cell);
+    return c < 0 ? 0 : (c >= G ? G - 1 : c);
+}
+__global__ __launch_bounds__(256) void radius_cellkey_kernel(const float* __restrict__ pos, const int32_t* __restrict__ cloud_of, int N,
+                                                            int d, RadGrid g, int64_t* __restrict__ key) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    long long k = cloud_of[i];
+    for (int a = d - 1; a >= 0; --a) k = k * g.G[a] + rad_cell(pos[(size_t)i * d + a], g.mn[a], g.inv_cell, g.G[a]);
+    key[i] = k;
+}
+constexpr int kRadList = 33;  // ints per thread in LDS (max_nbrs <= 32, + 1 against bank conflicts)
+__global__ __launch_bounds__(256) void radius_grid_kernel(const float* __restrict__ pos, const int32_t* __restrict__ cloud_of,
+                                                         const int64_t* __restrict__ sorted_idx, const int32_t* __restrict__ cell_ptr,
+                                                         int N, int d, RadGrid g, float r2, int max_nbrs,
+                                                         int32_t* __restrict__ nbr, int32_t* __restrict__ cnt) {
+    __shared__ int lst[256 * kRadList];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= N) return;
+    int* const mine = lst + threadIdx.x * kRadList;
+    const int i = (int)sorted_idx[t];
+    float xi[3] = {0.f, 0.f, 0.f};
+    int ci[3] = {0, 0, 0};
+    for (int k = 0; k < d; ++k) {
+        xi[k] = pos[(size_t)i * d + k];
+        ci[k] = rad_cell(xi[k], g.mn[k], g.inv_cell, g.G[k]);
+    }
+    const long long cloud_base = (long long)cloud_of[i] * g.G[0] * g.G[1] * (d == 3 ? g.G[2] : 1);
+    int count = 0;
+    const int z0 = d == 3 ? max(ci[2] - 1, 0) : 0, z1 = d == 3 ? min(ci[2] + 1, g.G[2] - 1) : 0;
+    for (int cz = z0; cz <= z1; ++cz)
+        for (int cy = max(ci[1] - 1, 0); cy <= min(ci[1] + 1, g.G[1] - 1); ++cy)
+            for (int cx = max(ci[0] - 1, 0); cx <= min(ci[0] + 1, g.G[0] - 1); ++cx) {
+                const long long cell = cloud_base + ((long long)cz * g.G[1] + cy) * g.G[0] + cx;
+                const int e0 = cell_ptr[cell], e1 = cell_ptr[cell + 1];
+                for (int e = e0; e < e1; ++e) {
+                    const int j = (int)sorted_idx[e];
+                    if (count == max_nbrs && j > mine[count - 1]) break;  // the cell lists ascending indices
+                    float d2 = 0.f;
+                    for (int k = 0; k < d; ++k) {
+                        const float df = __fsub_rn(pos[(size_t)j * d + k], xi[k]);
+                        d2 = __fadd_rn(d2, __fmul_rn(df, df));
+                    }
+                    if (!(d2 < r2)) continue;
+                    int q = count < max_nbrs ? count : max_nbrs - 1;  // insert j into the ascending list
+                    while (q > 0 && mine[q - 1] > j) {
+                        mine[q] = mine[q - 1];
+                        --q;
+                    }
+                    mine[q] = j;
+                    if (count < max_nbrs) ++count;
+                }
+            }
+    for (int q = 0; q < count; ++q) nbr[(size_t)i * max_nbrs + q] = mine[q];
+    cnt[i] = count;
+}
+
 }  // namespace haet
 
 using namespace haet;
@@ -656,4 +722,32 @@ extern "C" int haet_pc_radius_fill(const int32_t* nbr, const int32_t* cnt, const
     hipLaunchKernelGGL(radius_fill_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), nbr, cnt, rowptr, N, max_nbrs, E,
                        edge_index);
     return check_launch("radius_fill_kernel");
+}
+
+/* grid variant: key [N] int64 = (cloud, cell) of every point for the caller's stable sort; then the neighbour search on
+ * sorted_idx (point ids by key) and cell_ptr (first sorted position of every key, n_clouds * G0 G1 G2 + 1 entries).   */
+static RadGrid rad_grid(const float* mn, float cell, const int32_t* G) {
+    RadGrid g;
+    for (int k = 0; k < 3; ++k) g.mn[k] = mn[k], g.G[k] = G[k];
+    g.inv_cell = 1.0f / cell;
+    return g;
+}
+extern "C" int haet_pc_radius_cell_keys(const float* pos, const int32_t* cloud_of, int N, int d, const float* mn, float cell,
+                                        const int32_t* G, int64_t* key, haet_stream_t stream) {
+    if (!pos || !cloud_of || !mn || !G || !key || N < 1 || (d != 2 && d != 3) || !(cell > 0.f))
+        return fail(HAET_E_ARG, "pc_radius_cell_keys: bad arguments");
+    hipLaunchKernelGGL(radius_cellkey_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), pos, cloud_of, N, d,
+                       rad_grid(mn, cell, G), key);
+    return check_launch("radius_cellkey_kernel");
+}
+extern "C" int haet_pc_radius_neighbours_grid(const float* pos, const int32_t* cloud_of, const int64_t* sorted_idx,
+                                              const int32_t* cell_ptr, int N, int d, const float* mn, float cell, const int32_t* G,
+                                              float r, int max_nbrs, int32_t* nbr, int32_t* cnt, haet_stream_t stream) {
+    if (!pos || !cloud_of || !sorted_idx || !cell_ptr || !mn || !G || !nbr || !cnt || N < 1 || (d != 2 && d != 3))
+        return fail(HAET_E_ARG, "pc_radius_neighbours_grid: bad arguments");
+    if (max_nbrs < 1 || max_nbrs > kRadList - 1) return fail(HAET_E_ARG, "pc_radius_neighbours_grid: max_nbrs=%d (<= 32)", max_nbrs);
+    if (!(cell >= r)) return fail(HAET_E_ARG, "pc_radius_neighbours_grid: cell %g < r %g", cell, r);
+    hipLaunchKernelGGL(radius_grid_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), pos, cloud_of, sorted_idx, cell_ptr,
+                       N, d, rad_grid(mn, cell, G), r * r, max_nbrs, nbr, cnt);
+    return check_launch("radius_grid_kernel");
 }

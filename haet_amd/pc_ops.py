@@ -62,20 +62,44 @@ def balltree_big(pos: Tensor, cloud_sizes: Sequence[int], strides: Sequence[int]
 
 
 # --------------------------------------------------------------------------- radius graph / MPNN
-def radius_graph(pos: Tensor, r: float, batch_idx: Tensor, cloud_sizes: Sequence[int], max_num_neighbors: int = 32) -> Tensor:
-    """torch_cluster.radius_graph(pos, r, batch=batch_idx, loop=True) -> edge_index int64 [2, E] (erwin_flash.py:160-166)."""
+def radius_graph(pos: Tensor, r: float, batch_idx: Tensor, cloud_sizes: Sequence[int], max_num_neighbors: int = 32,
+                 grid: Optional[bool] = None) -> Tensor:
+    """torch_cluster.radius_graph(pos, r, batch=batch_idx, loop=True) -> edge_index int64 [2, E] (erwin_flash.py:160-166).
+    grid=None: the uniform-grid search wherever it applies (max_num_neighbors <= 32), else all pairs of a cloud."""
     lib = _lib.load()
     pos = _f32(pos, "pos")
     N, d = pos.shape
     dev = pos.device
-    offs = torch.zeros(len(cloud_sizes) + 1, dtype=torch.int32, device=dev)
-    offs[1:] = torch.tensor(list(cloud_sizes), dtype=torch.int32, device=dev).cumsum(0)
-    b = batch_idx.to(torch.long)
-    lo, hi = offs[b].contiguous(), offs[b + 1].contiguous()
+    nc = len(cloud_sizes)
     nbr = torch.empty((N, max_num_neighbors), dtype=torch.int32, device=dev)
     cnt = torch.empty(N, dtype=torch.int32, device=dev)
-    check(lib.haet_pc_radius_neighbours(_p(pos), _p(lo), _p(hi), N, d, float(r), max_num_neighbors, _p(nbr), _p(cnt), _stream()),
-          "haet_pc_radius_neighbours")
+    if grid is None:
+        grid = max_num_neighbors <= 32
+    if grid:
+        lo_hi = torch.stack([pos.min(dim=0)[0], pos.max(dim=0)[0]]).tolist()  # one host read (it sizes the cell table)
+        cell = float(r) * (1.0 + 1.0 / 256.0)  # a little wider than r: the cell of a point is computed in fp32
+        while True:
+            G = [min(2048, int((lo_hi[1][k] - lo_hi[0][k]) / cell) + 1) if k < d else 1 for k in range(3)]
+            if nc * G[0] * G[1] * G[2] <= (1 << 24) and all(G[k] < 2048 or (lo_hi[1][k] - lo_hi[0][k]) / cell < 2047 for k in range(d)):
+                break
+            cell *= 1.5
+        mn = (ctypes.c_float * 3)(*[lo_hi[0][k] if k < d else 0.0 for k in range(3)])
+        Gc = (ctypes.c_int32 * 3)(*G)
+        cloud_of = batch_idx.to(torch.int32).contiguous()
+        key = torch.empty(N, dtype=torch.int64, device=dev)
+        check(lib.haet_pc_radius_cell_keys(_p(pos), _p(cloud_of), N, d, mn, cell, Gc, _p(key), _stream()), "haet_pc_radius_cell_keys")
+        skey, order = torch.sort(key, stable=True)
+        ncell = nc * G[0] * G[1] * G[2]
+        cell_ptr = torch.searchsorted(skey, torch.arange(ncell + 1, device=dev, dtype=torch.int64)).to(torch.int32)
+        check(lib.haet_pc_radius_neighbours_grid(_p(pos), _p(cloud_of), _p(order), _p(cell_ptr), N, d, mn, cell, Gc, float(r),
+                                                 max_num_neighbors, _p(nbr), _p(cnt), _stream()), "haet_pc_radius_neighbours_grid")
+    else:
+        offs = torch.zeros(nc + 1, dtype=torch.int32, device=dev)
+        offs[1:] = torch.tensor(list(cloud_sizes), dtype=torch.int32, device=dev).cumsum(0)
+        b = batch_idx.to(torch.long)
+        lo, hi = offs[b].contiguous(), offs[b + 1].contiguous()
+        check(lib.haet_pc_radius_neighbours(_p(pos), _p(lo), _p(hi), N, d, float(r), max_num_neighbors, _p(nbr), _p(cnt), _stream()),
+              "haet_pc_radius_neighbours")
     rowptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
     rowptr[1:] = cnt.to(torch.int64).cumsum(0)
     E = int(rowptr[-1].item())  # the edge list's size is data dependent: one host read, like the reference's own sync

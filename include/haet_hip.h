@@ -424,6 +424,14 @@ int haet_balltree_big_build(const float* pos, const int32_t* cloud_sizes, int n_
  * prefix sum of cnt, edge_index [2][E] int64 = [[neighbour j ...], [centre i ...]] grouped by centre.          */
 int haet_pc_radius_neighbours(const float* pos, const int32_t* cloud_lo, const int32_t* cloud_hi, int N, int d, float r,
                               int max_nbrs, int32_t* nbr, int32_t* cnt, haet_stream_t stream);
+/* the same neighbour lists through a uniform grid (cells of edge `cell` >= r, G[k] cells along axis k from mn[k]):
+ * haet_pc_radius_cell_keys writes key[i] = (cloud, cell) of point i; the caller sorts the points by key (stable) into
+ * sorted_idx [N] and builds cell_ptr [n_clouds * G0 G1 G2 + 1] (first sorted position of every key); max_nbrs <= 32. */
+int haet_pc_radius_cell_keys(const float* pos, const int32_t* cloud_of, int N, int d, const float* mn /*[3], host*/, float cell,
+                             const int32_t* G /*[3], host*/, int64_t* key, haet_stream_t stream);
+int haet_pc_radius_neighbours_grid(const float* pos, const int32_t* cloud_of, const int64_t* sorted_idx, const int32_t* cell_ptr,
+                                   int N, int d, const float* mn, float cell, const int32_t* G, float r, int max_nbrs,
+                                   int32_t* nbr, int32_t* cnt, haet_stream_t stream);
 int haet_pc_radius_fill(const int32_t* nbr, const int32_t* cnt, const int64_t* rowptr, int N, int max_nbrs, long long E,
                         int64_t* edge_index, haet_stream_t stream);
 /* MPNN step (components/mpnn.py:48-68): AB [N][ldab] = [h Wa^T | h Wb^T] (Wa, Wb = the h_j and h_i column blocks of the

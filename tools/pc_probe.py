@@ -1,7 +1,7 @@
 """Stand-alone ErwinFlash (ShapeNetCar configuration, benchmarks/02.1-Car-Design-ShapeNetCar/main.py:57-71) on one
 synthetic cloud: ms per stage and per forward on the GPU, and the CPU oracle's forward beside it."""
-import argparse, json, sys, time
-sys.path.insert(0, ".")
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from haet_amd import pc_ops
 from haet_amd.components.erwinflash import ErwinTransformer, pointcloud
