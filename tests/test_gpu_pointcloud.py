@@ -214,3 +214,28 @@ def test_car_design_shape_properties(hip_device):
         ref = pointcloud.forward_autograd(m, feat, pos, bidx, None, 0.04)
     assert out.shape == (N, 128) and bool(torch.isfinite(out).all())
     assert O.rel_l2(out.cpu(), ref.cpu()) < FP32_TOL
+
+
+def test_encoder_only_and_argument_errors(hip_device):
+    """decode=False returns the bottleneck tokens and their (strided) batch index (erwin_flash.py:195); a caller-made
+    tree and a missing radius are refused like in the reference."""
+    from haet_amd.components.erwinflash import ErwinTransformer
+
+    f = G.load_ef("two_clouds")
+    kw = dict(f["meta"]["kw"], decode=False)
+    m = ErwinTransformer(**kw)
+    m.load_state_dict({k: v for k, v in f["sd"].items() if not k.startswith("decoder.")}, strict=True)
+    m = m.to(hip_device).eval()
+    feat, pos, bidx = f["feat"].to(hip_device), f["pos"].to(hip_device), f["batch_idx"].to(hip_device)
+    with torch.no_grad():
+        x, b = m(feat, pos, bidx, radius=f["meta"]["radius"])
+    cfg = G.ef_cfg(dict(kw=kw))
+    with torch.no_grad():
+        want = O.erwinflash_forward(f["feat"], f["pos"], f["batch_idx"], f["sd"], cfg, kw["mp_steps"], radius=f["meta"]["radius"])
+    assert O.rel_l2(x.cpu(), want) < FP32_TOL
+    tree_idx = f["exp"]["tree_idx"]
+    assert torch.equal(b.cpu(), f["batch_idx"][tree_idx][::kw["strides"][0]])
+    with pytest.raises(AssertionError):
+        m(feat, pos, bidx)  # mp_steps > 0 and neither edge_index nor radius
+    with pytest.raises(NotImplementedError):
+        m(feat, pos, bidx, tree_idx=tree_idx.to(hip_device), tree_mask=f["exp"]["tree_mask"].to(hip_device), radius=0.2)

@@ -46,6 +46,12 @@ if a.cpu:
     cfg = O.ErwinCfg(**{k: kw[k] for k in ("c_in", "c_hidden", "ball_sizes", "enc_num_heads", "enc_depths", "dec_num_heads", "dec_depths",
                                               "strides", "rotate", "decode", "mlp_ratio", "dimensionality")})
     t = time.perf_counter()
+    O.build_balltree_with_rotations(pos_c, bidx.cpu(), kw["strides"], kw["ball_sizes"], 45.0)
+    res["cpu_oracle_tree_ms"] = (time.perf_counter() - t) * 1e3
+    t = time.perf_counter()
+    O.radius_graph(pos_c, a.radius, bidx.cpu())
+    res["cpu_oracle_radius_graph_ms"] = (time.perf_counter() - t) * 1e3
+    t = time.perf_counter()
     with torch.no_grad():
         ref = O.erwinflash_forward(feat_c, pos_c, bidx.cpu(), sd, cfg, 3, radius=a.radius)
     res["cpu_oracle_forward_s"] = time.perf_counter() - t
