@@ -12,13 +12,15 @@
 //   sequences are prefix counts of the ORIGINAL array, the number of swaps K is where the monotone predicate
 //   L_k < R_k flips, and the cut the loop returns is min(L_{K+1}, R_K).
 // Levels whose nodes are larger than kSubT items run one workgroup per node on global memory (a launch per level);
-// every node of at most kSubT items is finished -- all remaining levels -- by one wave in LDS with the per-lane
-// select of balltree_select_dev.h (nodes of a level are independent: one lane each).
+// every node of at most kSubT items is finished -- all remaining levels -- by one workgroup in LDS: nodes above 96 items
+// by a wave each (the same rounds with ballots), smaller ones by a lane each with the serial select of
+// balltree_select_dev.h (the nodes of a level are independent).
 // Keys are the fp32 coordinates (the reference's float64 conversion is exact and order preserving); spreads are
 // differenced in double like the reference.
 #include "common.h"
 #include "balltree_select_dev.h"
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -38,6 +40,11 @@ struct BigCloud {
 };
 
 // ----------------------------------------------------------------------------------------------- top levels
+// INLDS: the node's frame (working array, keys, stopper lists) lives in LDS -- nodes of at most kTopLds items; a round is
+// then a handful of LDS round trips instead of global-memory ones (a level launch: ~90 us -> ~15 us).
+constexpr int kTopLds = 8192;
+extern __shared__ __attribute__((aligned(16))) char top_lds[];
+template <bool INLDS>
 __global__ __launch_bounds__(kTopThreads) void big_top_kernel(
     const float* __restrict__ keys, int d, const BigCloud* __restrict__ tab, const int2* __restrict__ work, int level,
     int* __restrict__ idx, int* __restrict__ gid, float* __restrict__ knode, int* __restrict__ w,
@@ -53,21 +60,34 @@ __global__ __launch_bounds__(kTopThreads) void big_top_kernel(
     const int m = e - s;
     if (m <= 1) return;
     const size_t base = (size_t)C.off + s;
-    int* const W = w + base;
-    float* const KD = knode + base;
-    int* const ls = LS + base;
-    int* const rs = RS + base;
+    int* const W = INLDS ? reinterpret_cast<int*>(top_lds) : w + base;
+    float* const KD = INLDS ? reinterpret_cast<float*>(top_lds + 4 * kTopLds) : knode + base;
+    int* const ls = INLDS ? reinterpret_cast<int*>(top_lds + 8 * kTopLds) : LS + base;
+    int* const rs = INLDS ? reinterpret_cast<int*>(top_lds + 12 * kTopLds + 16) : RS + base;
 
-    // split dimension: largest max - min (first one on ties), balltree.h:32-66
+    // split dimension: largest max - min (first one on ties), balltree.h:32-66.  The gathers (entry -> point -> key) are
+    // issued kU positions at a time: one position per loop trip is two dependent memory round trips per trip, and the
+    // three sweeps of the node (this one, the frame below, the write-back) were most of a level's run time.
+    constexpr int kU = 8;
     float lo[3], hi[3];
     for (int k = 0; k < 3; ++k) lo[k] = INFINITY, hi[k] = -INFINITY;
-    for (int p = tid; p < m; p += kTopThreads) {
-        const int g = idx[base + p];
-        for (int k = 0; k < d; ++k) {
-            const float v = keys[((size_t)C.off + g) * d + k];
-            lo[k] = fminf(lo[k], v);
-            hi[k] = fmaxf(hi[k], v);
+    int g8[kU];        // INLDS (<= kU positions per thread): entries and keys stay in registers for the frame
+    float k8[kU][3];
+    for (int p0 = tid; p0 < m; p0 += kU * kTopThreads) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int p = p0 + u * kTopThreads;
+            g8[u] = idx[base + (p < m ? p : 0)];
         }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) k8[u][k] = k < d ? keys[((size_t)C.off + g8[u]) * d + k] : 0.f;
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+            if (p0 + u * kTopThreads < m)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) lo[k] = fminf(lo[k], k8[u][k]), hi[k] = fmaxf(hi[k], k8[u][k]);
     }
     for (int k = 0; k < d; ++k) {
         lo[k] = wave_min(lo[k]);
@@ -89,11 +109,36 @@ __global__ __launch_bounds__(kTopThreads) void big_top_kernel(
     __syncthreads();
     const int dim = sh_dim;
     // the node's own frame: keys by ENTRY position, working array of entry positions
-    for (int p = tid; p < m; p += kTopThreads) {
-        const int g = idx[base + p];
-        gid[base + p] = g;
-        KD[p] = keys[((size_t)C.off + g) * d + dim];
-        W[p] = p;
+    if (INLDS) {
+        static_assert(kTopLds <= kU * kTopThreads, "one sweep of kU positions per thread covers an LDS-tier node");
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int p = tid + u * kTopThreads;
+            if (p < m) {
+                gid[base + p] = g8[u];
+                KD[p] = dim == 0 ? k8[u][0] : (dim == 1 ? k8[u][1] : k8[u][2]);
+                W[p] = p;
+            }
+        }
+    } else {
+        for (int p0 = tid; p0 < m; p0 += kU * kTopThreads) {
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int p = p0 + u * kTopThreads;
+                g8[u] = idx[base + (p < m ? p : 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) k8[u][0] = keys[((size_t)C.off + g8[u]) * d + dim];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int p = p0 + u * kTopThreads;
+                if (p < m) {
+                    gid[base + p] = g8[u];
+                    KD[p] = k8[u][0];
+                    W[p] = p;
+                }
+            }
+        }
     }
     __syncthreads();
 
@@ -110,31 +155,53 @@ __global__ __launch_bounds__(kTopThreads) void big_top_kernel(
             break;
         }
         --depth;
-        if (tid == 0) {  // median of (first+1, mid, last-1) to the front
+        // median of (first+1, mid, last-1) to the front: every thread reads the three candidates and knows the pivot
+        // without waiting for lane 0's swap to come back through memory
+        float v;
+        int med_pos, med_val, front_old;
+        {
             int *a = W + first + 1, *b = W + first + (last - first) / 2, *c = W + last - 1, *f = W + first;
-            if (lt(KD, *a, *b)) {
-                if (lt(KD, *b, *c)) swp(f, b);
-                else if (lt(KD, *a, *c)) swp(f, c);
-                else swp(f, a);
-            } else if (lt(KD, *a, *c)) swp(f, a);
-            else if (lt(KD, *b, *c)) swp(f, c);
-            else swp(f, b);
+            const int ia = *a, ib = *b, ic = *c;
+            const float ka = KD[ia], kb = KD[ib], kc = KD[ic];
+            int* med;  // the position whose entry goes to the front (__move_median_to_first)
+            if (ka < kb) med = kb < kc ? b : (ka < kc ? c : a);
+            else med = ka < kc ? a : (kb < kc ? c : b);
+            v = med == a ? ka : (med == b ? kb : kc);
+            med_pos = (int)(med - W);
+            med_val = med == a ? ia : (med == b ? ib : ic);
+            front_old = *f;  // the entry that moves to `med_pos`: readers of that slot substitute it until the swap lands
         }
-        __syncthreads();
-        const float v = KD[W[first]];
         const int f1 = first + 1, len = last - f1;
         // every wave owns a contiguous chunk (multiple of 64 positions) of [f1, last)
         const int chunk = ((len + kTopWaves - 1) / kTopWaves + 63) & ~63;
         const int c0 = f1 + wave * chunk, c1 = min(c0 + chunk, last);
+        // pass 1: count the stoppers; their flags stay in registers (one bit per 64-position step, up to 64 steps =
+        // 4096 positions per wave = nodes of 64k items; larger nodes gather twice)
+        const bool cached = chunk <= 64 * 64;
+        unsigned long long fl = 0ull, fr = 0ull;
         int nl = 0, nr = 0;
-        for (int p0 = c0; p0 < c1; p0 += 64) {
-            const int p = p0 + lane;
-            const float x = p < c1 ? KD[W[p]] : 0.f;
-            nl += __popcll(__ballot(p < c1 && !(x < v)));
-            nr += __popcll(__ballot(p < c1 && !(v < x)));
+        {
+            int step = 0;
+            for (int p0 = c0; p0 < c1; p0 += 64, ++step) {
+                const int p = p0 + lane;
+                const float x = p < c1 ? KD[p == med_pos ? front_old : W[p]] : 0.f;
+                const bool isl = p < c1 && !(x < v), isr = p < c1 && !(v < x);
+                nl += __popcll(__ballot(isl));
+                nr += __popcll(__ballot(isr));
+                if (cached) {
+                    fl |= (unsigned long long)isl << step;
+                    fr |= (unsigned long long)isr << step;
+                }
+            }
         }
         if (lane == 0) sh_cl[wave] = nl, sh_cr[wave] = nr;
         __syncthreads();
+        // (every thread has read the candidates and its positions: the swap of the median may land now; it is ordered
+        // before the swaps of this round by the two barriers below)
+        if (tid == 0) {
+            W[med_pos] = front_old;
+            W[first] = med_val;
+        }
         int bl = 0, br = 0, nL = 0, nR = 0;
         for (int q = 0; q < kTopWaves; ++q) {
             if (q < wave) bl += sh_cl[q], br += sh_cr[q];
@@ -142,16 +209,26 @@ __global__ __launch_bounds__(kTopThreads) void big_top_kernel(
         }
         // stopper lists: ls[k] = k-th left stopper from the left, rs[k] = k-th right stopper from the right
         // (the pivot's slot `first` is the last right stopper)
-        for (int p0 = c0; p0 < c1; p0 += 64) {
-            const int p = p0 + lane;
-            const float x = p < c1 ? KD[W[p]] : 0.f;
-            const bool isl = p < c1 && !(x < v), isr = p < c1 && !(v < x);
-            const unsigned long long ml = __ballot(isl), mr = __ballot(isr);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (isl) ls[bl + __popcll(ml & below)] = p;
-            if (isr) rs[nR - 1 - (br + __popcll(mr & below))] = p;
-            bl += __popcll(ml);
-            br += __popcll(mr);
+        {
+            int step = 0;
+            for (int p0 = c0; p0 < c1; p0 += 64, ++step) {
+                const int p = p0 + lane;
+                bool isl, isr;
+                if (cached) {
+                    isl = (fl >> step) & 1ull;
+                    isr = (fr >> step) & 1ull;
+                } else {
+                    const float x = p < c1 ? KD[p == med_pos ? front_old : W[p]] : 0.f;
+                    isl = p < c1 && !(x < v);
+                    isr = p < c1 && !(v < x);
+                }
+                const unsigned long long ml = __ballot(isl), mr = __ballot(isr);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (isl) ls[bl + __popcll(ml & below)] = p;
+                if (isr) rs[nR - 1 - (br + __popcll(mr & below))] = p;
+                bl += __popcll(ml);
+                br += __popcll(mr);
+            }
         }
         if (tid == 0) rs[nR] = first;
         __syncthreads();
@@ -172,7 +249,6 @@ __global__ __launch_bounds__(kTopThreads) void big_top_kernel(
                 cut = Lk < bound ? Lk : bound;
             }
         }
-        __syncthreads();  // every lane has read ls / rs before the next round rewrites them
         for (int k = tid; k < K; k += kTopThreads) {
             const int a = ls[k], b = rs[k];
             const int t = W[a];
@@ -185,7 +261,20 @@ __global__ __launch_bounds__(kTopThreads) void big_top_kernel(
     }
     if (tid == 0 && last - first > 0) insertion_sort_(W + first, W + last, KD);
     __syncthreads();
-    for (int p = tid; p < m; p += kTopThreads) idx[base + p] = gid[base + W[p]];
+    for (int p0 = tid; p0 < m; p0 += kU * kTopThreads) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int p = p0 + u * kTopThreads;
+            g8[u] = W[p < m ? p : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) g8[u] = gid[base + g8[u]];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int p = p0 + u * kTopThreads;
+            if (p < m) idx[base + p] = g8[u];
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------------------- sub-trees
@@ -282,16 +371,17 @@ __device__ int wave_split_dim(const float* keys, int kstride, int nd, const int*
     return best;
 }
 
-constexpr int kCoop = 96;  // nodes larger than this are selected by the whole wave, smaller ones by one lane each
-__global__ __launch_bounds__(64) void big_sub_kernel(const float* __restrict__ keys, int d,
-                                                     const BigCloud* __restrict__ tab,
-                                                     const int2* __restrict__ work, int* __restrict__ idx) {
+constexpr int kCoop = 96;   // nodes larger than this are selected by a whole wave, smaller ones by one lane each
+constexpr int kSubWaves = 8;  // waves of a sub-tree workgroup: the nodes of a level are dealt to them
+__global__ __launch_bounds__(64 * kSubWaves) void big_sub_kernel(const float* __restrict__ keys, int d,
+                                                                 const BigCloud* __restrict__ tab,
+                                                                 const int2* __restrict__ work, int* __restrict__ idx) {
     __shared__ float lkey[3 * kSubT];
     __shared__ int lidx[kSubT];
     __shared__ int lgid[kSubT];
-    __shared__ int ls[kSubT];
+    __shared__ int ls[kSubT];   // scratch of wave_select: a node uses the slice of its own range
     __shared__ int rsl[kSubT];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int2 wk = work[blockIdx.x];
     const BigCloud C = tab[wk.x];
     int s, e;
@@ -299,25 +389,26 @@ __global__ __launch_bounds__(64) void big_sub_kernel(const float* __restrict__ k
     const int m = e - s, r = C.levels - C.top;
     if (m <= 1 || r <= 0) return;
     const size_t base = (size_t)C.off + s;
-    for (int i = lane; i < m; i += 64) {
+    for (int i = tid; i < m; i += 64 * kSubWaves) {
         const int g = idx[base + i];
         lgid[i] = g;
         lidx[i] = i;
         for (int k = 0; k < d; ++k) lkey[k * kSubT + i] = keys[((size_t)C.off + g) * d + k];
     }
-    wave_sync();
+    __syncthreads();
     for (int L = 0; L < r; ++L) {
         if (((m + (1 << L) - 1) >> L) > kCoop) {  // (an upper bound of every node size of this level)
-            for (int node = 0; node < (1 << L); ++node) {
+            for (int node = wave; node < (1 << L); node += kSubWaves) {
                 int ns, ne;
                 node_range(m, L, node, ns, ne);
                 if (ne - ns > kCoop) {
                     const int dim = wave_split_dim(lkey, kSubT, d, lidx, ns, ne, lane);
-                    wave_select(lidx + ns, (ns + ne) / 2 - ns, ne - ns, lkey + dim * kSubT, ls, rsl, lane);
+                    wave_select(lidx + ns, (ns + ne) / 2 - ns, ne - ns, lkey + dim * kSubT, ls + ns, rsl + ns, lane);
                 }
             }
+            __syncthreads();
         }
-        for (int node = lane; node < (1 << L); node += 64) {
+        for (int node = tid; node < (1 << L); node += 64 * kSubWaves) {
             int ns, ne;
             node_range(m, L, node, ns, ne);
             if (ne - ns > 1 && ne - ns <= kCoop) {
@@ -325,9 +416,9 @@ __global__ __launch_bounds__(64) void big_sub_kernel(const float* __restrict__ k
                 select_nth(lidx + ns, lidx + (ns + ne) / 2, lidx + ne, lkey + dim * kSubT);
             }
         }
-        wave_sync();
+        __syncthreads();
     }
-    for (int i = lane; i < m; i += 64) idx[base + i] = lgid[lidx[i]];
+    for (int i = tid; i < m; i += 64 * kSubWaves) idx[base + i] = lgid[lidx[i]];
 }
 
 __global__ void big_iota_kernel(const BigCloud* __restrict__ tab, int n_clouds, int total, int* __restrict__ idx) {
@@ -485,13 +576,29 @@ static int big_partition(const float* keys, int d, std::vector<BigCloud>& clouds
         return fail(HAET_E_LAUNCH, "balltree_big: work list upload failed");
     for (int L = 0; L < max_top; ++L) {
         const int nb = (int)(lvl_off[L + 1] - lvl_off[L]);
-        if (nb > 0)
-            hipLaunchKernelGGL(big_top_kernel, dim3(nb), dim3(kTopThreads), 0, st, keys, d, ws.tab, ws.work + lvl_off[L], L,
+        if (nb <= 0) continue;
+        int biggest = 0;  // ceil(n / 2^L) bounds every node of a cloud's level L
+        for (const BigCloud& C : clouds)
+            if (C.top > L) biggest = std::max(biggest, (C.n + (1 << L) - 1) >> L);
+        if (biggest <= kTopLds) {
+            constexpr int lds = 16 * kTopLds + 32;
+            static PerDeviceOnce attr;
+            if (!attr.done()) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(big_top_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        lds) != hipSuccess)
+                    return fail(HAET_E_LAUNCH, "balltree_big: hipFuncSetAttribute failed");
+                attr.set();
+            }
+            hipLaunchKernelGGL(big_top_kernel<true>, dim3(nb), dim3(kTopThreads), lds, st, keys, d, ws.tab, ws.work + lvl_off[L], L,
                                ws.idx, ws.gid, ws.knode, ws.w, ws.LS, ws.RS);
+        } else {
+            hipLaunchKernelGGL(big_top_kernel<false>, dim3(nb), dim3(kTopThreads), 0, st, keys, d, ws.tab, ws.work + lvl_off[L], L,
+                               ws.idx, ws.gid, ws.knode, ws.w, ws.LS, ws.RS);
+        }
     }
     const int nsub = (int)(lvl_off[max_top + 1] - lvl_off[max_top]);
     if (nsub > 0)
-        hipLaunchKernelGGL(big_sub_kernel, dim3(nsub), dim3(64), 0, st, keys, d, ws.tab, ws.work + lvl_off[max_top], ws.idx);
+        hipLaunchKernelGGL(big_sub_kernel, dim3(nsub), dim3(64 * kSubWaves), 0, st, keys, d, ws.tab, ws.work + lvl_off[max_top], ws.idx);
     // the uploads above read host vectors that die with this frame
     if (hipStreamSynchronize(st) != hipSuccess) return fail(HAET_E_LAUNCH, "balltree_big: %s", hipGetErrorString(hipGetLastError()));
     return check_launch("balltree_big partition");
