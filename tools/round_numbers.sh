@@ -13,3 +13,6 @@ python tools/shape_probe.py > $O/c2.txt 2>&1
 python tools/c5_probe.py > $O/c5.txt 2>&1
 python tools/bench_lines.py $O/bench_1m.json $O/bench_125k.json $O/bench_1m_unfused.json
 tail -2 $O/train_probe.txt; tail -1 $O/model_probe.txt; tail -1 $O/model_train.txt; tail -2 $O/c1.txt; tail -3 $O/c2.txt; tail -1 $O/c5.txt; cat $O/sweep.txt
+python tools/pc_probe.py --cpu > $O/pointcloud_32k.json 2> $O/pointcloud.err
+python tools/pc_probe.py --points 1000000 --radius 0.012 --steps 3 > $O/pointcloud_1m.json 2>> $O/pointcloud.err
+cat $O/pointcloud_32k.json $O/pointcloud_1m.json
