@@ -7,12 +7,15 @@ BallPooling / BallUnpooling in between, scatter back to the input order.  Here e
 launch on the current stream (haet_amd/pc_ops.py -> csrc/balltree_big.hip, csrc/pointcloud.hip, and the split-bf16
 GEMMs of csrc/gemm_x3.hip for the Linears); the state stays in HBM as [tree slots][channels] fp32.
 
-Gradients: with autograd recording, the same stages run as differentiable torch device ops on the HIP-built tree and
-radius graph (`_forward_autograd`); the hand-written backward exists only for the slice-token configuration
-(csrc/erwin_bwd.hip).
+Gradients (`forward_autograd`): the transformer blocks -- nearly all of the arithmetic -- run forward AND backward on the HIP
+stages (`ErwinBlockFunction`: input kept, block recomputed in the backward, input gradients through the split-bf16 GEMM
+on the transposed weights, RMSNorm / SwiGLU / ball attention through their backward kernels, weight gradients as fp32
+library GEMMs); embedding / MPNN, pooling, BatchNorm and the gathers differentiate through torch device ops on the
+HIP-built tree and radius graph.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -48,10 +51,13 @@ class _Weights:
         for L in layers:
             for blk in L.blocks:
                 a, s = blk.BMSA, blk.swiglu
+                w12 = torch.cat([s.w1.weight, s.w2.weight], 0)
                 self.blocks[id(blk)] = dict(
                     qkv=P(a.qkv.weight, a.qkv.bias), proj=P(a.proj.weight, a.proj.bias),
-                    w12=P(torch.cat([s.w1.weight, s.w2.weight], 0), torch.cat([s.w1.bias, s.w2.bias], 0)),
-                    w3=P(s.w3.weight, s.w3.bias),
+                    w12=P(w12, torch.cat([s.w1.bias, s.w2.bias], 0)), w3=P(s.w3.weight, s.w3.bias),
+                    # the same matrices transposed: input gradients of the Linears (training)
+                    qkvT=P(a.qkv.weight.t(), None), projT=P(a.proj.weight.t(), None), w12T=P(w12.t(), None),
+                    w3T=P(s.w3.weight.t(), None),
                     norm1=blk.norm1.weight.detach().float().contiguous(), norm2=blk.norm2.weight.detach().float().contiguous(),
                     pe_w=a.pe_proj.weight.detach().float().contiguous(), pe_b=a.pe_proj.bias.detach().float().contiguous())
             for name in ("pool", "unpool"):
@@ -176,6 +182,80 @@ def forward_hip(erwin, feat: Tensor, pos: Tensor, batch_idx: Tensor, edge_index:
     return pc_ops.scatter_masked(X, tree_idx, tree_mask, X.shape[1], feat.shape[0])
 
 
+# --------------------------------------------------------------------------- training: blocks on the HIP kernels
+class ErwinBlockFunction(torch.autograd.Function):
+    """One ErwinTransformerBlock (layers.py:30-32) over the tree-ordered state, forward AND backward on the HIP stages:
+    the forward keeps only its input, the backward recomputes the block (11 launches) and walks it back -- input
+    gradients of the four Linears through the split-bf16 GEMM on the transposed weights, RMSNorm / SwiGLU / ball
+    attention through their backward kernels (csrc/pointcloud.hip); weight gradients are fp32 library GEMMs over the
+    rows.  `perm` = the block's rotated order (int32) or None."""
+
+    @staticmethod
+    def forward(ctx, X, P, perm, blk, w, *params):
+        X = ops._f32(X, "x")
+        out = X.clone()
+        _block(out, P, perm, blk, w, P.shape[1])
+        ctx.save_for_backward(X, P, perm if perm is not None else torch.empty(0, dtype=torch.int32, device=X.device))
+        ctx.blk, ctx.w = blk, w
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X1, P, perm = ctx.saved_tensors
+        perm = perm if perm.numel() else None
+        blk, w = ctx.blk, ctx.w
+        c, ball, heads, hid = X1.shape[1], blk.ball_size, blk.BMSA.num_heads, w["w3"].K
+        g = ops._f32(g, "grad")
+        # the block again (nothing but its input was kept)
+        rel = pc_ops.ball_rel(P, perm, ball)
+        Y1 = pc_ops.rms_pe(X1, perm, rel, w["norm1"], w["pe_w"], w["pe_b"], c)
+        QKV = w["qkv"](Y1)
+        A = pc_ops.ball_attention(QKV, c, heads, ball)
+        X2 = X1.clone()
+        pc_ops.rows_add(X2, perm, w["proj"](A), c)
+        Y2 = pc_ops.rms_pe(X2, None, None, w["norm2"], None, None, c)
+        U = w["w12"](Y2)
+        H = pc_ops.swiglu(U, hid)
+        # x_out = x2 + w3(H)
+        dH = w["w3T"](g)
+        dU = pc_ops.swiglu_bwd(U, dH, hid)
+        dY2 = w["w12T"](dU)
+        dX = g.clone()
+        pc_ops.rms_bwd_(X2, None, dY2, w["norm2"], c, dX)
+        xh2 = X2 * torch.rsqrt(X2.pow(2).mean(-1, keepdim=True) + torch.finfo(torch.float32).eps)
+        g_norm2 = (dY2[:, :c] * xh2).sum(0)
+        g_w12, g_b12 = dU.t() @ Y2, dU.sum(0)
+        g_w3, g_b3 = g.t() @ H, g.sum(0)
+        del U, H, dH, Y2, xh2
+        # x2 = x1 + scatter(proj(attention(qkv(y1))))
+        dR = pc_ops.gather_rows(dX, perm, c) if perm is not None else dX
+        dA = w["projT"](dR)
+        g_wp, g_bp = dR.t() @ A, dR.sum(0)
+        dQKV = pc_ops.ball_attention_bwd(QKV, dA, c, heads, ball)
+        dY1 = w["qkvT"](dQKV)
+        g_wq, g_bq = dQKV.t() @ Y1, dQKV.sum(0)
+        pc_ops.rms_bwd_(X1, perm, dY1, w["norm1"], c, dX)
+        Xs = X1.index_select(0, perm.long()) if perm is not None else X1
+        xh1 = Xs * torch.rsqrt(Xs.pow(2).mean(-1, keepdim=True) + torch.finfo(torch.float32).eps)
+        d1 = dY1[:, :c]
+        g_norm1, g_pew, g_peb = (d1 * xh1).sum(0), d1.t() @ rel, d1.sum(0)
+        return (dX, None, None, None, None, g_norm1, g_pew, g_peb, g_wq, g_bq, g_wp, g_bp, g_norm2,
+                g_w12[:hid], g_b12[:hid], g_w12[hid:2 * hid], g_b12[hid:2 * hid], g_w3, g_b3)
+
+
+def _block_params(blk):
+    a, s = blk.BMSA, blk.swiglu
+    return (blk.norm1.weight, a.pe_proj.weight, a.pe_proj.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+            blk.norm2.weight, s.w1.weight, s.w1.bias, s.w2.weight, s.w2.bias, s.w3.weight, s.w3.bias)
+
+
+def hip_block_training_supported(erwin) -> bool:
+    if supported(erwin) is not None:
+        return False
+    layers = list(erwin.encoder) + [erwin.bottleneck] + (list(erwin.decoder) if erwin.decode else [])
+    return all(pc_ops.ball_attention_bwd_supported(L.hidden_dim, L.num_heads, L.ball_size) for L in layers)
+
+
 # --------------------------------------------------------------------------- differentiable restatement (training)
 def _rms(x, w):
     return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + torch.finfo(x.dtype).eps) * w
@@ -196,8 +276,15 @@ def _block_autograd(x, pos, blk):
     return x + F.linear(F.linear(y, s.w2.weight, s.w2.bias) * F.silu(F.linear(y, s.w1.weight, s.w1.bias)), s.w3.weight, s.w3.bias)
 
 
-def _layer_autograd(x, pos, rot, L):
+def _layer_autograd(x, pos, rot, L, W=None):
+    """W (the split-bf16 operands): the blocks run as ErwinBlockFunction on the HIP stages; None: torch device ops."""
     use_rot = any(L.rotate) and rot is not None
+    if W is not None:
+        rot32 = rot.to(torch.int32) if use_rot else None
+        for j, blk in enumerate(L.blocks):
+            x = ErwinBlockFunction.apply(x, pos, rot32 if (use_rot and L.rotate[j]) else None, blk, W.blocks[id(blk)],
+                                         *_block_params(blk))
+        return x
     inv = torch.argsort(rot) if use_rot else None
     for j, blk in enumerate(L.blocks):
         if use_rot and L.rotate[j]:
@@ -207,10 +294,16 @@ def _layer_autograd(x, pos, rot, L):
     return x
 
 
-def forward_autograd(erwin, feat, pos, batch_idx, edge_index, radius):
-    pos = pos.detach()
+def forward_autograd(erwin, feat, pos, batch_idx, edge_index, radius, hip_blocks: Optional[bool] = None):
+    """Training forward.  hip_blocks (default: wherever the configuration allows, HAET_PC_TORCH_BLOCKS=1 disables): the
+    transformer blocks -- where nearly all of the arithmetic is -- run forward and backward on the HIP stages
+    (ErwinBlockFunction); embedding / MPNN, pooling, BatchNorm and the gathers differentiate through torch device ops."""
+    pos = pos.detach().float().contiguous()
     d = erwin.dimensionality
-    sizes, tree_idx, tree_mask, rots, edge_index = build_structures(erwin, pos.float(), batch_idx, edge_index, radius)
+    if hip_blocks is None:
+        hip_blocks = not os.environ.get("HAET_PC_TORCH_BLOCKS") and hip_block_training_supported(erwin)
+    W = _weights(erwin) if hip_blocks else None
+    sizes, tree_idx, tree_mask, rots, edge_index = build_structures(erwin, pos, batch_idx, edge_index, radius)
     tree_idx = tree_idx.to(torch.long)
     rots = [None if r is None else r.to(torch.long) for r in rots]
     x = feat
@@ -229,7 +322,7 @@ def forward_autograd(erwin, feat, pos, batch_idx, edge_index, radius):
     x, p = x[tree_idx], pos[tree_idx]
     stack = []
     for i, L in enumerate(erwin.encoder):
-        x = _layer_autograd(x, p, rots[i], L)
+        x = _layer_autograd(x, p, rots[i], L, W)
         stack.append((x, p, rots[i]))
         st = L.pool.stride
         if st != 1:
@@ -238,7 +331,7 @@ def forward_autograd(erwin, feat, pos, batch_idx, edge_index, radius):
                 rel = (p.view(-1, st, d) - ctr[:, None]).reshape(-1, st * d)
             x = L.pool.norm(F.linear(torch.cat([x.reshape(-1, st * x.shape[1]), rel], 1), L.pool.proj.weight, L.pool.proj.bias))
             p = ctr
-    x = _layer_autograd(x, p, rots[len(erwin.encoder)], erwin.bottleneck)
+    x = _layer_autograd(x, p, rots[len(erwin.encoder)], erwin.bottleneck, W)
     if not erwin.decode:
         b = batch_idx[tree_idx]
         for s in erwin.strides:
@@ -252,7 +345,7 @@ def forward_autograd(erwin, feat, pos, batch_idx, edge_index, radius):
         y = F.linear(torch.cat([x, rel], -1), L.unpool.proj.weight, L.unpool.proj.bias).reshape(cx.shape[0], -1)
         x = L.unpool.norm(cx + y)
         p = cp
-        x = _layer_autograd(x, p, crot, L)
+        x = _layer_autograd(x, p, crot, L, W)
     mask = tree_mask.bool()
     return x[mask][torch.argsort(tree_idx[mask])]
 

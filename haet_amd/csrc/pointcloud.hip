@@ -491,6 +491,160 @@ __global__ __launch_bounds__(256) void radius_fill_kernel(const int32_t* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ block backward
+// y = x * rsqrt(mean(x^2) + eps) * w (+ positional term without x): dx = r (g - xhat mean(xhat g)), g = dy w, xhat = x r.
+// dX[slot(p)] (+)= dx of sequence row p.
+template <int NV>
+__global__ __launch_bounds__(256) void rms_bwd_kernel(const float* __restrict__ X, int ldx, const int32_t* __restrict__ perm,
+                                                     const float* __restrict__ dY, int ldy, const float* __restrict__ w,
+                                                     long long rows, int c, float* __restrict__ dX, int lddx, int accumulate) {
+    PC_ROW_PROLOGUE(rows)
+    const long long slot = perm ? perm[row] : row;
+    Row<NV> x, g;
+    x.load(X + (size_t)slot * ldx, c, lane);
+    g.load(dY + (size_t)row * ldy, c, lane);
+    const float r = rsqrtf(x.sumsq() / (float)c + FLT_EPSILON);
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int ch = 4 * (lane + 64 * i);
+        if (ch < c) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + ch);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                g.v[i][q] *= wv[q];
+                x.v[i][q] *= r;  // xhat
+                dot = fmaf(x.v[i][q], g.v[i][q], dot);
+            }
+        }
+    }
+    dot = wave_sum(dot) / (float)c;
+    Row<NV> o;
+    if (accumulate) o.load(dX + (size_t)slot * lddx, c, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float d = r * (g.v[i][q] - x.v[i][q] * dot);
+            o.v[i][q] = accumulate ? o.v[i][q] + d : d;
+        }
+    o.store(dX + (size_t)slot * lddx, c, lane);
+}
+
+// H = U2 silu(U1): dU1 = dH U2 sig (1 + U1 (1 - sig)), dU2 = dH silu(U1)
+template <int NV>
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const float* __restrict__ U, int ldu, const float* __restrict__ dH, int ldh,
+                                                        long long rows, int hid, float* __restrict__ dU, int lddu) {
+    PC_ROW_PROLOGUE(rows)
+    Row<NV> a, b, g;
+    a.load(U + (size_t)row * ldu, hid, lane);
+    b.load(U + (size_t)row * ldu + hid, hid, lane);
+    g.load(dH + (size_t)row * ldh, hid, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float u1 = a.v[i][q], sig = 1.0f / (1.0f + expf(-u1));
+            a.v[i][q] = g.v[i][q] * b.v[i][q] * sig * (1.0f + u1 * (1.0f - sig));
+            b.v[i][q] = g.v[i][q] * u1 * sig;
+        }
+    a.store(dU + (size_t)row * lddu, hid, lane);
+    b.store(dU + (size_t)row * lddu + hid, hid, lane);
+}
+
+// Backward of the per-ball attention (flash-attention style: nothing but qkv is kept from the forward).  One workgroup
+// per ball; Q, K, V, dO of all heads in LDS.  Pass A, one (query, head) per thread: row statistics (max, sum), O_i,
+// D_i = dO_i . O_i and dQ_i.  Pass B, one (key, head) per thread: dK_j, dV_j over the queries with the stored statistics.
+template <int HD>
+__global__ __launch_bounds__(256) void ball_attention_bwd_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dO,
+                                                                int ldo, int c, int heads, int ball, float scale,
+                                                                float* __restrict__ dqkv, int ldd) {
+    const int cs = c + 4;  // LDS row stride: lanes of a wave read DIFFERENT rows at the same channel
+    float* const Qs = pc_lds;
+    float* const Ks = Qs + (size_t)ball * cs;
+    float* const Vs = Ks + (size_t)ball * cs;
+    float* const Gs = Vs + (size_t)ball * cs;           // dO
+    float* const st = Gs + (size_t)ball * cs;           // [heads][ball][3]: max, 1 / sum, D
+    const size_t r0 = (size_t)blockIdx.x * ball;
+    for (int i = threadIdx.x; i < ball * (c / 4); i += 256) {
+        const int j = i / (c / 4), ch = 4 * (i % (c / 4));
+        *reinterpret_cast<f32x4*>(Qs + (size_t)j * cs + ch) = *reinterpret_cast<const f32x4*>(qkv + (r0 + j) * ldq + ch);
+        *reinterpret_cast<f32x4*>(Ks + (size_t)j * cs + ch) = *reinterpret_cast<const f32x4*>(qkv + (r0 + j) * ldq + c + ch);
+        *reinterpret_cast<f32x4*>(Vs + (size_t)j * cs + ch) = *reinterpret_cast<const f32x4*>(qkv + (r0 + j) * ldq + 2 * c + ch);
+        *reinterpret_cast<f32x4*>(Gs + (size_t)j * cs + ch) = *reinterpret_cast<const f32x4*>(dO + (r0 + j) * ldo + ch);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ball * heads; t += 256) {
+        const int h = t / ball, i = t % ball;
+        float q[HD], go[HD], acc[HD];
+#pragma unroll
+        for (int e = 0; e < HD; ++e) q[e] = Qs[(size_t)i * cs + h * HD + e] * scale, go[e] = Gs[(size_t)i * cs + h * HD + e], acc[e] = 0.f;
+        float mx = -INFINITY, l = 0.f;
+        for (int j = 0; j < ball; ++j) {  // statistics and O_i
+            const float* kj = Ks + (size_t)j * cs + h * HD;
+            float sc = 0.f;
+#pragma unroll
+            for (int e = 0; e < HD; ++e) sc = fmaf(q[e], kj[e], sc);
+            const float nm = fmaxf(mx, sc), corr = expf(mx - nm), pj = expf(sc - nm);
+            const float* vj = Vs + (size_t)j * cs + h * HD;
+            l = fmaf(l, corr, pj);
+#pragma unroll
+            for (int e = 0; e < HD; ++e) acc[e] = fmaf(acc[e], corr, pj * vj[e]);
+            mx = nm;
+        }
+        const float inv = 1.0f / l;
+        float D = 0.f;
+#pragma unroll
+        for (int e = 0; e < HD; ++e) D = fmaf(go[e], acc[e] * inv, D);
+        st[(h * ball + i) * 3 + 0] = mx;
+        st[(h * ball + i) * 3 + 1] = inv;
+        st[(h * ball + i) * 3 + 2] = D;
+        float dq[HD];
+#pragma unroll
+        for (int e = 0; e < HD; ++e) dq[e] = 0.f;
+        for (int j = 0; j < ball; ++j) {  // dQ_i = scale sum_j dS_ij K_j
+            const float* kj = Ks + (size_t)j * cs + h * HD;
+            const float* vj = Vs + (size_t)j * cs + h * HD;
+            float sc = 0.f, dp = 0.f;
+#pragma unroll
+            for (int e = 0; e < HD; ++e) sc = fmaf(q[e], kj[e], sc), dp = fmaf(go[e], vj[e], dp);
+            const float ds = expf(sc - mx) * inv * (dp - D);
+#pragma unroll
+            for (int e = 0; e < HD; ++e) dq[e] = fmaf(ds, kj[e], dq[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < HD; e += 4) {
+            const f32x4 o = {dq[e] * scale, dq[e + 1] * scale, dq[e + 2] * scale, dq[e + 3] * scale};
+            *reinterpret_cast<f32x4*>(dqkv + (r0 + i) * ldd + h * HD + e) = o;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ball * heads; t += 256) {
+        const int h = t / ball, j = t % ball;
+        float k[HD], v[HD], dk[HD], dv[HD];
+#pragma unroll
+        for (int e = 0; e < HD; ++e) k[e] = Ks[(size_t)j * cs + h * HD + e], v[e] = Vs[(size_t)j * cs + h * HD + e], dk[e] = 0.f, dv[e] = 0.f;
+        for (int i = 0; i < ball; ++i) {
+            const float* qi = Qs + (size_t)i * cs + h * HD;
+            const float* gi = Gs + (size_t)i * cs + h * HD;
+            float sc = 0.f, dp = 0.f;
+#pragma unroll
+            for (int e = 0; e < HD; ++e) sc = fmaf(qi[e], k[e], sc), dp = fmaf(gi[e], v[e], dp);
+            const float* s3 = st + (h * ball + i) * 3;
+            const float p = expf(sc * scale - s3[0]) * s3[1];
+            const float ds = p * (dp - s3[2]) * scale;
+#pragma unroll
+            for (int e = 0; e < HD; ++e) dv[e] = fmaf(p, gi[e], dv[e]), dk[e] = fmaf(ds, qi[e], dk[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < HD; e += 4) {
+            const f32x4 a = {dk[e], dk[e + 1], dk[e + 2], dk[e + 3]}, b = {dv[e], dv[e + 1], dv[e + 2], dv[e + 3]};
+            *reinterpret_cast<f32x4*>(dqkv + (r0 + j) * ldd + c + h * HD + e) = a;
+            *reinterpret_cast<f32x4*>(dqkv + (r0 + j) * ldd + 2 * c + h * HD + e) = b;
+        }
+    }
+}
+
 // The same edge list through a uniform grid (cells of edge >= r, keyed by (cloud, cell); points sorted by key, so a cell
 // lists its points in index order): a centre only looks at the 3^d cells around its own and keeps the max_nbrs SMALLEST
 // neighbour indices -- which is what "the first max_nbrs in index order" selects.  O(N * neighbours) instead of O(N^2).
@@ -750,4 +904,49 @@ extern "C" int haet_pc_radius_neighbours_grid(const float* pos, const int32_t* c
     hipLaunchKernelGGL(radius_grid_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), pos, cloud_of, sorted_idx, cell_ptr,
                        N, d, rad_grid(mn, cell, G), r * r, max_nbrs, nbr, cnt);
     return check_launch("radius_grid_kernel");
+}
+
+/* backward stages of an Erwin block on the point-cloud path (training): see haet_amd/components/erwinflash/pointcloud.py */
+extern "C" int haet_pc_rms_bwd(const float* X, int ldx, const int32_t* perm, const float* dY, int ldy, const float* w, long long rows,
+                               int c, float* dX, int lddx, int accumulate, haet_stream_t stream) {
+    if (!X || !dY || !w || !dX || rows < 1) return fail(HAET_E_ARG, "pc_rms_bwd: bad arguments");
+    PC_CHECK_WIDTH("pc_rms_bwd", c);
+    PC_DISPATCH(c, rms_bwd_kernel, row_grid(rows), dim3(256), 0, as_stream(stream), X, ldx, perm, dY, ldy, w, rows, c, dX, lddx, accumulate);
+    return check_launch("rms_bwd_kernel");
+}
+
+extern "C" int haet_pc_swiglu_bwd(const float* U, int ldu, const float* dH, int ldh, long long rows, int hid, float* dU, int lddu,
+                                  haet_stream_t stream) {
+    if (!U || !dH || !dU || rows < 1) return fail(HAET_E_ARG, "pc_swiglu_bwd: bad arguments");
+    PC_CHECK_WIDTH("pc_swiglu_bwd", hid);
+    PC_DISPATCH(hid, swiglu_bwd_kernel, row_grid(rows), dim3(256), 0, as_stream(stream), U, ldu, dH, ldh, rows, hid, dU, lddu);
+    return check_launch("swiglu_bwd_kernel");
+}
+
+extern "C" int haet_pc_ball_attention_bwd_supported(int c, int heads, int ball) {
+    if (!haet_pc_ball_attention_supported(c, heads, ball)) return 0;
+    return ((size_t)ball * (c + 4) * 16 + (size_t)heads * ball * 12 <= 156 * 1024) ? 1 : 0;
+}
+
+extern "C" int haet_pc_ball_attention_bwd(const float* qkv, int ldq, const float* dO, int ldo, long long rows, int c, int heads, int ball,
+                                          float* dqkv, int ldd, haet_stream_t stream) {
+    if (!qkv || !dO || !dqkv || rows < 1 || ball < 1 || rows % ball) return fail(HAET_E_ARG, "pc_ball_attention_bwd: bad arguments");
+    if (!haet_pc_ball_attention_bwd_supported(c, heads, ball))
+        return fail(HAET_E_ARG, "pc_ball_attention_bwd: c=%d heads=%d ball=%d unsupported", c, heads, ball);
+    const int hd = c / heads;
+    const size_t lds = (size_t)ball * (c + 4) * 16 + (size_t)heads * ball * 12;
+    const float scale = 1.0f / sqrtf((float)hd);
+    auto go = [&](auto kern) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(rows / ball)), dim3(256), lds, as_stream(stream), qkv, ldq, dO, ldo, c, heads, ball, scale,
+                           dqkv, ldd);
+    };
+    switch (hd) {
+        case 8: go(ball_attention_bwd_kernel<8>); break;
+        case 16: go(ball_attention_bwd_kernel<16>); break;
+        case 32: go(ball_attention_bwd_kernel<32>); break;
+        default: go(ball_attention_bwd_kernel<64>); break;
+    }
+    return check_launch("ball_attention_bwd_kernel");
 }

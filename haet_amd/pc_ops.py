@@ -182,6 +182,33 @@ def ball_attention(qkv: Tensor, c: int, heads: int, ball: int) -> Tensor:
     return out
 
 
+def rms_bwd_(X: Tensor, perm: Optional[Tensor], dY: Tensor, w: Tensor, c: int, dX: Tensor, accumulate: bool = True):
+    """dX[slot(p)] (+)= gradient of RMSNorm(X[slot(p)]) * w w.r.t. X, from dY[p] (in place on dX)."""
+    lib = _lib.load()
+    check(lib.haet_pc_rms_bwd(_p(X), X.stride(0), _p(perm), _p(dY), dY.stride(0), _p(w), X.shape[0], c, _p(dX), dX.stride(0),
+                              1 if accumulate else 0, _stream()), "haet_pc_rms_bwd")
+
+
+def swiglu_bwd(U: Tensor, dH: Tensor, hid: int) -> Tensor:
+    lib = _lib.load()
+    dU = torch.empty((U.shape[0], 2 * hid), dtype=torch.float32, device=U.device)
+    check(lib.haet_pc_swiglu_bwd(_p(U), U.stride(0), _p(dH), dH.stride(0), U.shape[0], hid, _p(dU), 2 * hid, _stream()),
+          "haet_pc_swiglu_bwd")
+    return dU
+
+
+def ball_attention_bwd_supported(c: int, heads: int, ball: int) -> bool:
+    return bool(_lib.load().haet_pc_ball_attention_bwd_supported(int(c), int(heads), int(ball)))
+
+
+def ball_attention_bwd(qkv: Tensor, dO: Tensor, c: int, heads: int, ball: int) -> Tensor:
+    lib = _lib.load()
+    dqkv = torch.empty((qkv.shape[0], 3 * c), dtype=torch.float32, device=qkv.device)
+    check(lib.haet_pc_ball_attention_bwd(_p(qkv), qkv.stride(0), _p(dO), dO.stride(0), qkv.shape[0], c, heads, ball, _p(dqkv), 3 * c,
+                                         _stream()), "haet_pc_ball_attention_bwd")
+    return dqkv
+
+
 def swiglu(U: Tensor, hid: int) -> Tensor:
     lib = _lib.load()
     H = torch.empty((U.shape[0], hid), dtype=torch.float32, device=U.device)
@@ -240,6 +267,9 @@ class PaddedLinear:
     def __init__(self, weight: Tensor, bias: Optional[Tensor]):
         O, K = weight.shape
         self.O, self.K, self.Op, self.Kp = O, K, round_up(O, 128), round_up(K, 32)
+        if self.Op == O and self.Kp == K:  # already inside the envelope: no padded copies (rebuilt every optimizer step)
+            self.w = SplitLinear(weight, bias)
+            return
         W = torch.zeros((self.Op, self.Kp), dtype=torch.float32, device=weight.device)
         W[:O, :K] = weight.detach()
         b = torch.zeros(self.Op, dtype=torch.float32, device=weight.device)

@@ -465,6 +465,18 @@ int haet_pc_unpool_input(const float* Xp, int ldx, const float* Pp, const float*
                          float* Y, int ldy, haet_stream_t stream);
 int haet_pc_unpool_merge(const float* skip, int lds_, const float* Yp, int ldy, long long rows, int c, int st, float* out,
                          int ldo, haet_stream_t stream);
+/* backward of the block stages (training of the stand-alone model: the blocks' forward and backward run on these
+ * kernels and the GEMMs; pooling / BatchNorm / MPNN differentiate through torch device ops):
+ *   haet_pc_rms_bwd:             dX[slot(p)] (+)= d RMSNorm(X[slot(p)]) * w  w.r.t. X, from dY[p]
+ *   haet_pc_swiglu_bwd:          dU [rows][2 hid] from dH and U = [U1 | U2]
+ *   haet_pc_ball_attention_bwd:  dqkv [rows][3c] from qkv and dO (statistics recomputed per ball)               */
+int haet_pc_rms_bwd(const float* X, int ldx, const int32_t* perm, const float* dY, int ldy, const float* w, long long rows,
+                    int c, float* dX, int lddx, int accumulate, haet_stream_t stream);
+int haet_pc_swiglu_bwd(const float* U, int ldu, const float* dH, int ldh, long long rows, int hid, float* dU, int lddu,
+                       haet_stream_t stream);
+int haet_pc_ball_attention_bwd_supported(int c, int heads, int ball);
+int haet_pc_ball_attention_bwd(const float* qkv, int ldq, const float* dO, int ldo, long long rows, int c, int heads, int ball,
+                               float* dqkv, int ldd, haet_stream_t stream);
 /* nn.BatchNorm1d over rows (pooling.py:23,38,56,68): batch statistics (stats [2][c] = mean, biased variance; part
  * [haet_pc_bn_blocks(rows)][2][c] scratch; running statistics / num_batches_tracked updated when given), then apply */
 int haet_pc_bn_blocks(long long rows);

@@ -171,14 +171,15 @@ def test_standalone_forward_vs_reference(name, hip_device):
 
 @pytest.mark.parametrize("name", ["two_clouds", "two_clouds_train", "planar_norot"])
 def test_autograd_restatement_matches_hip_forward_and_oracle_gradients(name, hip_device):
-    """With gradients recording the stages run as differentiable device ops on the HIP-built tree / graph: same output
-    as the HIP forward, gradients equal to the CPU oracle's autograd."""
+    """With gradients recording, the transformer blocks run forward and backward on the HIP stages (ErwinBlockFunction)
+    and the rest as differentiable device ops on the HIP-built tree / graph: same output as the no-grad HIP forward,
+    gradients equal to the CPU oracle's autograd."""
     f = G.load_ef(name)
     meta, kw = f["meta"], f["meta"]["kw"]
     m = _module(f, hip_device)
     feat = f["feat"].to(hip_device).requires_grad_(True)
     out = m(feat, f["pos"].to(hip_device), f["batch_idx"].to(hip_device), radius=meta["radius"])
-    assert O.rel_l2(out.detach().cpu(), f["exp"]["out"]) < FP32_TOL
+    assert O.rel_l2(out.detach().cpu(), f["exp"]["out"]) < (1e-4 if meta["train"] else FP32_TOL)
     with torch.no_grad():  # (the HIP stages on the same inputs; a fresh module: train mode moves the BatchNorm statistics)
         assert O.rel_l2(_module(f, hip_device)(feat.detach(), f["pos"].to(hip_device), f["batch_idx"].to(hip_device), radius=meta["radius"]).cpu(),
                         out.detach().cpu()) < (1e-4 if meta["train"] else FP32_TOL)
@@ -188,11 +189,12 @@ def test_autograd_restatement_matches_hip_forward_and_oracle_gradients(name, hip
     cf = f["feat"].clone().requires_grad_(True)
     want = O.erwinflash_forward(cf, f["pos"], f["batch_idx"], sd, G.ef_cfg(meta), kw["mp_steps"], radius=meta["radius"], training=meta["train"])
     (want * gout).sum().backward()
-    assert O.rel_l2(feat.grad.cpu(), cf.grad) < 1e-4
+    rel = 3e-4 if meta["train"] else 1e-4  # (train-mode BatchNorm: the same fp32 perturbation shows ~5x larger; bar 1e-3)
+    assert O.rel_l2(feat.grad.cpu(), cf.grad) < rel
     for k, p in m.named_parameters():
         if sd[k].grad is not None and float(sd[k].grad.abs().max()) > 0:
             diff = float((p.grad.cpu() - sd[k].grad).norm())
-            assert diff < 1e-4 * float(sd[k].grad.norm()) + 2e-5 * float(gout.norm()), k
+            assert diff < rel * float(sd[k].grad.norm()) + 2e-5 * float(gout.norm()), k
 
 
 def test_car_design_shape_properties(hip_device):
@@ -239,3 +241,59 @@ def test_encoder_only_and_argument_errors(hip_device):
         m(feat, pos, bidx)  # mp_steps > 0 and neither edge_index nor radius
     with pytest.raises(NotImplementedError):
         m(feat, pos, bidx, tree_idx=tree_idx.to(hip_device), tree_mask=f["exp"]["tree_mask"].to(hip_device), radius=0.2)
+
+
+@pytest.mark.parametrize("c,heads,ball,rotated", [(128, 8, 64, False), (128, 8, 32, True), (64, 4, 16, True), (32, 2, 32, False)])
+def test_block_function_matches_torch_autograd(c, heads, ball, rotated, hip_device):
+    """ErwinBlockFunction (forward and backward on the HIP stages) against the same block written with differentiable
+    torch ops: output, input gradient and all 14 parameter gradients."""
+    from haet_amd.components.erwinflash import pointcloud
+    from haet_amd.components.erwinflash.erwin_flash import ErwinTransformerBlock
+
+    torch.manual_seed(c + ball)
+    blk = ErwinTransformerBlock(c, heads, ball, 4, 3).to(hip_device)
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.copy_(torch.randn_like(p_) * (0.1 if p_.dim() == 2 else 0.2))
+        blk.norm1.weight.add_(1.0)
+        blk.norm2.weight.add_(1.0)
+    n = 8 * ball
+    g = torch.Generator().manual_seed(7)
+    x0 = torch.randn(n, c, generator=g).to(hip_device)
+    pos = torch.rand(n, 3, generator=g).to(hip_device)
+    rot = torch.randperm(n, generator=g).to(hip_device) if rotated else None
+    gout = torch.randn(n, c, generator=g).to(hip_device)
+
+    class _W:  # what pointcloud._Weights builds for one block
+        pass
+
+    class _Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder, self.decode, self.use_embedding = torch.nn.ModuleList(), False, False
+            layer = torch.nn.Module()
+            layer.blocks = torch.nn.ModuleList([blk])
+            self.bottleneck = layer
+
+    W = pointcloud._Weights(_Holder())
+    xa = x0.clone().requires_grad_(True)
+    out = pointcloud.ErwinBlockFunction.apply(xa, pos, rot.to(torch.int32) if rotated else None, blk, W.blocks[id(blk)],
+                                              *pointcloud._block_params(blk))
+    (out * gout).sum().backward()
+    got = [xa.grad.clone()] + [p_.grad.clone() for p_ in pointcloud._block_params(blk)]
+    for p_ in blk.parameters():
+        p_.grad = None
+    xb = x0.clone().requires_grad_(True)
+    if rotated:
+        ref = pointcloud._block_autograd(xb[rot], pos[rot], blk)[torch.argsort(rot)]
+    else:
+        ref = pointcloud._block_autograd(xb, pos, blk)
+    (ref * gout).sum().backward()
+    want = [xb.grad] + [p_.grad for p_ in pointcloud._block_params(blk)]
+    errs = {"out": O.rel_l2(out.detach().cpu(), ref.detach().cpu())}
+    names = ["x", "norm1", "pe_w", "pe_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "norm2", "w1_w", "w1_b", "w2_w", "w2_b", "w3_w", "w3_b"]
+    for nm, a, b in zip(names, got, want):
+        errs[nm] = O.rel_l2(a.cpu(), b.cpu())
+    print({k: f"{v:.1e}" for k, v in errs.items()})
+    assert errs.pop("out") < 5e-5  # (split-bf16 GEMMs against fp32 library GEMMs; north_star: 1e-3)
+    assert max(errs.values()) < 2e-4, errs
