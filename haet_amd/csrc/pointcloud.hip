@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) void ball_attention_kernel(const float* __rest
         *reinterpret_cast<f32x4*>(Vs + (size_t)j * c + ch) = *reinterpret_cast<const f32x4*>(qkv + (r0 + j) * ldq + 2 * c + ch);
     }
     __syncthreads();
+    constexpr float kL2e = 1.4426950408889634f;
     for (int t = threadIdx.x; t < ball * heads; t += 256) {
         const int h = t / ball, i = t % ball;
         float q[HD], acc[HD];
@@ -178,21 +179,35 @@ __global__ __launch_bounds__(256) void ball_attention_kernel(const float* __rest
         for (int e = 0; e < HD; e += 4) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(qkv + (r0 + i) * ldq + h * HD + e);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) q[e + u] = v[u] * scale, acc[e + u] = 0.f;
+            for (int u = 0; u < 4; ++u) q[e + u] = v[u] * (scale * kL2e), acc[e + u] = 0.f;  // scores in log2 units
         }
+        // online softmax over the keys in chunks of 16: one rescale of the accumulator per chunk, one v_exp per key
         float mx = -INFINITY, l = 0.f;
-        for (int j = 0; j < ball; ++j) {
-            const float* kj = Ks + (size_t)j * c + h * HD;
-            float s = 0.f;
+        for (int j0 = 0; j0 < ball; j0 += 16) {
+            float sc[16];
+            float cm = mx;
 #pragma unroll
-            for (int e = 0; e < HD; ++e) s = fmaf(q[e], kj[e], s);
-            const float nm = fmaxf(mx, s);
-            const float corr = expf(mx - nm), pj = expf(s - nm);
-            const float* vj = Vs + (size_t)j * c + h * HD;
-            l = fmaf(l, corr, pj);
+            for (int u = 0; u < 16; ++u) {
+                const float* kj = Ks + (size_t)(j0 + u < ball ? j0 + u : ball - 1) * c + h * HD;
+                float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < HD; ++e) acc[e] = fmaf(acc[e], corr, pj * vj[e]);
-            mx = nm;
+                for (int e = 0; e < HD; ++e) s = fmaf(q[e], kj[e], s);
+                sc[u] = j0 + u < ball ? s : -INFINITY;
+                cm = fmaxf(cm, sc[u]);
+            }
+            const float corr = __builtin_amdgcn_exp2f(mx - cm);  // (first chunk: exp2(-inf) = 0)
+            l *= corr;
+#pragma unroll
+            for (int e = 0; e < HD; ++e) acc[e] *= corr;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float pj = __builtin_amdgcn_exp2f(sc[u] - cm);
+                const float* vj = Vs + (size_t)(j0 + u < ball ? j0 + u : ball - 1) * c + h * HD;
+                l += pj;
+#pragma unroll
+                for (int e = 0; e < HD; ++e) acc[e] = fmaf(pj, vj[e], acc[e]);
+            }
+            mx = cm;
         }
         const float inv = 1.0f / l;
 #pragma unroll
@@ -560,6 +575,7 @@ __global__ __launch_bounds__(256) void ball_attention_bwd_kernel(const float* __
                                                                 int ldo, int c, int heads, int ball, float scale,
                                                                 float* __restrict__ dqkv, int ldd) {
     const int cs = c + 4;  // LDS row stride: lanes of a wave read DIFFERENT rows at the same channel
+    constexpr float kL2e = 1.4426950408889634f;  // scores are kept in log2 units: exp = one v_exp_f32
     float* const Qs = pc_lds;
     float* const Ks = Qs + (size_t)ball * cs;
     float* const Vs = Ks + (size_t)ball * cs;
@@ -578,14 +594,14 @@ __global__ __launch_bounds__(256) void ball_attention_bwd_kernel(const float* __
         const int h = t / ball, i = t % ball;
         float q[HD], go[HD], acc[HD];
 #pragma unroll
-        for (int e = 0; e < HD; ++e) q[e] = Qs[(size_t)i * cs + h * HD + e] * scale, go[e] = Gs[(size_t)i * cs + h * HD + e], acc[e] = 0.f;
+        for (int e = 0; e < HD; ++e) q[e] = Qs[(size_t)i * cs + h * HD + e] * (scale * kL2e), go[e] = Gs[(size_t)i * cs + h * HD + e], acc[e] = 0.f;
         float mx = -INFINITY, l = 0.f;
         for (int j = 0; j < ball; ++j) {  // statistics and O_i
             const float* kj = Ks + (size_t)j * cs + h * HD;
             float sc = 0.f;
 #pragma unroll
             for (int e = 0; e < HD; ++e) sc = fmaf(q[e], kj[e], sc);
-            const float nm = fmaxf(mx, sc), corr = expf(mx - nm), pj = expf(sc - nm);
+            const float nm = fmaxf(mx, sc), corr = __builtin_amdgcn_exp2f(mx - nm), pj = __builtin_amdgcn_exp2f(sc - nm);
             const float* vj = Vs + (size_t)j * cs + h * HD;
             l = fmaf(l, corr, pj);
 #pragma unroll
@@ -608,7 +624,7 @@ __global__ __launch_bounds__(256) void ball_attention_bwd_kernel(const float* __
             float sc = 0.f, dp = 0.f;
 #pragma unroll
             for (int e = 0; e < HD; ++e) sc = fmaf(q[e], kj[e], sc), dp = fmaf(go[e], vj[e], dp);
-            const float ds = expf(sc - mx) * inv * (dp - D);
+            const float ds = __builtin_amdgcn_exp2f(sc - mx) * inv * (dp - D);
 #pragma unroll
             for (int e = 0; e < HD; ++e) dq[e] = fmaf(ds, kj[e], dq[e]);
         }
@@ -631,7 +647,7 @@ __global__ __launch_bounds__(256) void ball_attention_bwd_kernel(const float* __
 #pragma unroll
             for (int e = 0; e < HD; ++e) sc = fmaf(qi[e], k[e], sc), dp = fmaf(gi[e], v[e], dp);
             const float* s3 = st + (h * ball + i) * 3;
-            const float p = expf(sc * scale - s3[0]) * s3[1];
+            const float p = __builtin_amdgcn_exp2f(sc * (scale * kL2e) - s3[0]) * s3[1];
             const float ds = p * (dp - s3[2]) * scale;
 #pragma unroll
             for (int e = 0; e < HD; ++e) dv[e] = fmaf(p, gi[e], dv[e]), dk[e] = fmaf(ds, qi[e], dk[e]);
