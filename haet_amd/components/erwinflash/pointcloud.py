@@ -89,14 +89,34 @@ def cloud_sizes(batch_idx: Tensor) -> List[int]:
     return torch.bincount(batch_idx.to(torch.long)).tolist()
 
 
-def build_structures(erwin, pos: Tensor, batch_idx: Tensor, edge_index: Optional[Tensor], radius: Optional[float]):
-    sizes = cloud_sizes(batch_idx)
-    tree_idx, tree_mask, rots = pc_ops.balltree_big(pos, sizes, erwin.strides, erwin.ball_sizes, float(erwin.rotate))
+def build_graph(erwin, pos: Tensor, batch_idx: Tensor, sizes, edge_index: Optional[Tensor], radius: Optional[float]):
     if edge_index is None and erwin.use_embedding and erwin.mp_steps > 0:
         if radius is None:
             raise AssertionError("radius (float) must be provided if edge_index is not given to build radius graph")
         edge_index = pc_ops.radius_graph(pos, radius, batch_idx, sizes)
-    return sizes, tree_idx, tree_mask, rots, edge_index
+    return edge_index
+
+
+def build_tree(erwin, pos: Tensor, sizes, side: Optional[torch.cuda.Stream] = None):
+    """The ball tree and its rotated re-partitions.  `side`: build on that stream -- the builder is a chain of small
+    launches with host waits in between (a few workgroups each), which the embedding's kernels on the caller's stream
+    overlap; the caller's stream then waits for the side stream."""
+    if side is None:
+        return pc_ops.balltree_big(pos, sizes, erwin.strides, erwin.ball_sizes, float(erwin.rotate))
+    cur = torch.cuda.current_stream(pos.device)
+    side.wait_stream(cur)  # (pos may still be in flight)
+    with torch.cuda.stream(side):
+        tree_idx, tree_mask, rots = pc_ops.balltree_big(pos, sizes, erwin.strides, erwin.ball_sizes, float(erwin.rotate))
+    cur.wait_stream(side)
+    for t in [tree_idx, tree_mask] + [r for r in rots if r is not None]:
+        t.record_stream(cur)
+    return tree_idx, tree_mask, rots
+
+
+def build_structures(erwin, pos: Tensor, batch_idx: Tensor, edge_index: Optional[Tensor], radius: Optional[float]):
+    sizes = cloud_sizes(batch_idx)
+    tree_idx, tree_mask, rots = build_tree(erwin, pos, sizes)
+    return sizes, tree_idx, tree_mask, rots, build_graph(erwin, pos, batch_idx, sizes, edge_index, radius)
 
 
 # --------------------------------------------------------------------------- HIP forward
@@ -145,8 +165,16 @@ def forward_hip(erwin, feat: Tensor, pos: Tensor, batch_idx: Tensor, edge_index:
     feat, pos = ops._f32(feat, "node_features"), ops._f32(pos, "node_positions")
     d = erwin.dimensionality
     W = _weights(erwin)
-    sizes, tree_idx, tree_mask, rots, edge_index = build_structures(erwin, pos, batch_idx, edge_index, radius)
+    sizes = cloud_sizes(batch_idx)
+    # graph + embedding are enqueued first; the tree is built beside them on a side stream (they meet at the gather)
+    edge_index = build_graph(erwin, pos, batch_idx, sizes, edge_index, radius)
     x = _embed(erwin, W, feat, pos, edge_index) if erwin.use_embedding else feat
+    side = None
+    if erwin.use_embedding and not os.environ.get("HAET_PC_ONE_STREAM"):
+        side = erwin.__dict__.get("_pc_side_stream")
+        if side is None or side.device != pos.device:
+            side = erwin.__dict__["_pc_side_stream"] = torch.cuda.Stream(device=pos.device)
+    tree_idx, tree_mask, rots = build_tree(erwin, pos, sizes, side)
     c0 = x.shape[1]
     X = pc_ops.gather_rows(x, tree_idx, c0)
     P = pos.index_select(0, tree_idx.to(torch.long))
