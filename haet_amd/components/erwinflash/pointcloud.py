@@ -252,16 +252,16 @@ class ErwinBlockFunction(torch.autograd.Function):
         pc_ops.rms_bwd_(X2, None, dY2, w["norm2"], c, dX)
         xh2 = X2 * torch.rsqrt(X2.pow(2).mean(-1, keepdim=True) + torch.finfo(torch.float32).eps)
         g_norm2 = (dY2[:, :c] * xh2).sum(0)
-        g_w12, g_b12 = dU.t() @ Y2, dU.sum(0)
-        g_w3, g_b3 = g.t() @ H, g.sum(0)
+        g_w12, g_b12 = ops.linear_wgrad(dU, Y2)  # (split-bf16 G^T X kernel where both widths are multiples of 128)
+        g_w3, g_b3 = ops.linear_wgrad(g, H)
         del U, H, dH, Y2, xh2
         # x2 = x1 + scatter(proj(attention(qkv(y1))))
         dR = pc_ops.gather_rows(dX, perm, c) if perm is not None else dX
         dA = w["projT"](dR)
-        g_wp, g_bp = dR.t() @ A, dR.sum(0)
+        g_wp, g_bp = ops.linear_wgrad(dR, A)
         dQKV = pc_ops.ball_attention_bwd(QKV, dA, c, heads, ball)
         dY1 = w["qkvT"](dQKV)
-        g_wq, g_bq = dQKV.t() @ Y1, dQKV.sum(0)
+        g_wq, g_bq = ops.linear_wgrad(dQKV, Y1)
         pc_ops.rms_bwd_(X1, perm, dY1, w["norm1"], c, dX)
         Xs = X1.index_select(0, perm.long()) if perm is not None else X1
         xh1 = Xs * torch.rsqrt(Xs.pow(2).mean(-1, keepdim=True) + torch.finfo(torch.float32).eps)

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_kernel(const float* __restric
     typedef float f4v __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
-    const int kblocks = K / 256;
+    const int kblocks = (K + 255) / 256;
     const int ob0 = (blockIdx.y / kblocks) * 256, kb0 = (blockIdx.y % kblocks) * 256;  // this workgroup's block of dW
     const int ol = 128 * (wave >> 2), kl = 64 * (wave & 3);                             // this wave's 128 x 64 part
     const int n0 = blockIdx.x * chunk, n1 = min(N, n0 + chunk);
@@ -96,10 +96,12 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_kernel(const float* __restric
                       (unsigned)(d + tg.dd) < (unsigned)tg.gD;
                 if (okx) rx = (size_t)((long long)r + ((long long)tg.dh * tg.gW + tg.dw) * tg.gD + tg.dd);
             }
-            const f4v g4 = *reinterpret_cast<const f4v*>(G + r * O + ob0 + sc);
-            const f4v x4 = *reinterpret_cast<const f4v*>(X + rx * K + kb0 + sc);
-            sg[i] = ok ? g4 : zero4;
-            sx[i] = okx ? x4 : zero4;
+            // (O, K multiples of 128: the columns of a 256-wide block past the matrix read a clamped address as zero)
+            const bool cg = ob0 + sc < O, cx = kb0 + sc < K;
+            const f4v g4 = *reinterpret_cast<const f4v*>(G + r * O + (cg ? ob0 + sc : 0));
+            const f4v x4 = *reinterpret_cast<const f4v*>(X + rx * K + (cx ? kb0 + sc : 0));
+            sg[i] = ok && cg ? g4 : zero4;
+            sx[i] = okx && cx ? x4 : zero4;
         }
     };
     auto stash = [&](float* buf) {
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const float* __restrict
     typedef float f4v __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char tsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
-    const int kblocks = K / 256;
+    const int kblocks = (K + 255) / 256;
     const int ob0 = (blockIdx.y / kblocks) * 256, kb0 = (blockIdx.y % kblocks) * 256;
     const int wo = wave >> 2, wk = wave & 3;  // this wave's 128 x 64 part of the 256 x 256 block
     const int n0 = blockIdx.x * chunk, n1 = min(N, n0 + chunk);
@@ -256,10 +258,12 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const float* __restrict
                       (unsigned)(d + tg.dd) < (unsigned)tg.gD;
                 if (okx) rx = (size_t)((long long)r + ((long long)tg.dh * tg.gW + tg.dw) * tg.gD + tg.dd);
             }
-            const f4v g4 = *reinterpret_cast<const f4v*>(G + r * O + ob0 + sc);
-            const f4v x4 = *reinterpret_cast<const f4v*>(X + rx * K + kb0 + sc);
-            sg[i] = ok ? g4 : zero4;
-            sx[i] = okx ? x4 : zero4;
+            // (O, K multiples of 128: the columns of a 256-wide block past the matrix read a clamped address as zero)
+            const bool cg = ob0 + sc < O, cx = kb0 + sc < K;
+            const f4v g4 = *reinterpret_cast<const f4v*>(G + r * O + (cg ? ob0 + sc : 0));
+            const f4v x4 = *reinterpret_cast<const f4v*>(X + rx * K + (cx ? kb0 + sc : 0));
+            sg[i] = ok && cg ? g4 : zero4;
+            sx[i] = okx && cx ? x4 : zero4;
         }
     };
     auto put = [&](int base, int row, const f4v v) {  // 4 consecutive columns of one row -> the 8-B {hi} and {lo} pieces
@@ -359,7 +363,7 @@ static int x3_attr() {
 
 using namespace haet;
 
-extern "C" int haet_linear_wgrad_supported(int O, int K) { return (O > 0 && K > 0 && O % 256 == 0 && K % 256 == 0) ? 1 : 0; }
+extern "C" int haet_linear_wgrad_supported(int O, int K) { return (O > 0 && K > 0 && O % 128 == 0 && K % 128 == 0) ? 1 : 0; }
 
 extern "C" int haet_linear_wgrad_num_parts(int N) {
     if (N < 1) return HAET_E_ARG;
@@ -371,9 +375,9 @@ extern "C" int haet_linear_wgrad(const float* G, const float* X, int N, int O, i
                                  haet_stream_t stream) {
     if (!G || !X || !parts) return fail(HAET_E_ARG, "linear_wgrad: null pointer");
     if (N < 1 || !haet_linear_wgrad_supported(O, K))
-        return fail(HAET_E_ARG, "linear_wgrad: N=%d O=%d K=%d unsupported (O, K multiples of 256)", N, O, K);
+        return fail(HAET_E_ARG, "linear_wgrad: N=%d O=%d K=%d unsupported (O, K multiples of 128)", N, O, K);
     const int chunk = wgrad_chunk(N);
-    dim3 grid((N + chunk - 1) / chunk, (O / 256) * (K / 256));
+    dim3 grid((N + chunk - 1) / chunk, ((O + 255) / 256) * ((K + 255) / 256));
     const size_t lds = 2 * (size_t)kTileFloats * sizeof(float);  // 128 KB
     static PerDeviceOnce attr_set;
     if (!attr_set.done()) {
@@ -405,9 +409,9 @@ extern "C" int haet_conv_wgrad_tap(const float* G, const float* X, int B, int gH
     if (!G || !X || !parts) return fail(HAET_E_ARG, "conv_wgrad_tap: null pointer");
     const long long rows = (long long)B * gH * gW * gD;
     if (B < 1 || gH < 1 || gW < 1 || gD < 1 || rows > 0x7fffffffLL || !haet_linear_wgrad_supported(O, Cin))
-        return fail(HAET_E_ARG, "conv_wgrad_tap: bad grid or O=%d / C_in=%d not multiples of 256", O, Cin);
+        return fail(HAET_E_ARG, "conv_wgrad_tap: bad grid or O=%d / C_in=%d not multiples of 128", O, Cin);
     const int N = (int)rows, chunk = wgrad_chunk(N);
-    dim3 grid((N + chunk - 1) / chunk, (O / 256) * (Cin / 256));
+    dim3 grid((N + chunk - 1) / chunk, ((O + 255) / 256) * ((Cin + 255) / 256));
     const size_t lds = 2 * (size_t)kTileFloats * sizeof(float);
     static PerDeviceOnce attr_set;
     if (!attr_set.done()) {

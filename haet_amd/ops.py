@@ -431,7 +431,7 @@ def linear_narrow(x: Tensor, weight: Tensor, bias: Optional[Tensor], gelu: bool 
 
 def linear_wgrad(g: Tensor, x: Tensor):
     """(dW [O,K], db [O]) of a Linear from g = dL/d output [..., O] and its input x [..., K], contracted over
-    all leading dimensions: haet_linear_wgrad where O, K are multiples of 256, the library GEMM otherwise."""
+    all leading dimensions: haet_linear_wgrad where O, K are multiples of 128, the library GEMM otherwise."""
     lib = _lib.load()
     g, x = _f32(g, "g"), _f32(x, "x")
     O, K = g.shape[-1], x.shape[-1]
@@ -442,12 +442,12 @@ def linear_wgrad(g: Tensor, x: Tensor):
     if not lib.haet_linear_wgrad_supported(O, K):
         return g2.t() @ x2, g2.sum(dim=0)
     P = lib.haet_linear_wgrad_num_parts(N)
-    ob, kb = O // 256, K // 256
+    ob, kb = (O + 255) // 256, (K + 255) // 256
     parts = torch.empty((P, ob * kb, 256 * 256 + 256), dtype=torch.float32, device=g.device)
     check(lib.haet_linear_wgrad(_p(g2), _p(x2), N, O, K, _p(parts), _stream()), "haet_linear_wgrad")
     s = parts.sum(dim=0)
-    dW = s[:, :256 * 256].view(ob, kb, 256, 256).permute(0, 2, 1, 3).reshape(O, K)
-    db = s[:, 256 * 256:].view(ob, kb, 256)[:, 0].reshape(O)
+    dW = s[:, :256 * 256].view(ob, kb, 256, 256).permute(0, 2, 1, 3).reshape(ob * 256, kb * 256)[:O, :K]
+    db = s[:, 256 * 256:].view(ob, kb, 256)[:, 0].reshape(ob * 256)[:O]
     return dW, db
 
 
@@ -468,7 +468,7 @@ def conv_wgrad(g: Tensor, x: Tensor, grid: Tuple[int, ...], kernel: Tuple[int, .
     if gH * gW * gD != N or x.shape[1] != N:
         raise HaetError("conv_wgrad: tensors do not match the grid")
     P = lib.haet_linear_wgrad_num_parts(B * N)
-    ob, kb = O // 256, Cin // 256
+    ob, kb = (O + 255) // 256, (Cin + 255) // 256
     parts = torch.empty((P, ob * kb, 256 * 256 + 256), dtype=torch.float32, device=g.device)
     dW = torch.empty((O, Cin) + ks, dtype=torch.float32, device=g.device)
     db = None
@@ -478,9 +478,9 @@ def conv_wgrad(g: Tensor, x: Tensor, grid: Tuple[int, ...], kernel: Tuple[int, .
                 check(lib.haet_conv_wgrad_tap(_p(g), _p(x), B, gH, gW, gD, O, Cin, a - ks[0] // 2, b - ks[1] // 2,
                                               c - ks[2] // 2, _p(parts), _stream()), "haet_conv_wgrad_tap")
                 s = parts.sum(dim=0)
-                dW[:, :, a, b, c] = s[:, :256 * 256].view(ob, kb, 256, 256).permute(0, 2, 1, 3).reshape(O, Cin)
+                dW[:, :, a, b, c] = s[:, :256 * 256].view(ob, kb, 256, 256).permute(0, 2, 1, 3).reshape(ob * 256, kb * 256)[:O, :Cin]
                 if db is None:
-                    db = s[:, 256 * 256:].view(ob, kb, 256)[:, 0].reshape(O).clone()
+                    db = s[:, 256 * 256:].view(ob, kb, 256)[:, 0].reshape(ob * 256)[:O].clone()
     return dW.reshape((O, Cin) + tuple(kernel)), db
 
 

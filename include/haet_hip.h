@@ -341,7 +341,8 @@ int haet_slice_bwd_points(const float* x_lin, const float* Ws, const float* bs, 
 /* Weight gradient of a Linear over the points (to_out, in_project_x): per-workgroup partial records of
  *   dW[O][K] = sum_n G[n][o] X[n][k],  db[o] = sum_n G[n][o]        (G = dL/d output [N,O], X = the input [N,K])
  * parts [P][(O/256)*(K/256)][256*256 + 256]: per 256 x 256 block of dW (row-major blocks, o-block major)
- * the block and its 256 entries of db; the caller sums over P.  O and K must be multiples of 256.       */
+ * the block and its 256 entries of db; the caller sums over P.  O and K must be multiples of 128 (a 256-wide
+ * block that sticks out of the matrix holds zeros there; ceil(O/256) * ceil(K/256) blocks).                  */
 int haet_linear_wgrad_supported(int O, int K);
 int haet_linear_wgrad_num_parts(int N);
 int haet_linear_wgrad(const float* G, const float* X, int N, int O, int K, float* parts, haet_stream_t stream);

@@ -175,7 +175,8 @@ def test_backward_never_materialises_the_slice_weights(hip_device):
 
 
 @pytest.mark.parametrize("rows,O,K", [(1, 256, 256), (31, 256, 256), (1000, 256, 256), (70001, 256, 256), (300, 512, 256),
-                                      (257, 256, 768), (500, 64, 128)])
+                                      (257, 256, 768), (500, 64, 128), (4097, 128, 128), (3000, 384, 128), (2000, 128, 512),
+                                      (1500, 1024, 128), (999, 640, 384)])
 def test_linear_weight_gradient_vs_fp64(rows, O, K, hip_device):
     """haet_linear_wgrad (split-bf16 MFMA, contraction over the points) against an fp64 product; shapes outside its
     envelope take the library GEMM."""
