@@ -154,6 +154,9 @@ SIGNATURES = {
     "haet_pc_swiglu_bwd": (c_int, [_P, c_int, _P, c_int, c_longlong, c_int, _P, c_int, _P]),
     "haet_pc_ball_attention_bwd_supported": (c_int, [c_int, c_int, c_int]),
     "haet_pc_ball_attention_bwd": (c_int, [_P, c_int, _P, c_int, c_longlong, c_int, c_int, c_int, _P, c_int, _P]),
+    "haet_pc_ln_bwd": (c_int, [_P, c_int, _P, c_int, c_longlong, c_int, c_float, _P, c_int, _P]),
+    "haet_pc_mpnn_bwd_waves": (c_int, [c_longlong]),
+    "haet_pc_mpnn_message_bwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, c_int, c_longlong, c_int, c_float, _P, c_int, _P, _P]),
     "haet_pc_bn_blocks": (c_int, [c_longlong]),
     "haet_pc_bn_stats": (c_int, [_P, c_int, c_longlong, c_int, c_float, _P, _P, _P, _P, _P, _P]),
     "haet_pc_bn_apply": (c_int, [_P, c_int, c_longlong, c_int, _P, _P, c_float, _P, _P, _P]),

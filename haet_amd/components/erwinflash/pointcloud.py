@@ -71,8 +71,10 @@ class _Weights:
             self.mp = []
             for msg, upd in zip(e.mpnn.fused_message_update, e.mpnn.update_fns):
                 W = msg[0].weight
-                self.mp.append(dict(ab=P(torch.cat([W[:, :c], W[:, c:2 * c]], 0), None), wc=W[:, 2 * c:].detach().float().contiguous(),
-                                    b=msg[0].bias.detach().float().contiguous(), upd=P(upd[0].weight, upd[0].bias)))
+                wab = torch.cat([W[:, :c], W[:, c:2 * c]], 0)
+                self.mp.append(dict(ab=P(wab, None), wc=W[:, 2 * c:].detach().float().contiguous(),
+                                    b=msg[0].bias.detach().float().contiguous(), upd=P(upd[0].weight, upd[0].bias),
+                                    abT=P(wab.t(), None), updT=P(upd[0].weight.t(), None)))
 
 
 def _weights(erwin) -> _Weights:
@@ -271,6 +273,42 @@ class ErwinBlockFunction(torch.autograd.Function):
                 g_w12[:hid], g_b12[:hid], g_w12[hid:2 * hid], g_b12[hid:2 * hid], g_w3, g_b3)
 
 
+class MpnnStepFunction(torch.autograd.Function):
+    """One message-passing step (mpnn.py:48-68) forward and backward on the HIP stages: node-level GEMMs for the h_j / h_i
+    parts of the message Linear, the per-edge kernel for GELU + LayerNorm + mean, and their backward (sender gradients
+    by float atomics, the position columns' gradient from per-wave partial sums).  Nothing of size [edges, .] exists."""
+
+    @staticmethod
+    def forward(ctx, h, pos, rowptr, src, st, w_msg, b_msg, w_upd, b_upd):
+        h = ops._f32(h, "h")
+        c = h.shape[1]
+        AB = st["ab"](h)
+        hcat = torch.empty((h.shape[0], 2 * c), dtype=torch.float32, device=h.device)
+        hcat[:, :c] = h
+        pc_ops.mpnn_message(AB, pos, rowptr, src, st["wc"], st["b"], c, hcat[:, c:])
+        v = st["upd"](hcat)
+        out = h.clone()
+        pc_ops.ln_residual(v, out, None, c)
+        ctx.save_for_backward(pos, rowptr, src, AB, hcat, v)
+        ctx.st = st
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, rowptr, src, AB, hcat, v = ctx.saved_tensors
+        st = ctx.st
+        c, d = hcat.shape[1] // 2, pos.shape[1]
+        g = ops._f32(g, "grad")
+        dv = pc_ops.ln_bwd(v, g, c)
+        g_wu, g_bu = ops.linear_wgrad(dv, hcat)
+        dhcat = st["updT"](dv)
+        dAB, g_wc = pc_ops.mpnn_message_bwd(AB, pos, rowptr, src, st["wc"], st["b"], dhcat[:, c:2 * c], c)
+        g_wab, _ = ops.linear_wgrad(dAB, hcat[:, :c].contiguous())
+        dh = g + dhcat[:, :c] + st["abT"](dAB)[:, :c]
+        g_wm = torch.cat([g_wab[:c], g_wab[c:2 * c], g_wc], dim=1)
+        return dh, None, None, None, None, g_wm, dAB[:, c:].sum(0), g_wu, g_bu
+
+
 def _block_params(blk):
     a, s = blk.BMSA, blk.swiglu
     return (blk.norm1.weight, a.pe_proj.weight, a.pe_proj.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
@@ -338,7 +376,11 @@ def forward_autograd(erwin, feat, pos, batch_idx, edge_index, radius, hip_blocks
     if erwin.use_embedding:
         e = erwin.embed
         x = F.linear(feat, e.embed_fn.weight, e.embed_fn.bias)
-        if erwin.mp_steps > 0:
+        if erwin.mp_steps > 0 and W is not None and x.shape[1] % 128 == 0 and x.shape[1] <= 512:
+            rowptr, src = pc_ops.edges_to_csr(edge_index, x.shape[0])
+            for st, msg, upd in zip(W.mp, e.mpnn.fused_message_update, e.mpnn.update_fns):
+                x = MpnnStepFunction.apply(x, pos, rowptr, src, st, msg[0].weight, msg[0].bias, upd[0].weight, upd[0].bias)
+        elif erwin.mp_steps > 0:
             row, col = edge_index[0].to(torch.long), edge_index[1].to(torch.long)
             attr = pos[row] - pos[col]
             c = x.shape[1]

@@ -661,6 +661,149 @@ __global__ __launch_bounds__(256) void ball_attention_bwd_kernel(const float* __
     }
 }
 
+// u = LayerNorm_noaffine(v): dv = rstd (g - mean(g) - xhat mean(g xhat))
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ V, int ldv, const float* __restrict__ dU, int ldu,
+                                                    long long rows, int c, float eps, float* __restrict__ dV, int lddv) {
+    PC_ROW_PROLOGUE(rows)
+    Row<NV> x, g;
+    x.load(V + (size_t)row * ldv, c, lane);
+    g.load(dU + (size_t)row * ldu, c, lane);
+    const float mean = x.sum() / (float)c;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float dv = (4 * (lane + 64 * i) < c) ? x.v[i][q] - mean : 0.f;
+            x.v[i][q] = dv;
+            ss = fmaf(dv, dv, ss);
+        }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)c + eps);
+    float gm = 0.f, gx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            x.v[i][q] *= rstd;  // xhat (0 past c)
+            gm += g.v[i][q];
+            gx = fmaf(g.v[i][q], x.v[i][q], gx);
+        }
+    gm = wave_sum(gm) / (float)c;
+    gx = wave_sum(gx) / (float)c;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g.v[i][q] = rstd * (g.v[i][q] - gm - x.v[i][q] * gx);
+    g.store(dV + (size_t)row * lddv, c, lane);
+}
+
+// Backward of mpnn_message_kernel.  One wave per receiving node i walks its edges again (z, GELU, LayerNorm statistics
+// recomputed), with dm_e = dagg_i / deg_i:  dz_e = gelu'(z_e) LN_bwd(dm_e);  dA[src_e] += dz_e (float atomics: a sender has
+// edges in many segments),  dB[i] = sum_e dz_e,  and this wave's share of dWc = sum_e dz_e (pos_src - pos_i)^T goes to
+// its own row of `wc_part` (persistent waves: the caller adds the rows).  d bias = sum_i dB[i].
+template <int NV>
+__global__ __launch_bounds__(256) void mpnn_message_bwd_kernel(const float* __restrict__ AB, int ldab, const float* __restrict__ pos, int d,
+                                                              const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
+                                                              const float* __restrict__ Wc, const float* __restrict__ bias,
+                                                              const float* __restrict__ dagg, int ldg, long long rows, int c, float eps,
+                                                              float* __restrict__ dAB, int ldd, float* __restrict__ wc_part) {
+    const int lane = threadIdx.x & 63;
+    const long long wid = (long long)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6), nw = (long long)gridDim.x * kRowsPerBlock;
+    f32x4 wc[NV][3], dwc[NV][3], bs[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int ch = 4 * (lane + 64 * i);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bs[i][q] = ch < c ? bias[ch + q] : 0.f;
+            for (int k = 0; k < 3; ++k) wc[i][k][q] = (ch < c && k < d) ? Wc[(size_t)(ch + q) * d + k] : 0.f, dwc[i][k][q] = 0.f;
+        }
+    }
+    for (long long row = wid; row < rows; row += nw) {
+        Row<NV> b, gi, dB;
+        b.load(AB + (size_t)row * ldab + c, c, lane);
+        gi.load(dagg + (size_t)row * ldg, c, lane);
+        const int e0 = rowptr[row], e1 = rowptr[row + 1];
+        const float inv = 1.0f / (float)(e1 > e0 ? e1 - e0 : 1);
+        float pi[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < d; ++k) pi[k] = pos[(size_t)row * d + k];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            b.v[i] += bs[i];
+            gi.v[i] *= inv;
+            dB.v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int e = e0; e < e1; ++e) {
+            const int j = src[e];
+            float dp[3] = {0.f, 0.f, 0.f};
+            for (int k = 0; k < d; ++k) dp[k] = pos[(size_t)j * d + k] - pi[k];
+            Row<NV> z, m;
+            z.load(AB + (size_t)j * ldab, c, lane);
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = z.v[i][q] + b.v[i][q];
+                    v = fmaf(wc[i][0][q], dp[0], v);
+                    v = fmaf(wc[i][1][q], dp[1], v);
+                    v = fmaf(wc[i][2][q], dp[2], v);
+                    const bool live = 4 * (lane + 64 * i) < c;
+                    z.v[i][q] = live ? v : 0.f;
+                    m.v[i][q] = live ? pc_gelu(v) : 0.f;
+                }
+            const float mean = m.sum() / (float)c;
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float dv = (4 * (lane + 64 * i) < c) ? m.v[i][q] - mean : 0.f;
+                    m.v[i][q] = dv;
+                    ss = fmaf(dv, dv, ss);
+                }
+            const float rstd = rsqrtf(wave_sum(ss) / (float)c + eps);
+            float gm = 0.f, gx = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    m.v[i][q] *= rstd;  // xhat
+                    gm += gi.v[i][q];
+                    gx = fmaf(gi.v[i][q], m.v[i][q], gx);
+                }
+            gm = wave_sum(gm) / (float)c;
+            gx = wave_sum(gx) / (float)c;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int ch = 4 * (lane + 64 * i);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float zz = z.v[i][q];
+                    const float dg = rstd * (gi.v[i][q] - gm - m.v[i][q] * gx);
+                    const float gp = 0.5f * (1.0f + erff(zz * 0.70710678118654752440f)) + zz * 0.3989422804014327f * expf(-0.5f * zz * zz);
+                    const float dz = ch < c ? dg * gp : 0.f;
+                    dB.v[i][q] += dz;
+                    dwc[i][0][q] = fmaf(dz, dp[0], dwc[i][0][q]);
+                    dwc[i][1][q] = fmaf(dz, dp[1], dwc[i][1][q]);
+                    dwc[i][2][q] = fmaf(dz, dp[2], dwc[i][2][q]);
+                    if (ch < c) atomicAdd(dAB + (size_t)j * ldd + ch + q, dz);
+                }
+            }
+        }
+        dB.store(dAB + (size_t)row * ldd + c, c, lane);
+    }
+    if (wid < nw) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int ch = 4 * (lane + 64 * i);
+            if (ch < c)
+                for (int q = 0; q < 4; ++q)
+                    for (int k = 0; k < 3; ++k) wc_part[((size_t)wid * c + ch + q) * 3 + k] = dwc[i][k][q];
+        }
+    }
+}
+
 // The same edge list through a uniform grid (cells of edge >= r, keyed by (cloud, cell); points sorted by key, so a cell
 // lists its points in index order): a centre only looks at the 3^d cells around its own and keeps the max_nbrs SMALLEST
 // neighbour indices -- which is what "the first max_nbrs in index order" selects.  O(N * neighbours) instead of O(N^2).
@@ -965,4 +1108,35 @@ extern "C" int haet_pc_ball_attention_bwd(const float* qkv, int ldq, const float
         default: go(ball_attention_bwd_kernel<64>); break;
     }
     return check_launch("ball_attention_bwd_kernel");
+}
+
+extern "C" int haet_pc_ln_bwd(const float* V, int ldv, const float* dU, int ldu, long long rows, int c, float eps, float* dV, int lddv,
+                              haet_stream_t stream) {
+    if (!V || !dU || !dV || rows < 1) return fail(HAET_E_ARG, "pc_ln_bwd: bad arguments");
+    PC_CHECK_WIDTH("pc_ln_bwd", c);
+    PC_DISPATCH(c, ln_bwd_kernel, row_grid(rows), dim3(256), 0, as_stream(stream), V, ldv, dU, ldu, rows, c, eps, dV, lddv);
+    return check_launch("ln_bwd_kernel");
+}
+
+/* wc_part: [haet_pc_mpnn_bwd_waves(rows)][c][3] floats (one row per persistent wave; the caller adds them);
+ * dAB [rows][ldd]: the A half (columns [0, c)) must be zero on entry (float atomics), the B half is written. */
+extern "C" int haet_pc_mpnn_bwd_waves(long long rows) {
+    const long long blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
+    return (int)((blocks < 2048 ? blocks : 2048) * kRowsPerBlock);
+}
+
+extern "C" int haet_pc_mpnn_message_bwd(const float* AB, int ldab, const float* pos, int d, const int32_t* rowptr, const int32_t* src,
+                                        const float* Wc, const float* bias, const float* dagg, int ldg, long long rows, int c, float eps,
+                                        float* dAB, int ldd, float* wc_part, haet_stream_t stream) {
+    if (!AB || !pos || !rowptr || !src || !Wc || !bias || !dagg || !dAB || !wc_part || rows < 1 || (d != 2 && d != 3))
+        return fail(HAET_E_ARG, "pc_mpnn_message_bwd: bad arguments");
+    if (!width_ok(c) || c > 512) return fail(HAET_E_ARG, "pc_mpnn_message_bwd: width %d (multiple of 4, <= 512)", c);
+    const dim3 grid((unsigned)(haet_pc_mpnn_bwd_waves(rows) / kRowsPerBlock));
+    if (c <= 256)
+        hipLaunchKernelGGL((mpnn_message_bwd_kernel<1>), grid, dim3(256), 0, as_stream(stream), AB, ldab, pos, d, rowptr, src, Wc, bias,
+                           dagg, ldg, rows, c, eps, dAB, ldd, wc_part);
+    else
+        hipLaunchKernelGGL((mpnn_message_bwd_kernel<2>), grid, dim3(256), 0, as_stream(stream), AB, ldab, pos, d, rowptr, src, Wc, bias,
+                           dagg, ldg, rows, c, eps, dAB, ldd, wc_part);
+    return check_launch("mpnn_message_bwd_kernel");
 }

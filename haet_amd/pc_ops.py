@@ -133,6 +133,26 @@ def ln_residual(u: Tensor, h: Tensor, h2: Optional[Tensor], c: int, eps: float =
                                   _stream()), "haet_pc_ln_residual")
 
 
+def ln_bwd(v: Tensor, dU: Tensor, c: int, eps: float = 1e-5) -> Tensor:
+    """Gradient of LayerNorm without affine w.r.t. its input v [rows, >= c], from dU [rows, >= c]."""
+    lib = _lib.load()
+    dV = torch.empty((v.shape[0], c), dtype=torch.float32, device=v.device)
+    check(lib.haet_pc_ln_bwd(_p(v), v.stride(0), _p(dU), dU.stride(0), v.shape[0], c, eps, _p(dV), c, _stream()), "haet_pc_ln_bwd")
+    return dV
+
+
+def mpnn_message_bwd(AB: Tensor, pos: Tensor, rowptr: Tensor, src: Tensor, Wc: Tensor, bias: Tensor, dagg: Tensor, c: int,
+                     eps: float = 1e-5):
+    """Backward of mpnn_message: (dAB [N, 2c] = [dA | dB], dWc [c, d]) from dagg [N, c] (any row stride)."""
+    lib = _lib.load()
+    N, d = pos.shape
+    dAB = torch.zeros((N, 2 * c), dtype=torch.float32, device=AB.device)
+    part = torch.empty((lib.haet_pc_mpnn_bwd_waves(N), c, 3), dtype=torch.float32, device=AB.device)
+    check(lib.haet_pc_mpnn_message_bwd(_p(AB), AB.stride(0), _p(pos), d, _p(rowptr), _p(src), _p(Wc), _p(bias), _p(dagg), dagg.stride(0),
+                                       N, c, eps, _p(dAB), 2 * c, _p(part), _stream()), "haet_pc_mpnn_message_bwd")
+    return dAB, part.sum(dim=0)[:, :d]
+
+
 # --------------------------------------------------------------------------- Erwin body stages
 def gather_rows(x: Tensor, idx: Tensor, c: int) -> Tensor:
     lib = _lib.load()

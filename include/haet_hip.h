@@ -478,6 +478,15 @@ int haet_pc_swiglu_bwd(const float* U, int ldu, const float* dH, int ldh, long l
 int haet_pc_ball_attention_bwd_supported(int c, int heads, int ball);
 int haet_pc_ball_attention_bwd(const float* qkv, int ldq, const float* dO, int ldo, long long rows, int c, int heads, int ball,
                                float* dqkv, int ldd, haet_stream_t stream);
+/* backward of an MPNN step: LayerNorm without affine (haet_pc_ln_bwd), and the per-edge message stage
+ * (haet_pc_mpnn_message_bwd: dAB [rows][2c] = [dA | dB] -- the A half zero on entry, senders are added with float atomics --
+ * and wc_part [haet_pc_mpnn_bwd_waves(rows)][c][3], the persistent waves' shares of d Wc, to be summed by the caller) */
+int haet_pc_ln_bwd(const float* V, int ldv, const float* dU, int ldu, long long rows, int c, float eps, float* dV, int lddv,
+                   haet_stream_t stream);
+int haet_pc_mpnn_bwd_waves(long long rows);
+int haet_pc_mpnn_message_bwd(const float* AB, int ldab, const float* pos, int d, const int32_t* rowptr, const int32_t* src,
+                             const float* Wc, const float* bias, const float* dagg, int ldg, long long rows, int c, float eps,
+                             float* dAB, int ldd, float* wc_part, haet_stream_t stream);
 /* nn.BatchNorm1d over rows (pooling.py:23,38,56,68): batch statistics (stats [2][c] = mean, biased variance; part
  * [haet_pc_bn_blocks(rows)][2][c] scratch; running statistics / num_batches_tracked updated when given), then apply */
 int haet_pc_bn_blocks(long long rows);

@@ -169,11 +169,12 @@ def test_standalone_forward_vs_reference(name, hip_device):
                 assert O.rel_l2(sd[k].cpu(), v) < 1e-5, k
 
 
-@pytest.mark.parametrize("name", ["two_clouds", "two_clouds_train", "planar_norot"])
+@pytest.mark.parametrize("name", ["two_clouds", "two_clouds_train", "planar_norot", "car_like"])
 def test_autograd_restatement_matches_hip_forward_and_oracle_gradients(name, hip_device):
     """With gradients recording, the transformer blocks run forward and backward on the HIP stages (ErwinBlockFunction)
-    and the rest as differentiable device ops on the HIP-built tree / graph: same output as the no-grad HIP forward,
-    gradients equal to the CPU oracle's autograd."""
+    and the rest as differentiable device ops on the HIP-built tree / graph (at widths that are multiples of 128 --
+    car_like -- the message-passing steps run on their HIP forward / backward too, MpnnStepFunction): same output as the
+    no-grad HIP forward, gradients equal to the CPU oracle's autograd."""
     f = G.load_ef(name)
     meta, kw = f["meta"], f["meta"]["kw"]
     m = _module(f, hip_device)
