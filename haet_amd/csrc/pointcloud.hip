@@ -188,10 +188,13 @@ __global__ __launch_bounds__(256) void ball_attention_kernel(const float* __rest
             float cm = mx;
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const float* kj = Ks + (size_t)(j0 + u < ball ? j0 + u : ball - 1) * c + h * HD;
+                const f32x4* kj = reinterpret_cast<const f32x4*>(Ks + (size_t)(j0 + u < ball ? j0 + u : ball - 1) * c + h * HD);
                 float s = 0.f;
 #pragma unroll
-                for (int e = 0; e < HD; ++e) s = fmaf(q[e], kj[e], s);
+                for (int e = 0; e < HD; e += 4) {
+                    const f32x4 k4 = kj[e / 4];  // (one 16-B LDS read per four channels; all lanes of a head read the same row)
+                    s = fmaf(q[e], k4[0], fmaf(q[e + 1], k4[1], fmaf(q[e + 2], k4[2], fmaf(q[e + 3], k4[3], s))));
+                }
                 sc[u] = j0 + u < ball ? s : -INFINITY;
                 cm = fmaxf(cm, sc[u]);
             }
@@ -202,10 +205,14 @@ __global__ __launch_bounds__(256) void ball_attention_kernel(const float* __rest
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const float pj = __builtin_amdgcn_exp2f(sc[u] - cm);
-                const float* vj = Vs + (size_t)(j0 + u < ball ? j0 + u : ball - 1) * c + h * HD;
+                const f32x4* vj = reinterpret_cast<const f32x4*>(Vs + (size_t)(j0 + u < ball ? j0 + u : ball - 1) * c + h * HD);
                 l += pj;
 #pragma unroll
-                for (int e = 0; e < HD; ++e) acc[e] = fmaf(pj, vj[e], acc[e]);
+                for (int e = 0; e < HD; e += 4) {
+                    const f32x4 v4 = vj[e / 4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[e + r] = fmaf(pj, v4[r], acc[e + r]);
+                }
             }
             mx = cm;
         }
@@ -570,6 +577,16 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const float* __restrict
 // Backward of the per-ball attention (flash-attention style: nothing but qkv is kept from the forward).  One workgroup
 // per ball; Q, K, V, dO of all heads in LDS.  Pass A, one (query, head) per thread: row statistics (max, sum), O_i,
 // D_i = dO_i . O_i and dQ_i.  Pass B, one (key, head) per thread: dK_j, dV_j over the queries with the stored statistics.
+// HD consecutive floats of a 16-B aligned LDS row as 16-B reads
+template <int HD>
+__device__ __forceinline__ void row_load(const float* p, float (&v)[HD]) {
+#pragma unroll
+    for (int e = 0; e < HD; e += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p + e);
+        v[e] = t[0], v[e + 1] = t[1], v[e + 2] = t[2], v[e + 3] = t[3];
+    }
+}
+
 template <int HD>
 __global__ __launch_bounds__(256) void ball_attention_bwd_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dO,
                                                                 int ldo, int c, int heads, int ball, float scale,
@@ -597,12 +614,13 @@ __global__ __launch_bounds__(256) void ball_attention_bwd_kernel(const float* __
         for (int e = 0; e < HD; ++e) q[e] = Qs[(size_t)i * cs + h * HD + e] * (scale * kL2e), go[e] = Gs[(size_t)i * cs + h * HD + e], acc[e] = 0.f;
         float mx = -INFINITY, l = 0.f;
         for (int j = 0; j < ball; ++j) {  // statistics and O_i
-            const float* kj = Ks + (size_t)j * cs + h * HD;
+            float kj[HD], vj[HD];
+            row_load<HD>(Ks + (size_t)j * cs + h * HD, kj);
+            row_load<HD>(Vs + (size_t)j * cs + h * HD, vj);
             float sc = 0.f;
 #pragma unroll
             for (int e = 0; e < HD; ++e) sc = fmaf(q[e], kj[e], sc);
             const float nm = fmaxf(mx, sc), corr = __builtin_amdgcn_exp2f(mx - nm), pj = __builtin_amdgcn_exp2f(sc - nm);
-            const float* vj = Vs + (size_t)j * cs + h * HD;
             l = fmaf(l, corr, pj);
 #pragma unroll
             for (int e = 0; e < HD; ++e) acc[e] = fmaf(acc[e], corr, pj * vj[e]);
@@ -619,8 +637,9 @@ __global__ __launch_bounds__(256) void ball_attention_bwd_kernel(const float* __
 #pragma unroll
         for (int e = 0; e < HD; ++e) dq[e] = 0.f;
         for (int j = 0; j < ball; ++j) {  // dQ_i = scale sum_j dS_ij K_j
-            const float* kj = Ks + (size_t)j * cs + h * HD;
-            const float* vj = Vs + (size_t)j * cs + h * HD;
+            float kj[HD], vj[HD];
+            row_load<HD>(Ks + (size_t)j * cs + h * HD, kj);
+            row_load<HD>(Vs + (size_t)j * cs + h * HD, vj);
             float sc = 0.f, dp = 0.f;
 #pragma unroll
             for (int e = 0; e < HD; ++e) sc = fmaf(q[e], kj[e], sc), dp = fmaf(go[e], vj[e], dp);
@@ -641,8 +660,9 @@ __global__ __launch_bounds__(256) void ball_attention_bwd_kernel(const float* __
 #pragma unroll
         for (int e = 0; e < HD; ++e) k[e] = Ks[(size_t)j * cs + h * HD + e], v[e] = Vs[(size_t)j * cs + h * HD + e], dk[e] = 0.f, dv[e] = 0.f;
         for (int i = 0; i < ball; ++i) {
-            const float* qi = Qs + (size_t)i * cs + h * HD;
-            const float* gi = Gs + (size_t)i * cs + h * HD;
+            float qi[HD], gi[HD];
+            row_load<HD>(Qs + (size_t)i * cs + h * HD, qi);
+            row_load<HD>(Gs + (size_t)i * cs + h * HD, gi);
             float sc = 0.f, dp = 0.f;
 #pragma unroll
             for (int e = 0; e < HD; ++e) sc = fmaf(qi[e], k[e], sc), dp = fmaf(gi[e], v[e], dp);
