@@ -298,3 +298,30 @@ def test_block_function_matches_torch_autograd(c, heads, ball, rotated, hip_devi
     print({k: f"{v:.1e}" for k, v in errs.items()})
     assert errs.pop("out") < 5e-5  # (split-bf16 GEMMs against fp32 library GEMMs; north_star: 1e-3)
     assert max(errs.values()) < 2e-4, errs
+
+
+def test_large_cloud_without_embedding_takes_the_streaming_path(hip_device):
+    """embed=False on clouds far beyond the one-launch token kernel (5000 and 3000 points, c = 32): ErwinTransformer
+    routes them to the point-cloud path; against the CPU oracle."""
+    from haet_amd.components.erwinflash import ErwinTransformer
+
+    torch.manual_seed(3)
+    kw = dict(c_in=32, c_hidden=[32, 64], ball_sizes=[64, 32], enc_num_heads=[2, 4], enc_depths=[2, 2], dec_num_heads=[2],
+              dec_depths=[2], strides=[2], rotate=45, decode=True, mlp_ratio=4, dimensionality=3, mp_steps=0, embed=False)
+    m = ErwinTransformer(**kw)
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if p_.dim() == 2:
+                p_.mul_(5.0)
+    g = torch.Generator().manual_seed(4)
+    sizes = [5000, 3000]
+    feat = torch.randn(sum(sizes), 32, generator=g)
+    pos = torch.rand(sum(sizes), 3, generator=g)
+    bidx = torch.cat([torch.full((s,), i, dtype=torch.long) for i, s in enumerate(sizes)])
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    cfg = G.ef_cfg(dict(kw=kw))
+    with torch.no_grad():
+        want = O.erwinflash_forward(feat, pos, bidx, sd, cfg, 0, embed=False)
+        got = m.to(hip_device).eval()(feat.to(hip_device), pos.to(hip_device), bidx.to(hip_device))
+    assert got.shape == want.shape
+    assert O.rel_l2(got.cpu(), want) < FP32_TOL
