@@ -52,6 +52,21 @@ struct Row {
     }
 };
 
+// sum over the 64 lanes of the wave, or (HALF) over the 32 lanes of this lane's half
+template <bool HALF>
+__device__ __forceinline__ float red_sum(float v) {
+#pragma unroll
+    for (int o = HALF ? 16 : 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int NV>
+__device__ __forceinline__ float row_partial(const f32x4 (&v)[NV]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    return s;
+}
+
 #define PC_ROW_PROLOGUE(ROWS)                                          \
     const int lane = threadIdx.x & 63;                                 \
     const long long row = (long long)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6); \
@@ -367,12 +382,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(float* __restrict__ X, in
 // NODE (AB = [A | B], one GEMM over N rows instead of one over E edges); this kernel finishes the message per edge --
 // GELU, LayerNorm without affine -- and averages the messages that END in node i (scatter_mean over edge_index[1]):
 // one wave per receiving node over its CSR segment, no atomics.
-template <int NV>
+// HALF (c <= 128: a row is 32 lanes x 16 B): the two halves of a wave take one receiving node each
+template <int NV, bool HALF = false>
 __global__ __launch_bounds__(256) void mpnn_message_kernel(const float* __restrict__ AB, int ldab, const float* __restrict__ pos, int d,
                                                           const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
                                                           const float* __restrict__ Wc /*[c][d]*/, const float* __restrict__ bias,
                                                           long long rows, int c, float eps, float* __restrict__ out, int ldo) {
-    PC_ROW_PROLOGUE(rows)
+    const int lane = HALF ? (threadIdx.x & 31) : (threadIdx.x & 63);
+    const long long wrow = (long long)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    const long long row = HALF ? 2 * wrow + ((threadIdx.x >> 5) & 1) : wrow;
+    if (row >= rows) return;
     Row<NV> b, acc;
     b.load(AB + (size_t)row * ldab + c, c, lane);
     f32x4 wc[NV][3];
@@ -405,7 +424,7 @@ __global__ __launch_bounds__(256) void mpnn_message_kernel(const float* __restri
                 v = fmaf(wc[i][2][q], dp[2], v);
                 m.v[i][q] = (4 * (lane + 64 * i) < c) ? pc_gelu(v) : 0.f;
             }
-        const float mean = m.sum() / (float)c;
+        const float mean = red_sum<HALF>(row_partial<NV>(m.v)) / (float)c;
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
@@ -415,7 +434,7 @@ __global__ __launch_bounds__(256) void mpnn_message_kernel(const float* __restri
                 m.v[i][q] = dv;
                 ss = fmaf(dv, dv, ss);
             }
-        const float rstd = rsqrtf(wave_sum(ss) / (float)c + eps);
+        const float rstd = rsqrtf(red_sum<HALF>(ss) / (float)c + eps);
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc.v[i] += m.v[i] * rstd;
     }
@@ -722,104 +741,111 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ V
 // recomputed), with dm_e = dagg_i / deg_i:  dz_e = gelu'(z_e) LN_bwd(dm_e);  dA[src_e] += dz_e (float atomics: a sender has
 // edges in many segments),  dB[i] = sum_e dz_e,  and this wave's share of dWc = sum_e dz_e (pos_src - pos_i)^T goes to
 // its own row of `wc_part` (persistent waves: the caller adds the rows).  d bias = sum_i dB[i].
-template <int NV>
+template <int NV, bool HALF = false>
 __global__ __launch_bounds__(256) void mpnn_message_bwd_kernel(const float* __restrict__ AB, int ldab, const float* __restrict__ pos, int d,
                                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
                                                               const float* __restrict__ Wc, const float* __restrict__ bias,
                                                               const float* __restrict__ dagg, int ldg, long long rows, int c, float eps,
                                                               float* __restrict__ dAB, int ldd, float* __restrict__ wc_part) {
-    const int lane = threadIdx.x & 63;
-    const long long wid = (long long)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6), nw = (long long)gridDim.x * kRowsPerBlock;
-    f32x4 wc[NV][3], dwc[NV][3], bs[NV];
+    constexpr int E = 4 * NV;  // channels per lane
+    const int lane = HALF ? (threadIdx.x & 31) : (threadIdx.x & 63);
+    const long long w0 = (long long)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6), nw0 = (long long)gridDim.x * kRowsPerBlock;
+    // (HALF: every half-wave is a worker of its own: one receiving node at a time each)
+    const long long wid = HALF ? 2 * w0 + ((threadIdx.x >> 5) & 1) : w0, nw = HALF ? 2 * nw0 : nw0;
+    // channel of element x of this lane.  HALF: lane + 32 x -- the 32 lanes of one atomic instruction then add to 128
+    // CONSECUTIVE bytes of the sender's row (with four consecutive channels per lane an instruction touches every fourth
+    // dword of 512 bytes, and the memory-side adders take a 64-B request for every 16 B of it)
+    auto chan = [&](int x) { return HALF ? lane + 32 * x : 4 * (lane + 64 * (x >> 2)) + (x & 3); };
+    auto load_row = [&](const float* p, float (&v)[E]) {
+        if (HALF) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int ch = 4 * (lane + 64 * i);
+            for (int x = 0; x < E; ++x) v[x] = chan(x) < c ? p[chan(x)] : 0.f;
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bs[i][q] = ch < c ? bias[ch + q] : 0.f;
-            for (int k = 0; k < 3; ++k) wc[i][k][q] = (ch < c && k < d) ? Wc[(size_t)(ch + q) * d + k] : 0.f, dwc[i][k][q] = 0.f;
+            for (int i = 0; i < NV; ++i) {
+                const int ch = 4 * (lane + 64 * i);
+                const f32x4 t = ch < c ? *reinterpret_cast<const f32x4*>(p + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[4 * i + q] = t[q];
+            }
         }
+    };
+    float wc[E][3], dwc[E][3], bs[E];
+#pragma unroll
+    for (int x = 0; x < E; ++x) {
+        const int ch = chan(x);
+        bs[x] = ch < c ? bias[ch] : 0.f;
+        for (int k = 0; k < 3; ++k) wc[x][k] = (ch < c && k < d) ? Wc[(size_t)ch * d + k] : 0.f, dwc[x][k] = 0.f;
     }
     for (long long row = wid; row < rows; row += nw) {
-        Row<NV> b, gi, dB;
-        b.load(AB + (size_t)row * ldab + c, c, lane);
-        gi.load(dagg + (size_t)row * ldg, c, lane);
+        float b[E], gi[E], dB[E];
+        load_row(AB + (size_t)row * ldab + c, b);
+        load_row(dagg + (size_t)row * ldg, gi);
         const int e0 = rowptr[row], e1 = rowptr[row + 1];
         const float inv = 1.0f / (float)(e1 > e0 ? e1 - e0 : 1);
         float pi[3] = {0.f, 0.f, 0.f};
         for (int k = 0; k < d; ++k) pi[k] = pos[(size_t)row * d + k];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            b.v[i] += bs[i];
-            gi.v[i] *= inv;
-            dB.v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int x = 0; x < E; ++x) b[x] += bs[x], gi[x] *= inv, dB[x] = 0.f;
         for (int e = e0; e < e1; ++e) {
             const int j = src[e];
             float dp[3] = {0.f, 0.f, 0.f};
             for (int k = 0; k < d; ++k) dp[k] = pos[(size_t)j * d + k] - pi[k];
-            Row<NV> z, m;
-            z.load(AB + (size_t)j * ldab, c, lane);
+            float z[E], m[E];
+            load_row(AB + (size_t)j * ldab, z);
+            float sum = 0.f;
 #pragma unroll
-            for (int i = 0; i < NV; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v = z.v[i][q] + b.v[i][q];
-                    v = fmaf(wc[i][0][q], dp[0], v);
-                    v = fmaf(wc[i][1][q], dp[1], v);
-                    v = fmaf(wc[i][2][q], dp[2], v);
-                    const bool live = 4 * (lane + 64 * i) < c;
-                    z.v[i][q] = live ? v : 0.f;
-                    m.v[i][q] = live ? pc_gelu(v) : 0.f;
-                }
-            const float mean = m.sum() / (float)c;
+            for (int x = 0; x < E; ++x) {
+                float v = z[x] + b[x];
+                v = fmaf(wc[x][0], dp[0], v);
+                v = fmaf(wc[x][1], dp[1], v);
+                v = fmaf(wc[x][2], dp[2], v);
+                const bool live = chan(x) < c;
+                z[x] = live ? v : 0.f;
+                m[x] = live ? pc_gelu(v) : 0.f;
+                sum += m[x];
+            }
+            const float mean = red_sum<HALF>(sum) / (float)c;
             float ss = 0.f;
 #pragma unroll
-            for (int i = 0; i < NV; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float dv = (4 * (lane + 64 * i) < c) ? m.v[i][q] - mean : 0.f;
-                    m.v[i][q] = dv;
-                    ss = fmaf(dv, dv, ss);
-                }
-            const float rstd = rsqrtf(wave_sum(ss) / (float)c + eps);
+            for (int x = 0; x < E; ++x) {
+                m[x] = chan(x) < c ? m[x] - mean : 0.f;
+                ss = fmaf(m[x], m[x], ss);
+            }
+            const float rstd = rsqrtf(red_sum<HALF>(ss) / (float)c + eps);
             float gm = 0.f, gx = 0.f;
 #pragma unroll
-            for (int i = 0; i < NV; ++i)
+            for (int x = 0; x < E; ++x) {
+                m[x] *= rstd;  // xhat
+                gm += gi[x];
+                gx = fmaf(gi[x], m[x], gx);
+            }
+            gm = red_sum<HALF>(gm) / (float)c;
+            gx = red_sum<HALF>(gx) / (float)c;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    m.v[i][q] *= rstd;  // xhat
-                    gm += gi.v[i][q];
-                    gx = fmaf(gi.v[i][q], m.v[i][q], gx);
-                }
-            gm = wave_sum(gm) / (float)c;
-            gx = wave_sum(gx) / (float)c;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int ch = 4 * (lane + 64 * i);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float zz = z.v[i][q];
-                    const float dg = rstd * (gi.v[i][q] - gm - m.v[i][q] * gx);
-                    const float gp = 0.5f * (1.0f + erff(zz * 0.70710678118654752440f)) + zz * 0.3989422804014327f * expf(-0.5f * zz * zz);
-                    const float dz = ch < c ? dg * gp : 0.f;
-                    dB.v[i][q] += dz;
-                    dwc[i][0][q] = fmaf(dz, dp[0], dwc[i][0][q]);
-                    dwc[i][1][q] = fmaf(dz, dp[1], dwc[i][1][q]);
-                    dwc[i][2][q] = fmaf(dz, dp[2], dwc[i][2][q]);
-                    if (ch < c) atomicAdd(dAB + (size_t)j * ldd + ch + q, dz);
-                }
+            for (int x = 0; x < E; ++x) {
+                const int ch = chan(x);
+                const float zz = z[x];
+                const float dg = rstd * (gi[x] - gm - m[x] * gx);
+                const float gp = 0.5f * (1.0f + erff(zz * 0.70710678118654752440f)) + zz * 0.3989422804014327f * expf(-0.5f * zz * zz);
+                const float dz = ch < c ? dg * gp : 0.f;
+                dB[x] += dz;
+                dwc[x][0] = fmaf(dz, dp[0], dwc[x][0]);
+                dwc[x][1] = fmaf(dz, dp[1], dwc[x][1]);
+                dwc[x][2] = fmaf(dz, dp[2], dwc[x][2]);
+                if (ch < c) atomicAdd(dAB + (size_t)j * ldd + ch, dz);
             }
         }
-        dB.store(dAB + (size_t)row * ldd + c, c, lane);
+#pragma unroll
+        for (int x = 0; x < E; ++x)
+            if (chan(x) < c) dAB[(size_t)row * ldd + c + chan(x)] = dB[x];
     }
     if (wid < nw) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int ch = 4 * (lane + 64 * i);
+        for (int x = 0; x < E; ++x) {
+            const int ch = chan(x);
             if (ch < c)
-                for (int q = 0; q < 4; ++q)
-                    for (int k = 0; k < 3; ++k) wc_part[((size_t)wid * c + ch + q) * 3 + k] = dwc[i][k][q];
+                for (int k = 0; k < 3; ++k) wc_part[((size_t)wid * c + ch) * 3 + k] = dwc[x][k];
         }
     }
 }
@@ -1026,6 +1052,11 @@ extern "C" int haet_pc_mpnn_message(const float* AB, int ldab, const float* pos,
     if (!AB || !pos || !rowptr || !src || !Wc || !bias || !out || rows < 1 || (d != 2 && d != 3))
         return fail(HAET_E_ARG, "pc_mpnn_message: bad arguments");
     PC_CHECK_WIDTH("pc_mpnn_message", c);
+    if (c <= 128) {
+        hipLaunchKernelGGL((mpnn_message_kernel<1, true>), row_grid((rows + 1) / 2), dim3(256), 0, as_stream(stream), AB, ldab, pos, d,
+                           rowptr, src, Wc, bias, rows, c, eps, out, ldo);
+        return check_launch("mpnn_message_kernel<half>");
+    }
     PC_DISPATCH(c, mpnn_message_kernel, row_grid(rows), dim3(256), 0, as_stream(stream), AB, ldab, pos, d, rowptr, src, Wc, bias, rows,
                 c, eps, out, ldo);
     return check_launch("mpnn_message_kernel");
@@ -1140,10 +1171,12 @@ extern "C" int haet_pc_ln_bwd(const float* V, int ldv, const float* dU, int ldu,
 
 /* wc_part: [haet_pc_mpnn_bwd_waves(rows)][c][3] floats (one row per persistent wave; the caller adds them);
  * dAB [rows][ldd]: the A half (columns [0, c)) must be zero on entry (float atomics), the B half is written. */
-extern "C" int haet_pc_mpnn_bwd_waves(long long rows) {
+static int mpnn_bwd_blocks(long long rows) {
     const long long blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
-    return (int)((blocks < 2048 ? blocks : 2048) * kRowsPerBlock);
+    return (int)(blocks < 2048 ? blocks : 2048);
 }
+/* rows of wc_part (zero-initialised by the caller: the half-wave variant fills all of them, the others the first half) */
+extern "C" int haet_pc_mpnn_bwd_waves(long long rows) { return 2 * mpnn_bwd_blocks(rows) * kRowsPerBlock; }
 
 extern "C" int haet_pc_mpnn_message_bwd(const float* AB, int ldab, const float* pos, int d, const int32_t* rowptr, const int32_t* src,
                                         const float* Wc, const float* bias, const float* dagg, int ldg, long long rows, int c, float eps,
@@ -1151,8 +1184,11 @@ extern "C" int haet_pc_mpnn_message_bwd(const float* AB, int ldab, const float* 
     if (!AB || !pos || !rowptr || !src || !Wc || !bias || !dagg || !dAB || !wc_part || rows < 1 || (d != 2 && d != 3))
         return fail(HAET_E_ARG, "pc_mpnn_message_bwd: bad arguments");
     if (!width_ok(c) || c > 512) return fail(HAET_E_ARG, "pc_mpnn_message_bwd: width %d (multiple of 4, <= 512)", c);
-    const dim3 grid((unsigned)(haet_pc_mpnn_bwd_waves(rows) / kRowsPerBlock));
-    if (c <= 256)
+    const dim3 grid((unsigned)mpnn_bwd_blocks(rows));
+    if (c <= 128)
+        hipLaunchKernelGGL((mpnn_message_bwd_kernel<1, true>), grid, dim3(256), 0, as_stream(stream), AB, ldab, pos, d, rowptr, src, Wc,
+                           bias, dagg, ldg, rows, c, eps, dAB, ldd, wc_part);
+    else if (c <= 256)
         hipLaunchKernelGGL((mpnn_message_bwd_kernel<1>), grid, dim3(256), 0, as_stream(stream), AB, ldab, pos, d, rowptr, src, Wc, bias,
                            dagg, ldg, rows, c, eps, dAB, ldd, wc_part);
     else

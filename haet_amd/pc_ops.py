@@ -147,7 +147,7 @@ def mpnn_message_bwd(AB: Tensor, pos: Tensor, rowptr: Tensor, src: Tensor, Wc: T
     lib = _lib.load()
     N, d = pos.shape
     dAB = torch.zeros((N, 2 * c), dtype=torch.float32, device=AB.device)
-    part = torch.empty((lib.haet_pc_mpnn_bwd_waves(N), c, 3), dtype=torch.float32, device=AB.device)
+    part = torch.zeros((lib.haet_pc_mpnn_bwd_waves(N), c, 3), dtype=torch.float32, device=AB.device)
     check(lib.haet_pc_mpnn_message_bwd(_p(AB), AB.stride(0), _p(pos), d, _p(rowptr), _p(src), _p(Wc), _p(bias), _p(dagg), dagg.stride(0),
                                        N, c, eps, _p(dAB), 2 * c, _p(part), _stream()), "haet_pc_mpnn_message_bwd")
     return dAB, part.sum(dim=0)[:, :d]
