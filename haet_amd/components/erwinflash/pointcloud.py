@@ -268,7 +268,9 @@ class ErwinBlockFunction(torch.autograd.Function):
         Xs = X1.index_select(0, perm.long()) if perm is not None else X1
         xh1 = Xs * torch.rsqrt(Xs.pow(2).mean(-1, keepdim=True) + torch.finfo(torch.float32).eps)
         d1 = dY1[:, :c]
-        g_norm1, g_pew, g_peb = (d1 * xh1).sum(0), d1.t() @ rel, d1.sum(0)
+        # (d columns of [c, n] @ [n, d]: three fused multiply-reduce passes; the library GEMM for this shape takes 0.65 ms)
+        g_pew = torch.stack([(d1 * rel[:, k:k + 1]).sum(0) for k in range(rel.shape[1])], dim=1)
+        g_norm1, g_peb = (d1 * xh1).sum(0), d1.sum(0)
         return (dX, None, None, None, None, g_norm1, g_pew, g_peb, g_wq, g_bq, g_wp, g_bp, g_norm2,
                 g_w12[:hid], g_b12[:hid], g_w12[hid:2 * hid], g_b12[hid:2 * hid], g_w3, g_b3)
 
