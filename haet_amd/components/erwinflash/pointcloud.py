@@ -58,6 +58,9 @@ class _Weights:
                     # the same matrices transposed: input gradients of the Linears (training)
                     qkvT=P(a.qkv.weight.t(), None), projT=P(a.proj.weight.t(), None), w12T=P(w12.t(), None),
                     w3T=P(s.w3.weight.t(), None),
+                    # forward only: w1 | w2 with the SwiGLU gate in the GEMM's epilogue (the [rows, 2 hid] tensor never exists)
+                    glu=(pc_ops.SwigluLinear(s.w1.weight, s.w1.bias, s.w2.weight, s.w2.bias)
+                         if pc_ops.SwigluLinear.supported(s.w1.weight.shape[1], s.w1.weight.shape[0], 64) else None),
                     norm1=blk.norm1.weight.detach().float().contiguous(), norm2=blk.norm2.weight.detach().float().contiguous(),
                     pe_w=a.pe_proj.weight.detach().float().contiguous(), pe_b=a.pe_proj.bias.detach().float().contiguous())
             for name in ("pool", "unpool"):
@@ -150,7 +153,7 @@ def _block(X: Tensor, P: Tensor, perm: Optional[Tensor], blk, w: dict, d: int):
     A = pc_ops.ball_attention(w["qkv"](Y), c, heads, ball)
     pc_ops.rows_add(X, perm, w["proj"](A), c)
     Y = pc_ops.rms_pe(X, None, None, w["norm2"], None, None, c)
-    H = pc_ops.swiglu(w["w12"](Y), w["w3"].K)
+    H = w["glu"](Y) if (w["glu"] is not None and X.shape[0] >= 64) else pc_ops.swiglu(w["w12"](Y), w["w3"].K)
     pc_ops.rows_add(X, None, w["w3"](H), c)
 
 

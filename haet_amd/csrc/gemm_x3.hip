@@ -493,7 +493,16 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(
             v[m] = up ? recv : v[m];
             v[m + 2] = up ? v[m + 2] : recv;
         }
-        if (!SPLIT) {
+        if (!SPLIT && ACT == 2) {
+            // SwiGLU gate in the epilogue (components/mlp.py:17-18): the weight rows arrive INTERLEAVED (row 2j = w1[j],
+            // row 2j + 1 = w2[j]), so this lane's four consecutive columns are (u1, u2) of two hidden units and the
+            // output H [rows][O / 2] = u2 * silu(u1) is written instead of U: the [rows][2 hid] tensor never exists
+            const float a0 = __int_as_float(v[0]), b0 = __int_as_float(v[1]), a1 = __int_as_float(v[2]), b1 = __int_as_float(v[3]);
+            const f32x2 h2 = {b0 * a0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * a0)),
+                              b1 * a1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * a1))};
+            char* const hb = reinterpret_cast<char*>(out) + row0 * ((long long)O * 2);
+            *reinterpret_cast<f32x2*>(hb + (o_voff >> 1) + (unsigned)((32 * i + 8 * g) * O * 2)) = h2;
+        } else if (!SPLIT) {
             f32x4 o4 = {__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])};
             if (ACT) {
 #pragma unroll
@@ -711,6 +720,28 @@ extern "C" int haet_linear_fwd(const float* x, const uint16_t* W_hi, const uint1
 extern "C" int haet_linear_act_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
                                    int Nrows, int K, int O, int act, float* out, haet_stream_t stream) {
     return linear_fwd_impl(x, W_hi, W_lo, bias, Nrows, K, O, act, out, stream);
+}
+
+// SwiGLU pair (w1 | w2 interleaved row by row, see the kernel's ACT == 2 epilogue): H [Nrows][O / 2] = (x w2^T + b2) silu(x w1^T + b1)
+extern "C" int haet_linear_swiglu_supported(int K, int O, int Nrows) { return haet_project_split_supported(K, O, Nrows); }
+
+extern "C" int haet_linear_swiglu_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias, int Nrows,
+                                      int K, int O, float* H, haet_stream_t stream) {
+    if (!x || !W_hi || !W_lo || !H || Nrows < 1) return fail(HAET_E_ARG, "linear_swiglu_fwd: bad arguments");
+    if (!haet_linear_swiglu_supported(K, O, Nrows))
+        return fail(HAET_E_ARG, "linear_swiglu_fwd: K=%d O=%d rows=%d outside the W-stationary kernel", K, O, Nrows);
+    const int tiles = (Nrows + 63) / 64, ny = O / 256;
+    const int gx = tiles < 256 / ny ? tiles : (256 / ny > 0 ? 256 / ny : 1);
+    const size_t lds = (size_t)2 * 2 * (K / GBK) * WS_IMGP;
+    auto go = [&](auto kern) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi, W_lo, bias, Nrows, O, tiles, H,
+                           SplitArgs{nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, 0.f});
+    };
+    if (K == 256) go(gemm_ws_kernel<8, 4, false, 2>);
+    else go(gemm_ws_kernel<4, 4, false, 2>);
+    return check_launch("gemm_ws_kernel<swiglu>");
 }
 
 // LayerNorm(K) fused into the loader of the W-stationary kernel (same envelope as haet_project_split_fwd)

@@ -280,6 +280,28 @@ def batch_norm_(X: Tensor, c: int, bn: torch.nn.BatchNorm1d, training: bool):
                                _stream()), "haet_pc_bn_apply")
 
 
+class SwigluLinear:
+    """w1 | w2 of a SwiGLU as ONE GEMM with the gate in its epilogue (haet_linear_swiglu_fwd): rows interleaved."""
+
+    def __init__(self, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor):
+        hid, K = w1.shape
+        self.hid, self.K = hid, K
+        W = torch.stack([w1.detach(), w2.detach()], dim=1).reshape(2 * hid, K)
+        b = torch.stack([b1.detach(), b2.detach()], dim=1).reshape(2 * hid)
+        self.w = SplitLinear(W, b)
+
+    @staticmethod
+    def supported(K: int, hid: int, rows: int) -> bool:
+        return bool(_lib.load().haet_linear_swiglu_supported(int(K), int(2 * hid), int(rows)))
+
+    def __call__(self, x: Tensor) -> Tensor:
+        lib = _lib.load()
+        H = torch.empty((x.shape[0], self.hid), dtype=torch.float32, device=x.device)
+        check(lib.haet_linear_swiglu_fwd(_p(x), _p(self.w.hi), _p(self.w.lo), _p(self.w.bias), x.shape[0], self.K, 2 * self.hid, _p(H),
+                                         _stream()), "haet_linear_swiglu_fwd")
+        return H
+
+
 class PaddedLinear:
     """A Linear [O, K] for the split-bf16 GEMM (haet_linear_fwd: K % 32 = 0, O % 128 = 0): zero-padded to that envelope
     once per weight version; inputs carry Kp columns (zeros past K), outputs Op columns (zeros past O)."""
