@@ -108,7 +108,7 @@ SIGNATURES = {
     "haet_project_split_ln_fwd": (c_int, [_P, _P, _P, c_float, _P, _P, _P, _P, c_float, c_float, c_int, c_int, c_int,
                                           _P, _P, _P]),
     "haet_linear_swiglu_supported": (c_int, [c_int, c_int, c_int]),
-    "haet_linear_swiglu_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    "haet_linear_swiglu_fwd": (c_int, [_P, _P, c_float, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
     "haet_layernorm_supported": (c_int, [c_int]),
     "haet_layernorm_fwd": (c_int, [_P, _P, _P, c_float, c_int, c_int, _P, _P]),
     "haet_add_layernorm_fwd": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P]),

@@ -152,8 +152,11 @@ def _block(X: Tensor, P: Tensor, perm: Optional[Tensor], blk, w: dict, d: int):
     Y = pc_ops.rms_pe(X, perm, rel, w["norm1"], w["pe_w"], w["pe_b"], c)
     A = pc_ops.ball_attention(w["qkv"](Y), c, heads, ball)
     pc_ops.rows_add(X, perm, w["proj"](A), c)
-    Y = pc_ops.rms_pe(X, None, None, w["norm2"], None, None, c)
-    H = w["glu"](Y) if (w["glu"] is not None and X.shape[0] >= 64) else pc_ops.swiglu(w["w12"](Y), w["w3"].K)
+    if w["glu"] is not None and X.shape[0] >= 64:  # RMSNorm in the GEMM's loader, SwiGLU gate in its epilogue
+        H = w["glu"](X, w["norm2"])
+    else:
+        Y = pc_ops.rms_pe(X, None, None, w["norm2"], None, None, c)
+        H = pc_ops.swiglu(w["w12"](Y), w["w3"].K)
     pc_ops.rows_add(X, None, w["w3"](H), c)
 
 

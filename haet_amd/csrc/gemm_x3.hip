@@ -374,7 +374,7 @@ struct SplitArgs {
     const float* ln_b;
     float ln_eps;
 };
-template <int NKT, int S, bool SPLIT = false, int ACT = 0, bool LNORM = false>
+template <int NKT, int S, bool SPLIT = false, int ACT = 0, int LNORM = 0>  // LNORM: 0 none, 1 LayerNorm, 2 RMSNorm (weight only)
 __global__ __launch_bounds__(512) void gemm_ws_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ Whi,
     const unsigned short* __restrict__ Wlo, const float* __restrict__ bias, int Nrows, int O,
@@ -425,11 +425,19 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(
     f32x4 lng = {1.f, 1.f, 1.f, 1.f}, lnb = {0.f, 0.f, 0.f, 0.f};
     if (LNORM) {
         lng = *reinterpret_cast<const f32x4*>(sa.ln_g + 4 * lcol);
-        lnb = *reinterpret_cast<const f32x4*>(sa.ln_b + 4 * lcol);
+        if (LNORM == 1) lnb = *reinterpret_cast<const f32x4*>(sa.ln_b + 4 * lcol);
     }
     auto stage = [&](int tbuf, int j, const f32x4 vin) {
         f32x4 v = vin;
-        if (LNORM) {  // two-pass statistics over the LPR lanes that hold this row (torch's numerics)
+        if (LNORM == 2) {  // nn.RMSNorm(K) (eps = sa.ln_eps): x * rsqrt(mean(x^2) + eps) * g
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q = fmaf(v[e], v[e], q);
+            const float rstd = rsqrtf(row_lanes_sum<LPR>(q, hf) * (1.0f / K) + sa.ln_eps);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * rstd * lng[e];
+        }
+        if (LNORM == 1) {  // two-pass statistics over the LPR lanes that hold this row (torch's numerics)
             static_assert(!LNORM || LPR == 64 || LPR == 32, "one or two rows per wave load");
             const float mean = row_lanes_sum<LPR>((v[0] + v[1]) + (v[2] + v[3]), hf) * (1.0f / K);
             float q = 0.f;
@@ -725,8 +733,8 @@ extern "C" int haet_linear_act_fwd(const float* x, const uint16_t* W_hi, const u
 // SwiGLU pair (w1 | w2 interleaved row by row, see the kernel's ACT == 2 epilogue): H [Nrows][O / 2] = (x w2^T + b2) silu(x w1^T + b1)
 extern "C" int haet_linear_swiglu_supported(int K, int O, int Nrows) { return haet_project_split_supported(K, O, Nrows); }
 
-extern "C" int haet_linear_swiglu_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias, int Nrows,
-                                      int K, int O, float* H, haet_stream_t stream) {
+extern "C" int haet_linear_swiglu_fwd(const float* x, const float* rms_w, float rms_eps, const uint16_t* W_hi, const uint16_t* W_lo,
+                                      const float* bias, int Nrows, int K, int O, float* H, haet_stream_t stream) {
     if (!x || !W_hi || !W_lo || !H || Nrows < 1) return fail(HAET_E_ARG, "linear_swiglu_fwd: bad arguments");
     if (!haet_linear_swiglu_supported(K, O, Nrows))
         return fail(HAET_E_ARG, "linear_swiglu_fwd: K=%d O=%d rows=%d outside the W-stationary kernel", K, O, Nrows);
@@ -737,10 +745,15 @@ extern "C" int haet_linear_swiglu_fwd(const float* x, const uint16_t* W_hi, cons
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi, W_lo, bias, Nrows, O, tiles, H,
-                           SplitArgs{nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, 0.f});
+                           SplitArgs{nullptr, 0.f, 0.f, nullptr, rms_w, nullptr, rms_eps});
     };
-    if (K == 256) go(gemm_ws_kernel<8, 4, false, 2>);
-    else go(gemm_ws_kernel<4, 4, false, 2>);
+    if (rms_w) {  // nn.RMSNorm(K) of the rows in the loader: the normalised rows never exist in HBM
+        if (K == 256) go(gemm_ws_kernel<8, 4, false, 2, 2>);
+        else go(gemm_ws_kernel<4, 4, false, 2, 2>);
+    } else {
+        if (K == 256) go(gemm_ws_kernel<8, 4, false, 2>);
+        else go(gemm_ws_kernel<4, 4, false, 2>);
+    }
     return check_launch("gemm_ws_kernel<swiglu>");
 }
 

@@ -294,11 +294,12 @@ class SwigluLinear:
     def supported(K: int, hid: int, rows: int) -> bool:
         return bool(_lib.load().haet_linear_swiglu_supported(int(K), int(2 * hid), int(rows)))
 
-    def __call__(self, x: Tensor) -> Tensor:
+    def __call__(self, x: Tensor, rms_weight: Optional[Tensor] = None) -> Tensor:
+        """rms_weight: nn.RMSNorm(K) (eps = machine epsilon, layers.py:25-26) is applied to x's rows inside the GEMM's loader."""
         lib = _lib.load()
         H = torch.empty((x.shape[0], self.hid), dtype=torch.float32, device=x.device)
-        check(lib.haet_linear_swiglu_fwd(_p(x), _p(self.w.hi), _p(self.w.lo), _p(self.w.bias), x.shape[0], self.K, 2 * self.hid, _p(H),
-                                         _stream()), "haet_linear_swiglu_fwd")
+        check(lib.haet_linear_swiglu_fwd(_p(x), _p(rms_weight), 1.1920928955078125e-07, _p(self.w.hi), _p(self.w.lo), _p(self.w.bias),
+                                         x.shape[0], self.K, 2 * self.hid, _p(H), _stream()), "haet_linear_swiglu_fwd")
         return H
 
 

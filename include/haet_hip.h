@@ -375,8 +375,9 @@ int haet_project_split_ln_fwd(const float* x, const float* ln_gamma, const float
 /* SwiGLU pair in one GEMM (components/mlp.py:17-18): W rows INTERLEAVED (row 2j = w1[j], row 2j + 1 = w2[j]; bias
  * likewise), H [Nrows][O / 2] = (x w2^T + b2) * silu(x w1^T + b1); the envelope of haet_project_split_supported.     */
 int haet_linear_swiglu_supported(int K, int O, int Nrows);
-int haet_linear_swiglu_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias, int Nrows,
-                           int K, int O, float* H, haet_stream_t stream);
+/* rms_w != NULL: nn.RMSNorm(K, eps = rms_eps) with that weight is applied to the rows of x in the loader (layers.py:31) */
+int haet_linear_swiglu_fwd(const float* x, const float* rms_w, float rms_eps, const uint16_t* W_hi, const uint16_t* W_lo,
+                           const float* bias, int Nrows, int K, int O, float* H, haet_stream_t stream);
 int haet_layernorm_supported(int D);
 int haet_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int rows, int D,
                        float* out, haet_stream_t stream);
