@@ -91,7 +91,13 @@ def _weights(erwin) -> _Weights:
 
 def cloud_sizes(batch_idx: Tensor) -> List[int]:
     """Points per cloud (batch_idx is sorted, contiguous from 0 like balltree.pyx:459-470 requires); one host read."""
-    return torch.bincount(batch_idx.to(torch.long)).tolist()
+    b = batch_idx.to(torch.long)
+    if b.numel() > 1 and not bool((b[1:] >= b[:-1]).all()):
+        raise HaetError("batch_idx must be sorted (the points of a cloud contiguous), as the reference's tree builder requires")
+    sizes = torch.bincount(b).tolist()
+    if sizes and min(sizes) < 2:
+        raise HaetError(f"every cloud needs at least 2 points (cloud sizes {sizes[:8]}...)")
+    return sizes
 
 
 def build_graph(erwin, pos: Tensor, batch_idx: Tensor, sizes, edge_index: Optional[Tensor], radius: Optional[float]):

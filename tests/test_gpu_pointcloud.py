@@ -238,6 +238,10 @@ def test_encoder_only_and_argument_errors(hip_device):
     assert O.rel_l2(x.cpu(), want) < FP32_TOL
     tree_idx = f["exp"]["tree_idx"]
     assert torch.equal(b.cpu(), f["batch_idx"][tree_idx][::kw["strides"][0]])
+    from haet_amd._lib import HaetError
+
+    with pytest.raises(HaetError):
+        m(feat, pos, bidx.flip(0), radius=0.2)  # clouds not contiguous
     with pytest.raises(AssertionError):
         m(feat, pos, bidx)  # mp_steps > 0 and neither edge_index nor radius
     with pytest.raises(NotImplementedError):
