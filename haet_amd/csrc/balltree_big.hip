@@ -188,17 +188,41 @@ __global__ __launch_bounds__(kTopThreads) void big_top_kernel(
         const bool cached = chunk <= 64 * 64;
         unsigned long long fl = 0ull, fr = 0ull;
         int nl = 0, nr = 0;
-        {
+        if (INLDS) {
             int step = 0;
             for (int p0 = c0; p0 < c1; p0 += 64, ++step) {
                 const int p = p0 + lane;
-                const float x = p < c1 ? (INLDS ? KD[p == med_pos ? front_old : W[p]] : (p == med_pos ? front_key : KP[p])) : 0.f;
+                const float x = p < c1 ? KD[p == med_pos ? front_old : W[p]] : 0.f;
                 const bool isl = p < c1 && !(x < v), isr = p < c1 && !(v < x);
                 nl += __popcll(__ballot(isl));
                 nr += __popcll(__ballot(isr));
                 if (cached) {
                     fl |= (unsigned long long)isl << step;
                     fr |= (unsigned long long)isr << step;
+                }
+            }
+        } else {
+            // global tier: eight 64-position steps per trip, their loads issued together (a wave of a 2M-item node walks
+            // 2048 steps per sweep: one memory round trip per step is what a level launch cost there)
+            int step = 0;
+            for (int p0 = c0; p0 < c1; p0 += 8 * 64, step += 8) {
+                float xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int p = p0 + 64 * u + lane;
+                    xv[u] = KP[p < c1 ? p : c0];
+                    if (p == med_pos) xv[u] = front_key;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int p = p0 + 64 * u + lane;
+                    const bool isl = p < c1 && !(xv[u] < v), isr = p < c1 && !(v < xv[u]);
+                    nl += __popcll(__ballot(isl));
+                    nr += __popcll(__ballot(isr));
+                    if (cached) {
+                        fl |= (unsigned long long)isl << (step + u);
+                        fr |= (unsigned long long)isr << (step + u);
+                    }
                 }
             }
         }
@@ -230,7 +254,7 @@ __global__ __launch_bounds__(kTopThreads) void big_top_kernel(
                     const float x = p < c1 ? (INLDS ? KD[p == med_pos ? front_old : W[p]] : (p == med_pos ? front_key : KP[p])) : 0.f;
                     isl = p < c1 && !(x < v);
                     isr = p < c1 && !(v < x);
-                }
+                }  // (nodes above 64k items only: the flags of pass 1 did not fit the two register words)
                 const unsigned long long ml = __ballot(isl), mr = __ballot(isr);
                 const unsigned long long below = (1ull << lane) - 1ull;
                 if (isl) ls[bl + __popcll(ml & below)] = p;
@@ -243,7 +267,21 @@ __global__ __launch_bounds__(kTopThreads) void big_top_kernel(
         __syncthreads();
         const int kmax = min(nL, nR + 1);
         int kc = 0;
-        for (int k = tid; k < kmax; k += kTopThreads) kc += ls[k] < rs[k] ? 1 : 0;
+        if (INLDS) {
+            for (int k = tid; k < kmax; k += kTopThreads) kc += ls[k] < rs[k] ? 1 : 0;
+        } else {
+            for (int k0 = tid; k0 < kmax; k0 += 4 * kTopThreads) {
+                int a4[4], b4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + u * kTopThreads;
+                    a4[u] = ls[k < kmax ? k : 0];
+                    b4[u] = rs[k < kmax ? k : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kc += (k0 + u * kTopThreads < kmax && a4[u] < b4[u]) ? 1 : 0;
+            }
+        }
         kc = (int)wave_sum((float)kc);  // (< 2^24 per wave: exact)
         if (lane == 0) sh_k[wave] = kc;
         __syncthreads();
@@ -258,15 +296,28 @@ __global__ __launch_bounds__(kTopThreads) void big_top_kernel(
                 cut = Lk < bound ? Lk : bound;
             }
         }
-        for (int k = tid; k < K; k += kTopThreads) {
-            const int a = ls[k], b = rs[k];
-            const int t = W[a];
-            W[a] = W[b];
-            W[b] = t;
-            if (!INLDS) {
-                const float tk = KP[a];
-                KP[a] = KP[b];
-                KP[b] = tk;
+        if (INLDS) {
+            for (int k = tid; k < K; k += kTopThreads) {
+                const int a = ls[k], b = rs[k];
+                const int t = W[a];
+                W[a] = W[b];
+                W[b] = t;
+            }
+        } else {
+            for (int k0 = tid; k0 < K; k0 += 4 * kTopThreads) {
+                int a4[4], b4[4], wa[4], wb[4];
+                float ka4[4], kb4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + u * kTopThreads;
+                    a4[u] = ls[k < K ? k : 0];
+                    b4[u] = rs[k < K ? k : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wa[u] = W[a4[u]], wb[u] = W[b4[u]], ka4[u] = KP[a4[u]], kb4[u] = KP[b4[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (k0 + u * kTopThreads < K) W[a4[u]] = wb[u], W[b4[u]] = wa[u], KP[a4[u]] = kb4[u], KP[b4[u]] = ka4[u];
             }
         }
         __syncthreads();
