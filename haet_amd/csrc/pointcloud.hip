@@ -174,20 +174,21 @@ __global__ __launch_bounds__(256) void rms_pe_kernel(const float* __restrict__ X
 // softmax(Q K^T / sqrt(hd)) V inside every ball, per head (attention.py:63-91; flash_attn_qkvpacked_func's contract).
 // One workgroup per ball: K and V of all heads in LDS, one (query, head) pair per thread at a time, online softmax.
 extern __shared__ __attribute__((aligned(16))) float pc_lds[];
+constexpr int kAttThreads = 512;  // one (query, head) pair per thread at ball 64 x 8 heads; the ball's K / V in LDS bound the workgroups per CU
 template <int HD>
-__global__ __launch_bounds__(256) void ball_attention_kernel(const float* __restrict__ qkv, int ldq, int c, int heads, int ball,
+__global__ __launch_bounds__(kAttThreads) void ball_attention_kernel(const float* __restrict__ qkv, int ldq, int c, int heads, int ball,
                                                             float scale, float* __restrict__ out, int ldo) {
     float* const Ks = pc_lds;
     float* const Vs = pc_lds + (size_t)ball * c;
     const size_t r0 = (size_t)blockIdx.x * ball;
-    for (int i = threadIdx.x; i < ball * (c / 4); i += 256) {
+    for (int i = threadIdx.x; i < ball * (c / 4); i += kAttThreads) {
         const int j = i / (c / 4), ch = 4 * (i % (c / 4));
         *reinterpret_cast<f32x4*>(Ks + (size_t)j * c + ch) = *reinterpret_cast<const f32x4*>(qkv + (r0 + j) * ldq + c + ch);
         *reinterpret_cast<f32x4*>(Vs + (size_t)j * c + ch) = *reinterpret_cast<const f32x4*>(qkv + (r0 + j) * ldq + 2 * c + ch);
     }
     __syncthreads();
     constexpr float kL2e = 1.4426950408889634f;
-    for (int t = threadIdx.x; t < ball * heads; t += 256) {
+    for (int t = threadIdx.x; t < ball * heads; t += kAttThreads) {
         const int h = t / ball, i = t % ball;
         float q[HD], acc[HD];
 #pragma unroll
@@ -607,7 +608,7 @@ __device__ __forceinline__ void row_load(const float* p, float (&v)[HD]) {
 }
 
 template <int HD>
-__global__ __launch_bounds__(256) void ball_attention_bwd_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dO,
+__global__ __launch_bounds__(kAttThreads) void ball_attention_bwd_kernel(const float* __restrict__ qkv, int ldq, const float* __restrict__ dO,
                                                                 int ldo, int c, int heads, int ball, float scale,
                                                                 float* __restrict__ dqkv, int ldd) {
     const int cs = c + 4;  // LDS row stride: lanes of a wave read DIFFERENT rows at the same channel
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(256) void ball_attention_bwd_kernel(const float* __
     float* const Gs = Vs + (size_t)ball * cs;           // dO
     float* const st = Gs + (size_t)ball * cs;           // [heads][ball][3]: max, 1 / sum, D
     const size_t r0 = (size_t)blockIdx.x * ball;
-    for (int i = threadIdx.x; i < ball * (c / 4); i += 256) {
+    for (int i = threadIdx.x; i < ball * (c / 4); i += kAttThreads) {
         const int j = i / (c / 4), ch = 4 * (i % (c / 4));
         *reinterpret_cast<f32x4*>(Qs + (size_t)j * cs + ch) = *reinterpret_cast<const f32x4*>(qkv + (r0 + j) * ldq + ch);
         *reinterpret_cast<f32x4*>(Ks + (size_t)j * cs + ch) = *reinterpret_cast<const f32x4*>(qkv + (r0 + j) * ldq + c + ch);
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256) void ball_attention_bwd_kernel(const float* __
         *reinterpret_cast<f32x4*>(Gs + (size_t)j * cs + ch) = *reinterpret_cast<const f32x4*>(dO + (r0 + j) * ldo + ch);
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < ball * heads; t += 256) {
+    for (int t = threadIdx.x; t < ball * heads; t += kAttThreads) {
         const int h = t / ball, i = t % ball;
         float q[HD], go[HD], acc[HD];
 #pragma unroll
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(256) void ball_attention_bwd_kernel(const float* __
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < ball * heads; t += 256) {
+    for (int t = threadIdx.x; t < ball * heads; t += kAttThreads) {
         const int h = t / ball, j = t % ball;
         float k[HD], v[HD], dk[HD], dv[HD];
 #pragma unroll
@@ -979,7 +980,7 @@ extern "C" int haet_pc_ball_attention(const float* qkv, int ldq, long long rows,
     auto go = [&](auto kern) {
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(rows / ball)), dim3(256), lds, as_stream(stream), qkv, ldq, c, heads, ball, scale, out, ldo);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(rows / ball)), dim3(kAttThreads), lds, as_stream(stream), qkv, ldq, c, heads, ball, scale, out, ldo);
     };
     switch (hd) {
         case 8: go(ball_attention_kernel<8>); break;
@@ -1149,8 +1150,8 @@ extern "C" int haet_pc_ball_attention_bwd(const float* qkv, int ldq, const float
     auto go = [&](auto kern) {
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(rows / ball)), dim3(256), lds, as_stream(stream), qkv, ldq, dO, ldo, c, heads, ball, scale,
-                           dqkv, ldd);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(rows / ball)), dim3(kAttThreads), lds, as_stream(stream), qkv, ldq, dO, ldo, c, heads, ball,
+                           scale, dqkv, ldd);
     };
     switch (hd) {
         case 8: go(ball_attention_bwd_kernel<8>); break;
