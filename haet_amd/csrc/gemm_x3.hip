@@ -107,7 +107,12 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 2, wn = wave & 3;
     const int col0 = blockIdx.y * BN;
-    const int nkt = K / GBK;
+    // ACT == 3 (CONV only): the k-tiles are split over gridDim.z workgroups per output tile, which ADD their partial sums
+    // into a zeroed `out` with float atomics (the bias goes in with z = 0).  For grids of a few thousand points (C1: 64 x 64)
+    // the launch is otherwise ~30 workgroups walking 72 items one after the other: pure latency.
+    constexpr bool kSplitK = ACT == 3;
+    const int nkt = kSplitK ? (K / GBK) / (int)gridDim.z : K / GBK;
+    const int kt0 = kSplitK ? (int)blockIdx.z * nkt : 0;
     const int my_tiles = n_row_tiles > (int)blockIdx.x ? (n_row_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const int total = my_tiles * nkt;
     if (total == 0) return;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     f32x16 acc[RB][WCB];
     float bv[WCB];  // bias of this lane's output columns: loaded (and waited for) once, up front
 #pragma unroll
-    for (int j = 0; j < WCB; ++j) bv[j] = bias ? bias[col0 + 32 * (WCB * wn + j) + l31] : 0.f;
+    for (int j = 0; j < WCB; ++j) bv[j] = (bias && (!kSplitK || blockIdx.z == 0)) ? bias[col0 + 32 * (WCB * wn + j) + l31] : 0.f;
 #pragma unroll
     for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
         {   // unconditional (rows are clamped, ghost items past the end load valid memory): a conditional
             // load inside the prefetch ring costs the waitcnt pass its counted waits
             int kk = fx_kt + krot;
-            kk = (kk >= nkt ? kk - nkt : kk) * GBK;
+            kk = ((kk >= nkt ? kk - nkt : kk) + kt0) * GBK;
             if (!CONV) {
 #pragma unroll
                 for (int i = 0; i < XPT; ++i) {
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     auto fetch_w = [&](u32x4 (&d)[2 * WPT]) {
         {
             int kk = fw_kt + krot;
-            kk = (kk >= nkt ? kk - nkt : kk) * GBK;
+            kk = ((kk >= nkt ? kk - nkt : kk) + kt0) * GBK;
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
                 const size_t o = (size_t)(col0 + wrow0 + 128 * i) * K + kk + 8 * wch;
@@ -245,16 +250,22 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
                 float* oc = out + (size_t)(row0 + 32 * RB * wm + 4 * hf) * O + col0 + 32 * (WCB * wn + j) + l31;
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
-                    if (full) {
+                    if (kSplitK) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rr = 32 * i + (r & 3) + 8 * (r >> 2);
+                            if (row0 + 32 * RB * wm + 4 * hf + rr < Nrows) atomicAdd(oc + (size_t)rr * O, acc[i][j][r]);
+                        }
+                    } else if (full) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            oc[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * O] = ACT ? g_gelu(acc[i][j][r]) : acc[i][j][r];
+                            oc[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * O] = ACT == 1 ? g_gelu(acc[i][j][r]) : acc[i][j][r];
                     } else {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int rr = 32 * i + (r & 3) + 8 * (r >> 2);
                             if (row0 + 32 * RB * wm + 4 * hf + rr < Nrows)
-                                oc[(size_t)rr * O] = ACT ? g_gelu(acc[i][j][r]) : acc[i][j][r];
+                                oc[(size_t)rr * O] = ACT == 1 ? g_gelu(acc[i][j][r]) : acc[i][j][r];
                         }
                     }
 #pragma unroll
@@ -841,6 +852,27 @@ extern "C" int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const
     const int gx = tiles < 256 / ny ? tiles : (256 / ny > 0 ? 256 / ny : 1);
     const size_t lds = (size_t)2 * (BM / 32 + NCBv) * 2 * GIMG;
     const ConvGeom cg{Cin, gH * gW * gD, gH, gW, gD, kH, kW, kD};
+    // few row tiles (small grids): split the k-tiles over Z workgroups per tile (one channel block each) that add into a
+    // zeroed output -- 32 workgroups x 72 items become 256 x 9
+    const int ncb = Cin / GBK;
+    static const bool no_split = getenv("HAET_CONV_NO_SPLITK") != nullptr;
+    if (!no_split && !big && tiles * ny * 4 <= 256 && ncb >= 2) {
+        int Z = ncb;
+        while (Z > 1 && tiles * ny * Z > 512) Z /= 2;
+        if (Z > 1 && ncb % Z == 0) {
+            if (hipMemsetAsync(out, 0, (size_t)Nrows * O * sizeof(float), as_stream(stream)) != hipSuccess)
+                return fail(HAET_E_LAUNCH, "conv_project_fwd: memset failed");
+            auto launch_z = [&](auto kern) {
+                if (lds > 64 * 1024)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(kern, dim3(tiles, ny, Z), dim3(512), lds, as_stream(stream), x, W_hi, W_lo, bias, Nrows, K, O,
+                                   tiles, out, cg);
+            };
+            if (NCBv == 8) launch_z(gemm_x3_kernel<8, 2, true, 3>);
+            else launch_z(gemm_x3_kernel<4, 2, true, 3>);
+            return check_launch("gemm_x3_kernel<conv, split-k>");
+        }
+    }
     auto launch = [&](auto kern) {
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
