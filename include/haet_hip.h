@@ -405,6 +405,9 @@ int haet_linear_narrow_fwd(const float* x, const float* W /*[O,K]*/, const float
  * matrix cores over the channels-last grid x [B, gH*gW*gD, C_in] -> out [B, gH*gW*gD, O]
  * (2-D: gD = kD = 1).  W_hi / W_lo: haet_split_bf16 of the weight re-laid as
  * [O][C_in/32][kH*kW*kD][32] (channel block, then tap, then the block's 32 channels).              */
+/* (grids of a few thousand points: the k-tiles of an output tile are split over several workgroups whose partial sums
+ * are added with float atomics -- the fp32 summation order, hence the last bit, can vary from run to run there;
+ * HAET_CONV_NO_SPLITK=1 keeps one workgroup per tile)                                                         */
 int haet_conv_project_supported(int Cin, int O);
 int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
                           int B, int gH, int gW, int gD, int Cin, int O, int kH, int kW, int kD,
