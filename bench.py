@@ -218,12 +218,37 @@ def sweep_main(args):
     return 0
 
 
+def visible_gpu_count() -> int:
+    """GPUs this process may use, WITHOUT touching the HIP runtime (the launcher must stay strictly pre-GPU: it
+    starts the ranks as children): the KFD topology in sysfs lists one node per agent, GPU nodes are those with
+    simd_count > 0; *_VISIBLE_DEVICES narrows the set like the runtime would."""
+    import glob
+
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:  # no KFD topology visible (some containers): NVML-style count, which does not create a HIP context
+        return torch.cuda.device_count()
+    n = 0
+    for props in nodes:
+        try:
+            with open(props) as fh:
+                fields = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            if int(fields.get("simd_count", "0")) > 0:
+                n += 1
+        except OSError:
+            continue
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def self_launch(args):
     """Run this script as N ranks on this node and return their exit code."""
     import socket
     import subprocess
 
-    n_dev = torch.cuda.device_count()  # (does not initialise the GPU on this image)
+    n_dev = visible_gpu_count()
     env = dict(os.environ)
     if n_dev < args.gpus:
         if not os.environ.get("HAET_BENCH_REHEARSE") or n_dev < 1 or args.gpus > 6:

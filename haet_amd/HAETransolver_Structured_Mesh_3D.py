@@ -30,7 +30,7 @@ class Model(ModelBase):
                  embed=False):
         super().__init__()
         self.__name__ = "Transolver_3D"
-        self.use_checkpoint = True
+        self.use_checkpoint = False  # (HAETransolver_Structured_Mesh_3D.py:243; set True for gradient checkpointing)
         self.H, self.W, self.D, self.ref = H, W, D, ref
         self.unified_pos, self.Time_Input = unified_pos, Time_Input
         self.n_hidden, self.space_dim = n_hidden, space_dim

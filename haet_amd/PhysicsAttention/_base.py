@@ -2,13 +2,14 @@
 
 The reference copy-pastes one forward three times (models/PhysicsAttention/
 IrregularMesh.py:141-235, StructuredMesh2D.py:157-262, StructuredMesh3D.py:161-266); the
-variants differ only in the per-point projection (Linear / Conv2d / Conv3d).  Here the
-projection stays a stock PyTorch-ROCm op (rocBLAS / MIOpen) and everything after it is the
-HIP path:
+variants differ only in the per-point projection (Linear / Conv2d / Conv3d).  Every stage is a
+hand-written HIP kernel behind the C ABI (rocBLAS / MIOpen only for channel counts outside the
+GEMM / implicit-GEMM kernels' envelopes):
 
-    x_lin [B,N,H*C] --haet_slice_fwd--> partial (m,l,St) --haet_slice_merge--> S, col stats
-      --haet_token_pos--> pos --haet_balltree_build + haet_erwin_fwd--> S'
-      --haet_deslice_fwd--> out_x [B,N,H*C] --to_out--> [B,N,dim]
+    x --haet_project_split_fwd | haet_conv_project_fwd--> x_lin [B,N,H*C] (fused operand format or fp32)
+      --haet_slice_fwd[_split]--> partial (m,l,St) --haet_slice_merge--> S, col stats
+      --haet_token_stage_fwd (positions + ball tree + Erwin, one launch)--> S'
+      --haet_deslice_out_fwd_split (de-slice + to_out fused) | haet_deslice_fwd + haet_linear_fwd--> [B,N,dim]
 
 The [B,H,N,G] slice-weight tensor of the reference (2 GB at N=1M) is never materialised.
 With `shard_group` set, each rank holds a shard of the points and the partial records are
@@ -59,6 +60,10 @@ class _StageTimer:
         return False
 
 
+def _invalidate_hook(module, incompatible):
+    module.invalidate_caches()
+
+
 class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
     dimensionality = 3
 
@@ -103,7 +108,7 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
         self.event_pool = None    # optional list of pre-recorded timing events the stage timer draws from
         self._slice_cache = None
         _compile.register(self)
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_caches())
+        self.register_load_state_dict_post_hook(_invalidate_hook)  # (a module-level function: the module stays picklable)
 
     # -- per-variant projection to [B, N, H*C] -------------------------------------------
     def project(self, x: torch.Tensor) -> torch.Tensor:
@@ -197,6 +202,9 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
               self.ada_temp_linear.weight, self.ada_temp_linear.bias)
         key = tuple((p.data_ptr(), p._version) for p in ps)
         if self._slice_cache is None or self._slice_cache[0] != key:
+            # (the .item() below synchronises: the point at which a timed-out grid barrier of the previous
+            # training step's Erwin launches is reported)
+            self.erwin.check_grid_barrier()
             sp = ops.SliceParams(ps[0].detach(), ps[1].detach(), ps[2].detach(),
                                  float(ps[3].detach().item()), self.base_temp, self.epsilon)
             self._slice_cache = (key, sp)
@@ -220,6 +228,16 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
     def _apply(self, fn, *args, **kwargs):  # .to() / .cuda(): parameter objects may be replaced
         self.__dict__["_grad_check_stale"] = True
         return super()._apply(fn, *args, **kwargs)
+
+    def __getstate__(self):
+        # cached operands (bf16 planes, slice parameters) and timing plumbing are per-process: rebuilt on demand
+        state = dict(self.__dict__)
+        for k in ("_split_cache", "_grad_check_params", "_event_chain", "_haet_handle"):
+            state.pop(k, None)
+        state["_slice_cache"] = None
+        state["stage_events"] = state["event_pool"] = None
+        state["_grad_check_stale"] = True
+        return state
 
     def invalidate_caches(self):
         """Drop every weight-derived operand this module caches (bf16 planes of the projections, the slice

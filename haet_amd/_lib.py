@@ -126,6 +126,10 @@ SIGNATURES = {
     "haet_erwin_bwd_supported": (c_int, [POINTER(ErwinDesc), c_int, c_int]),
     "haet_erwin_bwd": (c_int, [_P] * 8 + [POINTER(ErwinDesc), _P, _P, c_int, c_int, _P, _P, _P]),
     "haet_erwin_train_workspace_bytes": (c_size_t, [POINTER(ErwinDesc), c_int]),
+    "haet_set_deterministic": (None, [c_int]),
+    "haet_get_deterministic": (c_int, []),
+    "haet_resident_workgroup_limit": (c_int, []),
+    "haet_erwin_barrier_status": (c_int, [c_void_p]),
     "haet_token_stage_supported": (c_int, [POINTER(ErwinDesc), c_int, c_int]),
     "haet_token_stage_fwd": (c_int, [_P, c_int, c_int, c_float, _P, c_size_t, POINTER(ErwinDesc), POINTER(ErwinTrain),
                                      _P, _P, _P, _P, _P, _P]),

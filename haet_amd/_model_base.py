@@ -115,6 +115,13 @@ class ModelBase(_compile.OpaqueForwardMixin, nn.Module):
         self.__dict__["_pre_ops"] = pre  # (strong references: the registry only holds weak ones)
         self.__dict__["_pre_handles"] = (_compile.register(pre[0]), _compile.register(pre[1]))
 
+    def __getstate__(self):
+        # the preprocess operators hold a weak reference to the model: re-made by _after_copy() on unpickling
+        state = dict(self.__dict__)
+        for k in ("_pre_ops", "_pre_handles", "_haet_handle"):
+            state.pop(k, None)
+        return state
+
     def initialize_weights(self):
         self.apply(self._init_weights)
 

@@ -120,6 +120,16 @@ class ErwinEmbedding(nn.Module):
         self.mpnn = MPNN(dim, mp_steps, dimensionality)
 
 
+def _mark_stale_hook(module, incompatible):
+    module._mark_stale()
+
+
+def _barrier_check_hook(module, prefix, keep_vars):
+    # state_dict() copies the running statistics out: a natural point to learn that a train-mode launch's grid barrier
+    # gave up (the statistics would be garbage) -- raises HaetError
+    module.check_grid_barrier()
+
+
 class ErwinTransformer(nn.Module):
     """Same constructor and state_dict as the reference (erwin_flash.py:41-136)."""
 
@@ -153,7 +163,8 @@ class ErwinTransformer(nn.Module):
         self.in_dim, self.out_dim = c_in, c_hidden[0]
         self.apply(self._init_weights)
         self._packed = None  # (key, weights blob, desc)
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._mark_stale())
+        self.register_load_state_dict_post_hook(_mark_stale_hook)  # (module-level functions: the module stays picklable)
+        self.register_state_dict_pre_hook(_barrier_check_hook)
 
     def _init_weights(self, m):
         # erwin_flash.py:127-136
@@ -184,6 +195,15 @@ class ErwinTransformer(nn.Module):
 
     def _mark_stale(self, *_):
         self.__dict__["_pack_stale"] = True
+
+    def __getstate__(self):
+        # weight-derived caches hold ctypes descriptors and device scratch: never pickled, rebuilt at the next forward
+        state = dict(self.__dict__)
+        for k in ("_train_cache", "_packed_f32", "_fits_memo", "_pack_tensors", "last_positions"):
+            state.pop(k, None)
+        state["_packed"] = None
+        state["_pack_stale"] = True
+        return state
 
     def invalidate_caches(self):
         """Drop the packed weight blob (rebuilt at the next forward): needed after in-place writes through
@@ -255,7 +275,19 @@ class ErwinTransformer(nn.Module):
         blob, desc = self.packed()
         train = None
         if self.training:  # BatchNorm batch statistics over all clouds + running-stat update, inside the kernel
+            if n_clouds > _lib.load().haet_resident_workgroup_limit():
+                # more clouds than compute units: the kernel's grid barrier could not complete -- the torch
+                # restatement of the stage (same tree, same arithmetic, launch-bound) takes this case
+                from ... import _autograd
+
+                if node_positions is None:
+                    node_positions = ops.token_pos(node_features, self.dimensionality)
+                self.__dict__["last_positions"] = node_positions if self.__dict__.get("keep_positions", True) else None
+                with torch.no_grad():
+                    return _autograd.erwin_forward(self, node_features, node_positions, n_clouds)
             train = self._train_state(desc, n_clouds, node_features.device)
+            if os.environ.get("HAET_CHECK_BARRIER"):  # debug: learn about a timed-out barrier at every launch (syncs)
+                train.check_barrier()
         if node_positions is None and not os.environ.get("HAET_NO_TOKEN_STAGE") and ops.token_stage_supported(desc, n_clouds, M):
             out, node_positions = ops.token_stage(node_features, blob, desc, n_clouds, M, self.dimensionality,
                                                   self.strides, float(self.rotate), train)
@@ -325,6 +357,14 @@ class ErwinTransformer(nn.Module):
                                         _St if ctx["stats"] is not None else None)
         gsum = per_cloud.sum(dim=0)
         return g_in, {id(p): gsum[off:off + p.numel()].view_as(p) for p, off in pmap}
+
+    def check_grid_barrier(self):
+        """Raise HaetError if a grid barrier of a train-mode launch of this module timed out since the last check
+        (ops.ErwinTrainState.check_barrier; synchronises).  Called from state_dict(), from the owning attention module
+        whenever it re-reads its parameters after an optimizer step, and per launch under HAET_CHECK_BARRIER=1."""
+        hit = self.__dict__.get("_train_cache")
+        if hit is not None and hit[1].workspace.is_cuda:
+            hit[1].check_barrier()
 
     def _train_state(self, desc, n_clouds, device):
         """ops.ErwinTrainState for this (weights object set, cloud count): pointers to the BatchNorm running

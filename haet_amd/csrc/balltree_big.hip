@@ -704,6 +704,9 @@ extern "C" int haet_balltree_big_build(const float* pos, const int32_t* cloud_si
     const size_t need = big_carve((char*)workspace, nt, nt, d, n_clouds, &ws);
     if (workspace_bytes < need) return fail(HAET_E_ARG, "balltree_big: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t st = as_stream(stream);
+    if (stream_is_capturing(st))
+        return fail(HAET_E_ARG, "balltree_big: the build synchronises the stream between its level launches and cannot "
+                                "run under stream capture (build the tree before the capture begins)");
 
     // main tree: ceil(log2 n) - 1 levels of median splits, then leaves of one or two points (balltree.pyx:55-60)
     std::vector<BigCloud> clouds(n_clouds);

@@ -19,6 +19,17 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+static std::atomic<int> g_deterministic{-1};
+bool deterministic_mode() {
+    int v = g_deterministic.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("HAET_DETERMINISTIC");
+        v = (e && e[0] == '1') ? 1 : 0;
+        g_deterministic.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+
 // slice_valu.hip
 int slice_shape_ok(int B, int N, int H, int C, int M);
 int slice_valu_num_parts(int N);
@@ -68,6 +79,24 @@ using namespace haet;
 
 extern "C" int haet_abi_version(void) { return HAET_ABI_VERSION; }
 extern "C" const char* haet_last_error_string(void) { return err_buf(); }
+
+extern "C" void haet_set_deterministic(int on) { g_deterministic.store(on ? 1 : 0, std::memory_order_relaxed); }
+extern "C" int haet_get_deterministic(void) { return deterministic_mode() ? 1 : 0; }
+
+extern "C" int haet_resident_workgroup_limit(void) { return resident_workgroup_limit(); }
+
+extern "C" int haet_erwin_barrier_status(const void* workspace_host_copy8) {
+    // (host-side decode of the first 8 bytes of a train workspace: {arrival counter, time-out flag})
+    if (!workspace_host_copy8) return fail(HAET_E_ARG, "erwin_barrier_status: null pointer");
+    unsigned w[2];
+    memcpy(w, workspace_host_copy8, 8);
+    if (w[1] != 0)
+        return fail(HAET_E_LAUNCH, "erwin: a grid barrier of the train-mode Erwin stage timed out (a workgroup of the "
+                                   "launch was not resident: another kernel held compute units, or two processes share "
+                                   "the device) -- the BatchNorm batch statistics, running statistics and gradients of "
+                                   "that step are invalid");
+    return HAET_OK;
+}
 
 extern "C" int haet_slice_num_parts(int B, int N, int H, int C, int M) {
     if (slice_shape_ok(B, N, H, C, M) != HAET_OK) return HAET_E_ARG;

@@ -1203,9 +1203,9 @@ static int erwin_train_args(const haet_erwin_desc* desc, const haet_erwin_train*
     }
     if (!train || !train->workspace)
         return fail(HAET_E_ARG, "erwin: desc->bn_train is set but no train-mode plumbing (haet_erwin_train) was passed");
-    if (n_clouds > 256)
-        return fail(HAET_E_RESOURCE, "erwin: train-mode BatchNorm meets all %d clouds at a grid barrier: at most 256 "
-                                     "(one workgroup per CU)", n_clouds);
+    if (n_clouds > resident_workgroup_limit())
+        return fail(HAET_E_RESOURCE, "erwin: train-mode BatchNorm meets all %d clouds at a grid barrier: at most %d "
+                                     "(one workgroup per compute unit of this device)", n_clouds, resident_workgroup_limit());
     int cmax = 4;
     for (int l = 0; l < desc->n_levels; ++l) cmax = cmax > desc->enc[l].c ? cmax : desc->enc[l].c;
     for (int i = 0; i < 2 * HAET_ERWIN_MAX_LEVELS; ++i) {
@@ -1221,8 +1221,9 @@ static int erwin_train_args(const haet_erwin_desc* desc, const haet_erwin_train*
     t.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(train->workspace) + 64);
     t.cmax = cmax;
     t.on = 1;
-    // the barrier words are zeroed before EVERY launch (a memset node under graph capture)
-    hipError_t e = hipMemsetAsync(train->workspace, 0, 64, stream);
+    // the barrier COUNTER is zeroed before EVERY launch (a memset node under graph capture); the time-out word next
+    // to it is sticky: set by a barrier that gave up, cleared only by the host that reads it (haet_erwin_barrier_status)
+    hipError_t e = hipMemsetAsync(train->workspace, 0, 4, stream);
     if (e != hipSuccess) return fail(HAET_E_LAUNCH, "erwin: hipMemsetAsync: %s", hipGetErrorString(e));
     *out = t;
     return HAET_OK;

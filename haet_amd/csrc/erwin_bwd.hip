@@ -878,7 +878,7 @@ extern "C" size_t haet_erwin_tape_floats(const haet_erwin_desc* desc, int M, int
 
 extern "C" int haet_erwin_bwd_supported(const haet_erwin_desc* desc, int n_clouds, int M) {
     if (!desc || n_clouds < 1 || M < 2 || desc->n_levels < 1 || desc->n_levels > HAET_ERWIN_MAX_LEVELS) return 0;
-    if (desc->bn_train && n_clouds > 256) return 0;
+    if (desc->bn_train && n_clouds > resident_workgroup_limit()) return 0;
     int depth = 0;
     while ((2 << depth) < M) ++depth;
     for (int l = 0; l < desc->n_levels; ++l) {  // head dims with a register-resident attention instantiation
@@ -903,7 +903,7 @@ extern "C" int haet_erwin_bwd(const float* g_out, const float* tape, const float
         return fail(HAET_E_ARG, "erwin_bwd: null pointer");
     if (!haet_erwin_bwd_supported(desc, n_clouds, M))
         return fail(HAET_E_RESOURCE, "erwin_bwd: one cloud of %d tokens does not fit the backward kernel's LDS plan "
-                                     "(or > 256 clouds in train mode)", M);
+                                     "(or more clouds than compute units in train mode)", M);
     if (desc->rotate && !rot) return fail(HAET_E_ARG, "erwin_bwd: rotate set but rot is NULL");
     if (desc->bn_train && (!bn_batch_stats || !workspace))
         return fail(HAET_E_ARG, "erwin_bwd: train-mode BatchNorm needs the forward's batch statistics and a workspace");
@@ -928,7 +928,7 @@ extern "C" int haet_erwin_bwd(const float* g_out, const float* tape, const float
         attr_dev.store(bytes, std::memory_order_release);
     }
     if (desc->bn_train) {
-        hipError_t e = hipMemsetAsync(workspace, 0, 64, as_stream(stream));
+        hipError_t e = hipMemsetAsync(workspace, 0, 4, as_stream(stream));  // the counter; the time-out word stays (sticky)
         if (e != hipSuccess) return fail(HAET_E_LAUNCH, "erwin_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
     }
     hipLaunchKernelGGL(erwin_bwd_kernel, dim3(n_clouds), dim3(kBT), bytes, as_stream(stream), a, T);

@@ -856,7 +856,8 @@ extern "C" int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const
     // zeroed output -- 32 workgroups x 72 items become 256 x 9
     const int ncb = Cin / GBK;
     static const bool no_split = getenv("HAET_CONV_NO_SPLITK") != nullptr;
-    if (!no_split && !big && tiles * ny * 4 <= 256 && ncb >= 2) {
+    // (float atomics: the summation order varies from run to run -- not taken in deterministic mode)
+    if (!no_split && !deterministic_mode() && !big && tiles * ny * 4 <= 256 && ncb >= 2) {
         int Z = ncb;
         while (Z > 1 && tiles * ny * Z > 512) Z /= 2;
         if (Z > 1 && ncb % Z == 0) {

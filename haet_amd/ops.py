@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -156,6 +157,16 @@ class ErwinTrainState:
         self.tape = tape
         self.c.tape = 0 if tape is None else tape.data_ptr()
         self.c.tape_op_floats = int(op_floats)
+
+    def check_barrier(self):
+        """Read the workspace's barrier words (a device -> host copy: call at a point that synchronises anyway) and
+        raise HaetError if a grid barrier of a train-mode launch timed out since the last check (include/haet_hip.h,
+        residency contract: the launch's workgroups must all be resident, i.e. the device otherwise idle)."""
+        words = self.workspace[:2].cpu().contiguous()
+        rc = _lib.load().haet_erwin_barrier_status(ctypes.c_void_p(words.data_ptr()))
+        if rc != 0:
+            self.workspace[1:2].zero_()  # re-arm
+            check(rc, "haet_erwin_barrier_status")
 
     def __init__(self, erwin, desc, n_clouds: int, device):
         lib = _lib.load()
@@ -598,6 +609,8 @@ def conv_project(x: Tensor, w: SplitConv, grid: Tuple[int, ...]) -> Tensor:
         raise HaetError("conv_project: x does not match the grid / weight")
     out = torch.empty((B, N, w.O), dtype=torch.float32, device=x.device)
     kH, kW, kD = w.kernel
+    # small grids otherwise split the k-tiles over workgroups that add with float atomics (run-to-run order)
+    lib.haet_set_deterministic(1 if (torch.are_deterministic_algorithms_enabled() or os.environ.get("HAET_DETERMINISTIC") == "1") else 0)
     check(lib.haet_conv_project_fwd(_p(x), _p(w.lin.hi), _p(w.lin.lo), _p(w.lin.bias), B, gH, gW, gD, Cin, w.O,
                                     kH, kW, kD, _p(out), _stream()), "haet_conv_project_fwd")
     return out

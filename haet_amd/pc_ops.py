@@ -112,6 +112,12 @@ def radius_graph(pos: Tensor, r: float, batch_idx: Tensor, cloud_sizes: Sequence
 def edges_to_csr(edge_index: Tensor, N: int):
     """(rowptr int32 [N+1], src int32 [E]): the senders of every receiver's edges (receiver = edge_index[1])."""
     row, col = edge_index[0].to(torch.long), edge_index[1].to(torch.long)
+    if row.numel():
+        # the indices address rows of device tensors inside the message kernels (and atomic writes in their backward):
+        # one host read (the edge list's producer, radius_graph, synchronises anyway)
+        lo, hi = torch.aminmax(edge_index)
+        if int(lo) < 0 or int(hi) >= N:
+            raise HaetError(f"edge_index holds node indices outside [0, {N}): min {int(lo)}, max {int(hi)}")
     if col.numel() > 1 and not bool((col[1:] >= col[:-1]).all()):
         col, order = torch.sort(col, stable=True)
         row = row[order]

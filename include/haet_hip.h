@@ -46,6 +46,15 @@ typedef void* haet_stream_t;
 
 int haet_abi_version(void);
 const char* haet_last_error_string(void);
+/* Deterministic mode (process-wide; default: environment HAET_DETERMINISTIC=1, else off): entry points that have a
+ * faster variant whose floating-point summation ORDER varies from run to run take the fixed-order variant instead.
+ * Today that is the split-k convolution projection of small grids (haet_conv_project_fwd: k-tiles over several
+ * workgroups added with float atomics; deterministic mode runs one workgroup per output tile).  The Python host
+ * sets it from torch.are_deterministic_algorithms_enabled() before every convolution launch.  Every other FORWARD
+ * entry point sums in a fixed order always; the backward of the stand-alone point-cloud MPNN
+ * (haet_pc_mpnn_message_bwd) adds sender gradients with float atomics and has no fixed-order variant. */
+void haet_set_deterministic(int on);
+int haet_get_deterministic(void);
 
 /* ------------------------------------------------------------------ per-point projections
  * in_project_x (models/PhysicsAttention/IrregularMesh.py:157-158) and to_out (:235) are
@@ -195,7 +204,8 @@ size_t haet_erwin_lds_bytes(const haet_erwin_desc* desc, int Mp);
 /* Train-mode BatchNorm plumbing (BallPooling / BallUnpooling `norm` under module.train(), pooling.py:23,38,56,68:
  * batch statistics over the tokens of ALL clouds, running statistics updated with `momentum`, num_batches_tracked
  * incremented).  Slot 2l = pool of level l, 2l+1 = unpool of level l.  The clouds' workgroups meet at a grid
- * barrier per BatchNorm, so a train-mode launch takes at most 256 clouds (HAET_E_RESOURCE beyond). */
+ * barrier per BatchNorm, so a train-mode launch takes at most haet_resident_workgroup_limit() clouds (256 on
+ * MI355X; HAET_E_RESOURCE beyond) -- see the residency contract below. */
 typedef struct {
     float* running_mean[2 * HAET_ERWIN_MAX_LEVELS];          /* device, updated in place; NULL: slot unused / not tracked */
     float* running_var[2 * HAET_ERWIN_MAX_LEVELS];
@@ -210,6 +220,17 @@ typedef struct {
 } haet_erwin_train;
 
 size_t haet_erwin_train_workspace_bytes(const haet_erwin_desc* desc, int n_clouds);
+/* Residency contract of the train-mode launches (haet_erwin_fwd / haet_token_stage_fwd with desc->bn_train,
+ * haet_erwin_bwd with desc->bn_train): one workgroup per cloud, and ALL of them must be resident at once for the
+ * grid barriers to complete -- n_clouds <= haet_resident_workgroup_limit() (the device's compute-unit count; checked,
+ * HAET_E_RESOURCE beyond) AND a device that is otherwise idle while the launch runs (no other stream or process
+ * holding compute units: not checked, cannot be).  A barrier whose workgroups do not all arrive gives up after ~1 s
+ * instead of hanging the GPU and sets the workspace's time-out word (bytes 4..7; sticky: launches clear only the
+ * counter in bytes 0..3); the results of that launch are invalid.  The caller copies the first 8 bytes of the
+ * workspace to the host at its next synchronisation point and passes them to haet_erwin_barrier_status:
+ * HAET_OK, or HAET_E_LAUNCH with the explanation in haet_last_error_string(); to re-arm, zero bytes 4..7. */
+int haet_resident_workgroup_limit(void);
+int haet_erwin_barrier_status(const void* workspace_first_8_bytes_on_host);
 
 int haet_erwin_fwd(const float* tokens /*[n_clouds*M, c0]*/, const float* pos /*[n_clouds*M, d]*/,
                    const int32_t* tree_idx, const uint8_t* tree_mask, const int32_t* rot,
@@ -234,7 +255,7 @@ int haet_token_stage_fwd(const float* S, int n_clouds, int M, float angle_deg, c
  * exp_airfoil.py:249-255) in ONE launch, one workgroup per cloud: every block / pool / unpool is recomputed from its
  * taped input (haet_erwin_train.tape) in fp32 and differentiated -- RMSNorm, rel-pos PE, QKV, per-ball softmax
  * attention, proj, SwiGLU, BallPooling / BallUnpooling with eval- or train-mode BatchNorm (train: the cross-cloud
- * terms of the BatchNorm backward meet at a grid barrier, <= 256 clouds).  Positions carry no gradient (the
+ * terms of the BatchNorm backward meet at a grid barrier, <= haet_resident_workgroup_limit() clouds, idle device).  Positions carry no gradient (the
  * reference computes rel_pos / centres under no_grad: attention.py:35, pooling.py:29,59).
  *
  * Weights come as ONE fp32 blob that BEGINS WITH haet_erwin_f32_layout (offsets in floats of every tensor, original

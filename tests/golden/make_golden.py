@@ -460,6 +460,45 @@ def gen_erwinflash_fixtures(models, tree_store, only=None):
               f"{0 if edge_index is None else edge_index.shape[1]}")
 
 
+EF_GRAD_CASES = ["two_clouds", "two_clouds_train", "planar_norot"]
+
+
+def gen_erwinflash_grad_fixtures(models, only=None):
+    """Gradients of the REFERENCE ErwinTransformer (its own autograd) w.r.t. the node features and every parameter
+    for loss = <out, gout>, on the inputs / weights of an existing ef_* fixture (read back from its .npz)."""
+    import ast
+
+    from models.components.erwinflash import ErwinTransformer
+
+    for ci, name in enumerate(EF_GRAD_CASES):
+        if only and ("efgrad_" + name) not in only:
+            continue
+        z = np.load(os.path.join(HERE, f"ef_{name}.npz"))
+        meta = ast.literal_eval(bytes(z["meta"]).decode())
+        mod = ErwinTransformer(**meta["kw"])
+        mod.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")})
+        mod.train(meta["train"])
+        feat = torch.from_numpy(z["feat"].astype(np.float32)).requires_grad_(True)
+        pos, batch_idx = torch.from_numpy(z["pos"]), torch.from_numpy(z["batch_idx"])
+        if meta["edges"] == "given":
+            out = mod(feat, pos, batch_idx, edge_index=torch.from_numpy(z["edge_index"].astype(np.int64)))
+        else:
+            out = mod(feat, pos, batch_idx, radius=meta["radius"])
+        assert np.allclose(out.detach().numpy(), z["exp/out"], rtol=0, atol=1e-5 * float(np.abs(z["exp/out"]).max()))
+        gen = torch.Generator().manual_seed(6000 + ci)
+        gout = torch.randn(out.shape, generator=gen).half().float()
+        (out * gout).sum().backward()
+        arrays = {"gout": gout.half().numpy(), "gfeat": feat.grad.numpy()}
+        for pn, p in mod.named_parameters():
+            if p.grad is not None:
+                arrays["g/" + pn] = p.grad.numpy()
+            else:
+                arrays["nograd/" + pn] = np.zeros(0, dtype=np.float32)
+        path = os.path.join(HERE, f"efgrad_{name}.npz")
+        np.savez_compressed(path, **arrays)
+        print(f"{path}: {os.path.getsize(path)/1e6:.2f} MB  |gfeat|={feat.grad.norm():.4f}")
+
+
 MODEL_CASES = [
     ("irr", "HAETransolver_Irregular_Mesh", dict(space_dim=3, fun_dim=4, n_hidden=64, n_layers=2, n_head=4, mlp_ratio=2, out_dim=4, slice_num=16), 500, True),
     ("irr_nofx", "HAETransolver_Irregular_Mesh", dict(space_dim=3, fun_dim=0, n_hidden=64, n_layers=1, n_head=4, mlp_ratio=1, out_dim=1, slice_num=8), 300, False),
@@ -549,3 +588,4 @@ if __name__ == "__main__":
     gen_big_fixtures(models, store, only)
     gen_grad_fixtures(models, only)
     gen_erwinflash_fixtures(models, store, only)
+    gen_erwinflash_grad_fixtures(models, only)

@@ -66,6 +66,15 @@ def load_ef(name):
                 meta=_meta(z), exp={k[4:]: torch.from_numpy(np.asarray(z[k])) for k in z.files if k.startswith("exp/")})
 
 
+def load_ef_grad(name):
+    """Gradients of the REFERENCE ErwinTransformer for loss = <out, gout> on fixture ef_<name> (make_golden.py
+    gen_erwinflash_grad_fixtures): dict gout, gfeat, g {parameter name: gradient}, nograd [names]."""
+    z = np.load(os.path.join(GOLDEN, f"efgrad_{name}.npz"))
+    return dict(gout=torch.from_numpy(z["gout"].astype(np.float32)), gfeat=torch.from_numpy(z["gfeat"]),
+                g={k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g/")},
+                nograd=[k[7:] for k in z.files if k.startswith("nograd/")])
+
+
 def _meta(z):
     return ast.literal_eval(bytes(z["meta"]).decode())
 

@@ -140,3 +140,58 @@ def test_grad_check_cache_follows_requires_grad():
     assert not m._any_requires_grad()
     m.to_out[0].weight.requires_grad_(True)
     assert m._any_requires_grad()
+
+
+def test_modules_round_trip_through_pickle_and_deepcopy():
+    """torch.save(module) / copy.deepcopy (spawn-based multiprocessing passes models this way): the hooks are
+    module-level functions, per-process caches (ctypes descriptors, device scratch, weak references) are dropped and
+    re-made, the copy gets its own haet::module_forward handle and the same state_dict."""
+    import copy
+    import io
+
+    import haet_amd
+    from haet_amd.HAETransolver_Irregular_Mesh import Model
+
+    m = haet_amd.PhysicsAttention.Physics_Attention_Irregular_Mesh(64, heads=4, dim_head=16, slice_num=16, rotate=45)
+    blob, desc = m.erwin.packed()              # fill the caches that hold ctypes objects
+    m.erwin._train_state(desc, 4, torch.device("cpu"))
+    mm = Model(space_dim=3, n_layers=1, n_hidden=64, n_head=4, fun_dim=0, out_dim=1, slice_num=16)
+    for mod in (m, mm):
+        buf = io.BytesIO()
+        torch.save(mod, buf)
+        buf.seek(0)
+        for twin in (torch.load(buf, weights_only=False), copy.deepcopy(mod)):
+            if mod is m:
+                assert twin._haet_handle != mod._haet_handle
+            else:
+                assert twin._pre_handles != mod._pre_handles and twin.blocks[0]._haet_handle != mod.blocks[0]._haet_handle
+            a, b = mod.state_dict(), twin.state_dict()
+            assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+    assert copy.deepcopy(m).erwin._packed is None
+
+
+def test_grid_barrier_timeout_word_surfaces_as_error():
+    """A train-mode launch whose grid barrier gave up sets the workspace's sticky time-out word (include/haet_hip.h,
+    residency contract); the host raises at its next check and re-arms the word."""
+    import haet_amd
+    from haet_amd import _lib, ops
+
+    m = haet_amd.PhysicsAttention.Physics_Attention_Irregular_Mesh(64, heads=4, dim_head=16, slice_num=16, rotate=45)
+    _, desc = m.erwin.packed()
+    st = ops.ErwinTrainState(m.erwin, desc, 4, torch.device("cpu"))
+    st.check_barrier()                                   # clean
+    st.workspace.view(torch.int32)[0] = 12               # an arrival count is not an error
+    st.check_barrier()
+    st.workspace.view(torch.int32)[1] = 1                # what erwin_grid_barrier / bwd_grid_barrier store on time-out
+    with pytest.raises(_lib.HaetError, match="grid barrier"):
+        st.check_barrier()
+    st.check_barrier()                                   # re-armed
+    assert 1 <= _lib.load().haet_resident_workgroup_limit() <= 4096
+
+
+def test_structured_3d_model_defaults_follow_reference():
+    """HAETransolver_Structured_Mesh_3D.py:243: gradient checkpointing is off by default (with it on, every block's
+    forward runs twice per training step and train-mode BatchNorm statistics advance twice)."""
+    from haet_amd.HAETransolver_Structured_Mesh_3D import Model
+
+    assert Model(n_layers=1, n_hidden=64, n_head=4, H=4, W=4, D=4, slice_num=8).use_checkpoint is False

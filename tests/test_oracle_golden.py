@@ -155,3 +155,24 @@ def test_standalone_erwinflash_oracle_matches_reference(name):
     if "embed" in exp:
         assert O.rel_l2(trace["embed"], exp["embed"]) < 1e-6
     assert O.rel_l2(out, exp["out"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["two_clouds", "two_clouds_train", "planar_norot"])
+def test_standalone_erwinflash_oracle_gradients_match_reference_autograd(name):
+    """Autograd through the oracle's stand-alone ErwinFlash against the REFERENCE ErwinTransformer's own autograd
+    (tests/golden/efgrad_*.npz): node features and every parameter (sigma_att gets none).  Parameters whose true
+    gradient is zero (a bias in front of a train-mode BatchNorm) are held to the fp32 noise of the largest gradient."""
+    f, gr = G.load_ef(name), G.load_ef_grad(name)
+    meta, kw = f["meta"], f["meta"]["kw"]
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in f["sd"].items()}
+    feat = f["feat"].clone().requires_grad_(True)
+    out = O.erwinflash_forward(feat, f["pos"], f["batch_idx"], sd, G.ef_cfg(meta), kw["mp_steps"],
+                               edge_index=f["edge_index"] if meta["edges"] == "given" else None, radius=meta["radius"],
+                               training=meta["train"])
+    (out * gr["gout"]).sum().backward()
+    assert O.rel_l2(feat.grad, gr["gfeat"]) < 2e-5
+    scale = max(float(g.norm()) for g in gr["g"].values())
+    for k, g in gr["g"].items():
+        err = float((sd[k].grad - g).norm()) / max(float(g.norm()), 1e-3 * scale)
+        assert err < 5e-5, (k, err)
+    assert set(gr["nograd"]) == {k for k, v in sd.items() if v.requires_grad and v.grad is None}
