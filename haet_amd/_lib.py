@@ -133,6 +133,10 @@ SIGNATURES = {
     "haet_token_stage_supported": (c_int, [POINTER(ErwinDesc), c_int, c_int]),
     "haet_token_stage_fwd": (c_int, [_P, c_int, c_int, c_float, _P, c_size_t, POINTER(ErwinDesc), POINTER(ErwinTrain),
                                      _P, _P, _P, _P, _P, _P]),
+    "haet_erwin_frag_bytes": (c_size_t, [POINTER(ErwinDesc), c_int]),
+    "haet_erwin_frag_pack": (c_int, [_P, c_size_t, POINTER(ErwinDesc), c_int, _P, c_size_t, _P]),
+    "haet_token_stage_fwd_frag": (c_int, [_P, c_int, c_int, c_float, _P, c_size_t, _P, c_size_t, POINTER(ErwinDesc),
+                                          _P, _P, _P, _P, _P, _P]),
     "haet_deslice_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P]
                          + [c_int] * 5 + [_P, _P]),
     # stand-alone ErwinFlash on raw point clouds (include/haet_hip.h, last section)
@@ -226,8 +230,8 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
             fn.restype, fn.argtypes = res, args
-        if lib.haet_abi_version() != 5:
-            raise HaetError(f"libhaet_hip.so ABI {lib.haet_abi_version()} != 5")
+        if lib.haet_abi_version() != 6:
+            raise HaetError(f"libhaet_hip.so ABI {lib.haet_abi_version()} != 6")
         _lib = lib
     return _lib
 

@@ -199,7 +199,7 @@ class ErwinTransformer(nn.Module):
     def __getstate__(self):
         # weight-derived caches hold ctypes descriptors and device scratch: never pickled, rebuilt at the next forward
         state = dict(self.__dict__)
-        for k in ("_train_cache", "_packed_f32", "_fits_memo", "_pack_tensors", "last_positions"):
+        for k in ("_train_cache", "_packed_f32", "_packed_frags", "_fits_memo", "_pack_tensors", "last_positions"):
             state.pop(k, None)
         state["_packed"] = None
         state["_pack_stale"] = True
@@ -209,6 +209,7 @@ class ErwinTransformer(nn.Module):
         """Drop the packed weight blob (rebuilt at the next forward): needed after in-place writes through
         `.data` (EMA swap, manual clipping), which change neither `_version` nor the storage pointer."""
         self._packed = None
+        self.__dict__.pop("_packed_frags", None)
         self._mark_stale()
 
     def _apply(self, fn, *args, **kwargs):
@@ -224,6 +225,16 @@ class ErwinTransformer(nn.Module):
             blob, desc = pack_erwin(self)
             self._packed = (key, blob, desc)
         return self._packed[1], self._packed[2]
+
+    def packed_frags(self, M: int):
+        """The fragment-order weight blob of the fragment kernel (csrc/erwin2.hip) for clouds of M tokens, or None
+        outside its envelope; rebuilt (on the device) only when the packed blob was."""
+        blob, desc = self.packed()
+        hit = self.__dict__.get("_packed_frags")
+        if hit is None or hit[0] is not blob or hit[1] != M:
+            hit = (blob, M, ops.erwin_frags(blob, desc, M))
+            self.__dict__["_packed_frags"] = hit
+        return hit[2]
 
     # ------------------------------------------------------------------ forward
     def _token_kernel_fits(self, T: int, n_clouds: int) -> bool:
@@ -290,7 +301,8 @@ class ErwinTransformer(nn.Module):
                 train.check_barrier()
         if node_positions is None and not os.environ.get("HAET_NO_TOKEN_STAGE") and ops.token_stage_supported(desc, n_clouds, M):
             out, node_positions = ops.token_stage(node_features, blob, desc, n_clouds, M, self.dimensionality,
-                                                  self.strides, float(self.rotate), train)
+                                                  self.strides, float(self.rotate), train,
+                                                  frags=None if train is not None else self.packed_frags(M))
             self.__dict__["last_positions"] = node_positions if self.__dict__.get("keep_positions", True) else None
             return out
         if node_positions is None:

@@ -242,10 +242,26 @@ def token_stage_supported(desc: "_lib.ErwinDesc", n_clouds: int, M: int) -> bool
     return bool(_lib.load().haet_token_stage_supported(ctypes.byref(desc), n_clouds, M))
 
 
+def erwin_frags(weights: Tensor, desc: "_lib.ErwinDesc", M: int) -> Optional[Tensor]:
+    """The Linear weights of an Erwin stage in MFMA fragment order for the fragment kernel (haet_erwin_frag_pack), or
+    None when (desc, M) is outside that kernel's envelope.  Built on the device from the packed blob; the caller
+    caches it per weight version."""
+    lib = _lib.load()
+    nbytes = lib.haet_erwin_frag_bytes(ctypes.byref(desc), M)
+    if not nbytes:
+        return None
+    frags = torch.empty(nbytes // 4, dtype=torch.float32, device=weights.device)
+    check(lib.haet_erwin_frag_pack(_p(weights), weights.numel(), ctypes.byref(desc), M, _p(frags), nbytes, _stream()),
+          "haet_erwin_frag_pack")
+    return frags
+
+
 def token_stage(S: Tensor, weights: Tensor, desc: "_lib.ErwinDesc", n_clouds: int, M: int, d: int, strides: Sequence[int],
-                angle: float, train: Optional[ErwinTrainState] = None, want_tree: bool = False):
+                angle: float, train: Optional[ErwinTrainState] = None, want_tree: bool = False,
+                frags: Optional[Tensor] = None):
     """haet_token_stage_fwd: positions + ball tree + Erwin in one launch.  Returns (tokens', pos) and, with
-    want_tree, also (tree_idx, tree_mask, rot flat | None, level sizes)."""
+    want_tree, also (tree_idx, tree_mask, rot flat | None, level sizes).  With `frags` (erwin_frags; eval mode, no
+    tape) the launch is the fragment kernel, haet_token_stage_fwd_frag."""
     lib = _lib.load()
     S = _f32(S, "S")
     dev = S.device
@@ -262,9 +278,14 @@ def token_stage(S: Tensor, weights: Tensor, desc: "_lib.ErwinDesc", n_clouds: in
             if i < desc.n_levels - 1:
                 n //= strides[i]
         rot = torch.empty(sum(sizes), dtype=torch.int32, device=dev) if angle > 0 else None
-    check(lib.haet_token_stage_fwd(_p(S), n_clouds, M, float(angle), _p(weights), weights.numel(), ctypes.byref(desc),
-                                   ctypes.byref(train.c) if train is not None else None, _p(pos), _p(tree_idx),
-                                   _p(tree_mask), _p(rot), _p(out), _stream()), "haet_token_stage_fwd")
+    if frags is not None and train is None:
+        check(lib.haet_token_stage_fwd_frag(_p(S), n_clouds, M, float(angle), _p(weights), weights.numel(), _p(frags),
+                                            frags.numel() * 4, ctypes.byref(desc), _p(pos), _p(tree_idx), _p(tree_mask),
+                                            _p(rot), _p(out), _stream()), "haet_token_stage_fwd_frag")
+    else:
+        check(lib.haet_token_stage_fwd(_p(S), n_clouds, M, float(angle), _p(weights), weights.numel(), ctypes.byref(desc),
+                                       ctypes.byref(train.c) if train is not None else None, _p(pos), _p(tree_idx),
+                                       _p(tree_mask), _p(rot), _p(out), _stream()), "haet_token_stage_fwd")
     if want_tree:
         return out, pos, tree_idx, tree_mask, rot, sizes
     return out, pos

@@ -34,8 +34,9 @@
 extern "C" {
 #endif
 
-#define HAET_ABI_VERSION 5  /* 2: + haet_tokens_tree_build, haet_project_split_fwd, haet_*_fwd_split; 4: train-mode
-                             BatchNorm (haet_erwin_train), haet_token_stage_fwd */
+#define HAET_ABI_VERSION 6  /* 2: + haet_tokens_tree_build, haet_project_split_fwd, haet_*_fwd_split; 4: train-mode
+                             BatchNorm (haet_erwin_train), haet_token_stage_fwd; 6: haet_token_stage_fwd_frag (the
+                             fragment kernel), haet_erwin_barrier_status, haet_set_deterministic */
 
 #define HAET_OK 0
 #define HAET_E_ARG (-1)      /* bad argument / unsupported shape */
@@ -249,6 +250,26 @@ int haet_token_stage_fwd(const float* S, int n_clouds, int M, float angle_deg, c
                          size_t weight_floats, const haet_erwin_desc* desc, const haet_erwin_train* train,
                          float* pos_out, int32_t* tree_idx, uint8_t* tree_mask, int32_t* rot, float* out,
                          haet_stream_t stream);
+
+/* The same launch on the FRAGMENT kernel (csrc/erwin2.hip; eval-mode BatchNorm, no tape): a transformer block is two
+ * barrier-separated phases of wave-owned work items -- (32-token tile, head) through q/k/v, ball attention and its
+ * slice of the proj product; (tile, 32 hidden units) through w1/w2, the SwiGLU gate and its slice of the w3 product --
+ * whose operands stay in the wave's registers in the MFMA accumulator layout; only split-K partial sums go through
+ * LDS.  It reads the Linear weights from a second blob laid out in MFMA fragment order for exactly that data flow:
+ *   haet_erwin_frag_bytes   size of that blob for (desc, M), 0 = shape outside the kernel's envelope (head dim 8,
+ *                           32 / 64 channels, 32 | tokens per level, one wave per work item, stride 2, power-of-two
+ *                           clouds <= 64 tokens: BASELINE config C3) -- or HAET_ERWIN_V1 set in the environment;
+ *   haet_erwin_frag_pack    builds it on the device from the packed blob `weights` of haet_erwin_fwd (call once per
+ *                           weight version; stream-ordered, no synchronisation);
+ *   haet_token_stage_fwd_frag  same arguments and results as haet_token_stage_fwd (train = NULL) plus the blob.
+ * `weights` is still read for the small fp32 parameters and the pooling / unpooling Linears. */
+size_t haet_erwin_frag_bytes(const haet_erwin_desc* desc, int M);
+int haet_erwin_frag_pack(const float* weights, size_t weight_floats, const haet_erwin_desc* desc, int M, void* frags,
+                         size_t frag_bytes, haet_stream_t stream);
+int haet_token_stage_fwd_frag(const float* S, int n_clouds, int M, float angle_deg, const float* weights,
+                              size_t weight_floats, const void* frags, size_t frag_bytes, const haet_erwin_desc* desc,
+                              float* pos_out, int32_t* tree_idx, uint8_t* tree_mask, int32_t* rot, float* out,
+                              haet_stream_t stream);
 
 /* ------------------------------------------------------------------ Erwin stage, backward
  * Backward of haet_erwin_fwd / haet_token_stage_fwd (the training scripts call loss.backward(),

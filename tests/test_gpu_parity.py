@@ -240,6 +240,45 @@ def test_token_stage_one_launch(name, hip_device):
 
 
 @pytest.mark.parametrize("name", EVAL_CASES)
+def test_token_stage_fragment_kernel(name, hip_device):
+    """haet_token_stage_fwd_frag (csrc/erwin2.hip: wave-owned (tile, head) / (tile, hidden chunk) work items, operands
+    in the accumulator layout, weights in MFMA fragment order) on the reference's slice tokens: positions, tree and
+    rotated permutations bit-exact, tokens' against the reference's and against the v1 kernel's."""
+    from haet_amd import ops
+
+    x, sd, meta, exp, cfg, tr, _ = _oracle_trace(name)
+    mod = _hip_module(meta, sd, hip_device).eval()
+    blob, desc = mod.erwin.packed()
+    e = cfg.erwin
+    n_clouds, M = x.shape[0] * cfg.heads, cfg.slice_num
+    frags = mod.erwin.packed_frags(M)
+    if frags is None:
+        pytest.skip("shape outside the fragment kernel's envelope (head dim 8, 32 / 64 channels, M in {32, 64}, ...)")
+    assert ops.token_stage_supported(desc, n_clouds, M)
+    S = exp["eidetic_flat"].to(hip_device)
+    out, pos, ti, tm, rot, sizes = ops.token_stage(S, blob, desc, n_clouds, M, e.dimensionality, e.strides,
+                                                   float(e.rotate), None, want_tree=True, frags=frags)
+    assert torch.equal(pos.cpu(), exp["pos"])
+    rots = [exp[f"erwin.rot{j}"].numpy() for j in range(len(e.ball_sizes)) if f"erwin.rot{j}" in exp]
+    _check_tree(ti, tm, rot, sizes, exp["erwin.tree_idx"].numpy(), exp["erwin.tree_mask"].numpy(), rots)
+    assert O.rel_l2(out.cpu(), exp["processed_flat"]) < 5 * FP32_TOL
+    v1, _ = ops.token_stage(S, blob, desc, n_clouds, M, e.dimensionality, e.strides, float(e.rotate), None)
+    assert O.rel_l2(out.cpu(), v1.cpu()) < 5 * FP32_TOL
+    out2, pos2 = ops.token_stage(S, blob, desc, n_clouds, M, e.dimensionality, e.strides, float(e.rotate), None, frags=frags)
+    assert torch.equal(out2, out) and torch.equal(pos2, pos)  # deterministic (fixed summation order of the partials)
+
+
+def test_token_stage_fragment_kernel_covers_c3(hip_device):
+    """BASELINE config C3's Erwin stage (M = 64, 8 heads x 32: levels 64 x 32 and 32 x 64, balls 32 / 16, head dim 8) is
+    inside the fragment kernel's envelope, and the module's eval forward takes it."""
+    from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh
+
+    mod = Physics_Attention_Irregular_Mesh(256, heads=8, dim_head=32, slice_num=64, rotate=45).eval().to(hip_device)
+    assert mod.erwin.packed_frags(64) is not None
+    assert mod.erwin.packed_frags(64) is mod.erwin.packed_frags(64)  # cached per weight version
+
+
+@pytest.mark.parametrize("name", EVAL_CASES)
 def test_deslice_pass_vs_oracle(name, hip_device, kernel_path):
     from haet_amd import ops
 

@@ -52,8 +52,11 @@ def test_timed_kernels_full_size_properties_1m_points(hip_device):
     B, N, H, C, M, D = 1, 1_000_000, 8, 32, 64, 256
     dev = hip_device
     x = torch.randn(B, N, D, device=dev)
-    W_in, b_in = torch.randn(H * C, D) * 0.05, torch.randn(H * C) * 0.1
-    sd = {"in_project_slice.weight": torch.randn(M, C) * 0.3, "in_project_slice.bias": torch.randn(M) * 0.2,
+    # logits of a few units, like trained Transolver weights and the bench's (the split-bf16 logits carry an ABSOLUTE
+    # error of ~|z| 2^-16 inside the exponential: DESIGN.md "precision envelope"; at |z| ~ 15 the eidetic states of this
+    # test read 2e-4 from fp64, still inside north_star's 1e-3)
+    W_in, b_in = torch.randn(H * C, D) * 0.02, torch.randn(H * C) * 0.1
+    sd = {"in_project_slice.weight": torch.randn(M, C) * 0.2, "in_project_slice.bias": torch.randn(M) * 0.2,
           "ada_temp_linear.weight": torch.randn(1, C) * 0.2, "ada_temp_linear.bias": torch.tensor([0.05])}
     cfg = O.AttnCfg(dim=D, heads=H, dim_head=C, slice_num=M)
     sp = _slice_params(sd, cfg, dev)
