@@ -230,6 +230,12 @@ __device__ unsigned long long haet_tree_stamps[32];
 #define TSTAMP(i) do { } while (0)
 #endif
 
+// Workgroup barrier of the builder: waits for this wave's LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter, and the fused callers keep global loads in flight under the builder (the L2 warm-up of the Erwin weights,
+// one slice per level): every level then ended with a wait for HBM.  Everything the builder's waves exchange goes
+// through LDS; its global stores (tree_idx, rot, pos_out) are outputs nobody in the launch reads back.
+__device__ __forceinline__ void w_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // One tree level shared by the `nw` waves w0 .. w0+nw-1, which all hold the same lane arrays: the
 // nodes of a level are independent, so wave i runs the (sequential) introselect of nodes i, i+nw, ...
 // and the waves swap their results through `ex` (double-buffered by `par`: one barrier per level).
@@ -244,7 +250,7 @@ __device__ __forceinline__ void w_shared_level(LaneArr& a, float cx, float cy, f
         for (int j = me; j < nodes; j += nw) w_select_nth(a, j * sz, j * sz + sz / 2, j * sz + sz);
         if (lane < n && (lane / sz) % nw == me) haet_wex[ex + lane] = a.idx;
     }
-    __syncthreads();
+    w_barrier();
     if (work && lane < n) a.idx = haet_wex[ex + lane];
 }
 
@@ -285,32 +291,59 @@ __device__ __forceinline__ void w_tree_build(const WTreeCfg& cfg, const float* _
         // per-channel min / max over ALL tokens itself (T * d floats: a few KB), normalises its own
         // tokens with the formula of token_pos_kernel (bit-identical) and writes them for the Erwin stage.
         const int T = n_clouds * M;
-        for (int j = 0; j < nd; ++j) {
-            float lo = INFINITY, hi = -INFINITY;
+        // one 16-B load per token covers all position channels (rows are 16-B aligned: C % 4 == 0); the wave's own
+        // token rides along, so the whole pass is ONE global round trip (it was one per dimension plus one)
+        typedef __attribute__((ext_vector_type(4))) float f4;
+        typedef const __attribute__((address_space(1))) f4* gf4p;
+        f4 mine = {0.f, 0.f, 0.f, 0.f};
+        float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+        const size_t own = ((size_t)cloud * M + (lane < M ? lane : 0)) * C;
+        if ((C & 3) == 0) {  // (workgroup-uniform)
+            mine = *(gf4p)(S + own);
             for (int t = threadIdx.x; t < T; t += 64 * TW) {
-                const float v = S[(size_t)t * C + j];
-                lo = fminf(lo, v);
-                hi = fmaxf(hi, v);
+                const f4 v = *(gf4p)(S + (size_t)t * C);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    lo3[j] = fminf(lo3[j], v[j]);
+                    hi3[j] = fmaxf(hi3[j], v[j]);
+                }
             }
-            lo = wave_min(lo);
-            hi = wave_max(hi);
+        } else {  // odd widths: scalar loads of the nd position channels
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (j < nd) {
+                    mine[j] = S[own + j];
+                    for (int t = threadIdx.x; t < T; t += 64 * TW) {
+                        const float v = S[(size_t)t * C + j];
+                        lo3[j] = fminf(lo3[j], v);
+                        hi3[j] = fmaxf(hi3[j], v);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float lo = wave_min(lo3[j]), hi = wave_max(hi3[j]);
             if (lane == 0) {
                 mm[wave][0][j] = lo;
                 mm[wave][1][j] = hi;
             }
         }
-        __syncthreads();
+        w_barrier();
         float c3[3] = {0.f, 0.f, 0.f};
-        for (int j = 0; j < nd; ++j) {
-            float lo = mm[0][0][j], hi = mm[0][1][j];
-            for (int w = 1; w < TW; ++w) {
-                lo = fminf(lo, mm[w][0][j]);
-                hi = fmaxf(hi, mm[w][1][j]);
-            }
-            const float rng = hi - lo + 1e-8f;
-            if (lane < M) {
-                c3[j] = (S[((size_t)cloud * M + lane) * C + j] - lo) / rng;
-                if (wave == 0 && pos_out) pos_out[((size_t)cloud * M + lane) * nd + j] = c3[j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j < nd) {
+                float lo = mm[0][0][j], hi = mm[0][1][j];
+                for (int w = 1; w < TW; ++w) {
+                    lo = fminf(lo, mm[w][0][j]);
+                    hi = fmaxf(hi, mm[w][1][j]);
+                }
+                const float rng = hi - lo + 1e-8f;
+                if (lane < M) {
+                    c3[j] = (mine[j] - lo) / rng;
+                    if (wave == 0 && pos_out) pos_out[((size_t)cloud * M + lane) * nd + j] = c3[j];
+                }
             }
         }
         cx = c3[0];

@@ -14,15 +14,19 @@
 // step is then permuted: element j of lane half h is row 16s + 8(j>>2) + 4h + (j&3) -- the weights are re-laid on the
 // host side of this file into exactly that order, one 16-B load per lane and plane: haet_erwin_frag_pack).  V is
 // computed with the operand roles swapped (tokens as A), which lands it transposed -- feature on the lane -- as the
-// PV product wants it.  Nothing but the split-K partial sums and the token state X goes through LDS, and the only
-// workgroup barriers are one per phase plus a cheap one between a phase's loads and its stores (all waves arrive
-// together), 4 per block against ~10 in erwin.hip, with none of its ~50 LDS round trips per block.
+// PV product wants it.  Nothing but the split-K partial sums and the token state X goes through LDS: a phase ends with
+// its partial slabs stored, one barrier, a reduction step in which every thread adds bias + partials into ONE 16-B
+// piece of X (each partial element is read once -- letting every consumer wave sum all slabs itself cost 4-8x the LDS
+// traffic and was the largest part of a phase), and a second barrier: 4 per block against ~10 in erwin.hip, with none
+// of its ~50 LDS round trips per block.
 //
 // Envelope (haet_erwin_frag_bytes != 0): eval-mode BatchNorm, head dim 8, channels 32 or 64, 32 | tokens per level,
 // (tokens / 32) * heads <= 8 and (tokens / 32) * hidden / 32 <= 8 (every item of a phase on its own wave), power-of-two
 // balls <= 32, stride 2, power-of-two clouds <= 64 tokens (the wave tree builder).  BASELINE config C3 (M = 64: 64 x 32
 // and 32 x 64 tokens x channels) is inside; everything else, training (tape, batch statistics) included, stays on
 // erwin.hip.
+#include <cstdlib>
+
 #include "common.h"
 #include "balltree_wave_dev.h"
 
@@ -38,10 +42,28 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef const __attribute__((address_space(1))) u32x4* gv4;
 typedef const __attribute__((address_space(1))) f32x4* gf4;
 
+#ifdef HAET_STAMPS
+// Diagnostic build only (make EXTRA=-DHAET_STAMPS; tools/erwin2_stamps.py): s_memtime at phase boundaries of cloud 0,
+// written to a buffer nothing else reads.  Never quote this build's run time.
+__device__ unsigned long long haet_stamps2[128];
+__device__ int haet_stamp2_op;  // block op whose inner phases are stamped (slots 32..)
+#define STAMP2(i)                                                                       \
+    do {                                                                                \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                      \
+            haet_stamps2[i] = __builtin_amdgcn_s_memtime();                             \
+            haet_stamps2[64 + (i)] = __builtin_amdgcn_s_memrealtime();                  \
+        }                                                                               \
+    } while (0)
+#define PSTAMP(i) do { if (stamp_on) STAMP2(i); } while (0)
+#else
+#define STAMP2(i) do { } while (0)
+#define PSTAMP(i) do { } while (0)
+#endif
+
 constexpr int kThreads = 512;
 constexpr int kMaxOps = 16;
 constexpr int kPad = 4;  // fp32 row padding of the token state (floats)
-enum { OP_BLOCK = 0, OP_FLUSH = 1, OP_POOL = 2, OP_UNPOOL = 3 };
+enum { OP_BLOCK = 0, OP_POOL = 2, OP_UNPOOL = 3 };
 
 __host__ __device__ inline int round32(int k) { return (k + 31) & ~31; }
 
@@ -58,17 +80,27 @@ struct Op {
     int w, b, bn_scale, bn_shift, stride, c2;  // resample: v1 offsets, stride, width of the coarse level
 };
 
+constexpr int kOpInts = sizeof(Op) / 4;
+static_assert(kOpInts <= 64, "an Op is fetched from LDS with one dword per lane");
+
 struct Dir {  // LDS byte offsets
     int X[HAET_ERWIN_MAX_LEVELS], ld[HAET_ERWIN_MAX_LEVELS], n[HAET_ERWIN_MAX_LEVELS], P[HAET_ERWIN_MAX_LEVELS];
-    int rel[HAET_ERWIN_MAX_LEVELS][2], rotm[HAET_ERWIN_MAX_LEVELS], invr[HAET_ERWIN_MAX_LEVELS];
-    int ident, tmap, par[2], slab, total;
+    int rel[HAET_ERWIN_MAX_LEVELS][2], rotm[HAET_ERWIN_MAX_LEVELS];
+    int ident, tmap, par[2], slab, ops, total;
 };
 
-struct Plan {
+// The head travels to the kernel as an argument (scalar registers from the first instruction on); the op table sits
+// behind it in the fragment blob and is copied to LDS once: read from global memory where they are used, the fields of
+// an op were 4-5 DEPENDENT scalar-cache misses at the top of every phase (~1.3k cycles each time).
+struct Head {
     int n_ops, n_levels, d, M, c0, rotate;
     int ball[HAET_ERWIN_MAX_LEVELS], stride[HAET_ERWIN_MAX_LEVELS];
     unsigned frag_begin, total_bytes;
+    unsigned v1_lo, v1_bytes;  // byte range of the v1 blob that holds the pooling / unpooling Linears (L2 warm-up)
     Dir dir;
+};
+struct Plan {
+    Head h;
     Op ops[kMaxOps];
 };
 constexpr unsigned kPlanBytes = (sizeof(Plan) + 1023) & ~1023u;
@@ -119,17 +151,23 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 __device__ __forceinline__ u32x4 ldg16(const char* p) { return *(gv4)p; }
 
-// What the previous phase left to be added to X before anyone may use it: a bias row and `np` partial slabs per
-// 32-token tile, written in the PREVIOUS phase's place order (`inv` maps a token to its place there).
-struct Pending {
-    int np, bias, inv;  // np = 0: nothing pending; bias, inv: LDS byte offsets
-};
+// op `oi` of the table in LDS: one dword per lane; a field is one v_readlane where it is used (OF), so that no phase
+// keeps 41 scalars alive
+__device__ __forceinline__ int fetch_op(int opsL, int oi) {
+    const int lane = threadIdx.x & 63;
+    return I(opsL + 4 * (oi * kOpInts + min(lane, kOpInts - 1)));
+}
+#define OF(field) __builtin_amdgcn_readlane(opf, offsetof(Op, field) / 4)
+// the LDS directory the same way: one dword per lane for the kernel's lifetime (39 scalars otherwise, most of them
+// spilled), DF(field) / DFI(array, i) = one v_readlane
+#define DF(field) __builtin_amdgcn_readlane(dirf, offsetof(Dir, field) / 4)
+#define DFI(field, i) __builtin_amdgcn_readlane(dirf, offsetof(Dir, field) / 4 + (i))
+static_assert(sizeof(Dir) / 4 <= 64, "the directory is held with one dword per lane");
 
 // x (accumulator layout: lane = (token place p, half hf), register 4q+i of tile nc = channel 32nc + 8q + 4hf + i) of
-// token `tau` = X[tau] + pending
+// token `tau`
 template <int NC>
-__device__ __forceinline__ void load_x(f32x16 (&x)[NC], int X, int ld, int tau, int hf, const Pending& pd, int slab) {
-    constexpr int slabB = NC * 4096;
+__device__ __forceinline__ void load_x(f32x16 (&x)[NC], int X, int ld, int tau, int hf) {
     const int xrow = X + 4 * (tau * ld + 4 * hf);
 #pragma unroll
     for (int nc = 0; nc < NC; ++nc)
@@ -139,39 +177,23 @@ __device__ __forceinline__ void load_x(f32x16 (&x)[NC], int X, int ld, int tau, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[nc][4 * q + i] = v[i];
         }
-    if (pd.np) {  // (wave-uniform)
-        const int pp = I(pd.inv + 4 * tau);
-        const int sl = slab + (pp >> 5) * pd.np * slabB + ((pp & 31) + 32 * hf) * 16;
-#pragma unroll
-        for (int nc = 0; nc < NC; ++nc)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b = F4(pd.bias + 4 * (32 * nc + 8 * q + 4 * hf));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) x[nc][4 * q + i] += b[i];
-            }
-        for (int k = 0; k < pd.np; ++k) {
-#pragma unroll
-            for (int nc = 0; nc < NC; ++nc)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = F4(sl + k * slabB + (nc * 4 + q) * 1024);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) x[nc][4 * q + i] += v[i];
-                }
-        }
-    }
 }
-template <int NC>
-__device__ __forceinline__ void store_x(const f32x16 (&x)[NC], int X, int ld, int tau, int hf) {
-    const int xrow = X + 4 * (tau * ld + 4 * hf);
-#pragma unroll
-    for (int nc = 0; nc < NC; ++nc)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = {x[nc][4 * q], x[nc][4 * q + 1], x[nc][4 * q + 2], x[nc][4 * q + 3]};
-            F4(xrow + 4 * (32 * nc + 8 * q)) = v;
-        }
+// End of a phase: X[token at place] += bias + the `np` partial slabs of its tile (fixed order), one 16-B piece of X per
+// thread and step; a wave reads 64 consecutive lanes of one slab row (1 KB, conflict-free).  Barriers on both sides.
+__device__ __forceinline__ void reduce_phase(const int tid, const int dirf, int l, int c, int np, int bias, int perm) {
+    lds_barrier();
+    const int n = DFI(n, l), ld = DFI(ld, l), X = DFI(X, l), ncl = c >> 5, slabB = ncl * 4096;
+    for (int idx = tid; idx < n * (c >> 2); idx += kThreads) {
+        const int ln = idx & 63, combo = idx >> 6, q = combo & 3, rest = combo >> 2;
+        const int tile = rest / ncl, nc = rest - tile * ncl;
+        const int tau = I(perm + 4 * (32 * tile + (ln & 31)));
+        const int ch = 32 * nc + 8 * q + 4 * (ln >> 5);
+        const int sl = DF(slab) + tile * np * slabB + (nc * 4 + q) * 1024 + ln * 16;
+        f32x4 v = F4(X + 4 * (tau * ld + ch)) + F4(bias + 4 * ch);
+        for (int k = 0; k < np; ++k) v += F4(sl + k * slabB);
+        F4(X + 4 * (tau * ld + ch)) = v;
+    }
+    lds_barrier();
 }
 template <int NC>
 __device__ __forceinline__ void store_slab(const f32x16 (&y)[NC], int slab, int item, int lane) {
@@ -207,48 +229,50 @@ __device__ __forceinline__ void split_tiles(const f32x16 (&x)[NC], u32x4 (&xh)[N
 // ---------------------------------------------------------------------------------------------------------------------
 // attention phase of a block: BallMSA up to the proj product's split-K partials (attention.py:58-88)
 template <int NC>
-__device__ __forceinline__ void attn_phase(const Op& op, const Dir& D, const char* __restrict__ FR, int d, const Pending& pd) {
+__device__ __forceinline__ void attn_phase(const int tid, const int opf, const int dirf, const char* __restrict__ FR, unsigned frag_bytes,
+                                           int d, bool stamp_on) {
     constexpr int KS = 2 * NC;
-    const int lane = threadIdx.x & 63, p = lane & 31, hf = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int heads = op.heads, l = op.lvl, c = op.c;
-    const int nitems = (op.n >> 5) * heads;
+    PSTAMP(32);
+    const int lane = tid & 63, p = lane & 31, hf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int heads = OF(heads), l = OF(lvl), c = OF(c);
+    const int nitems = (OF(n) >> 5) * heads;
     const bool active = wave < nitems;
     const int item = active ? wave : nitems - 1;  // idle waves shadow the last item (no stores): one code path
     const int T = item / heads, h = item - T * heads;
     // weight fragments of this item: requested first, consumed after the token state is ready
     u32x4 wqk[KS][2], wv[KS][2], wp[NC][2];
+    const char* bp = FR + OF(pj) + (size_t)h * (NC * 2048) + lane * 16;
     {
-        const char* bq = FR + op.qk + (size_t)(h >> 1) * (KS * 2048) + (((p + 16 * (h & 1)) & 31) + 32 * hf) * 16;
-        const char* bv = FR + op.v + (size_t)(h >> 2) * (KS * 2048) + (((p + 8 * (h & 3)) & 31) + 32 * hf) * 16;
-        const char* bp = FR + op.pj + (size_t)h * (NC * 2048) + lane * 16;
+        // The QK tile holds a head PAIR and the V tile a head QUAD (dense bytes in HBM); this item uses 16 / 8 of the 32
+        // rows.  The other lanes' offsets are pushed out of the buffer's range: the hardware returns zeros for them and
+        // fetches nothing -- half / three quarters of the phase's L2 -> CU bytes were rows nobody used.
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(FR), 0, (int)frag_bytes, 0x00020000);
+        const unsigned oq = p < 16 ? OF(qk) + (unsigned)(h >> 1) * (KS * 2048) + (((p + 16 * (h & 1)) & 31) + 32 * hf) * 16 : 0xfffff000u;
+        const unsigned ov = p < 8 ? OF(v) + (unsigned)(h >> 2) * (KS * 2048) + (((p + 8 * (h & 3)) & 31) + 32 * hf) * 16 : 0xfffff000u;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
-                wqk[s][pl] = ldg16(bq + (s * 2 + pl) * 1024);
-                wv[s][pl] = ldg16(bv + (s * 2 + pl) * 1024);
+                wqk[s][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, oq, (s * 2 + pl) * 1024, 0);
+                wv[s][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, ov, (s * 2 + pl) * 1024, 0);
             }
-#pragma unroll
-        for (int nc = 0; nc < NC; ++nc)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) wp[nc][pl] = ldg16(bp + (nc * 2 + pl) * 1024);
     }
-    const int perm = op.rot ? D.rotm[l] : D.ident;
+    const int perm = OF(rot) ? DFI(rotm, l) : DF(ident);
     const int tau = I(perm + 4 * (32 * T + p));
     f32x16 x[NC];
-    load_x<NC>(x, D.X[l], D.ld[l], tau, hf, pd, D.slab);
+    load_x<NC>(x, DFI(X, l), DFI(ld, l), tau, hf);
     float rl[3] = {0.f, 0.f, 0.f};
     {
-        const int rel = D.rel[l][op.rot ? 1 : 0] + 4 * tau * d;
+        const int rel = DFI(rel, 2 * (l) + (OF(rot) ? 1 : 0)) + 4 * tau * d;
         rl[0] = F(rel);
         rl[1] = F(rel + 4);
         if (d > 2) rl[2] = F(rel + 8);
     }
-    lds_barrier();  // every wave has read X and the pending slabs: both may be overwritten from here on
-    if (active && h == 0 && pd.np) store_x<NC>(x, D.X[l], D.ld[l], tau, hf);
+    PSTAMP(33);
+    PSTAMP(34);
     // x~ = RMSNorm(x) * w + pe_b + rel . pe_w                  (attention.py:59-61)
-    const int par = D.par[op.pbuf] - 4 * op.small_off;  // par + 4 * <v1 blob offset> addresses the LDS copy
+    const int par = DFI(par, OF(pbuf)) - 4 * OF(small_off);  // par + 4 * <v1 blob offset> addresses the LDS copy
     {
         const float rinv = rms_inv<NC>(x, c);
 #pragma unroll
@@ -256,17 +280,25 @@ __device__ __forceinline__ void attn_phase(const Op& op, const Dir& D, const cha
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int ch = 32 * nc + 8 * q + 4 * hf;
-                const f32x4 w = F4(par + 4 * (op.norm1 + ch));
-                f32x4 pe = F4(par + 4 * (op.pe_b + ch));
-                pe += rl[0] * F4(par + 4 * (op.pe_w + ch));
-                pe += rl[1] * F4(par + 4 * (op.pe_w + c + ch));
-                if (d > 2) pe += rl[2] * F4(par + 4 * (op.pe_w + 2 * c + ch));
+                const f32x4 w = F4(par + 4 * (OF(norm1) + ch));
+                f32x4 pe = F4(par + 4 * (OF(pe_b) + ch));
+                pe += rl[0] * F4(par + 4 * (OF(pe_w) + ch));
+                pe += rl[1] * F4(par + 4 * (OF(pe_w) + c + ch));
+                if (d > 2) pe += rl[2] * F4(par + 4 * (OF(pe_w) + 2 * c + ch));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x[nc][4 * q + i] = x[nc][4 * q + i] * rinv * w[i] + pe[i];
             }
     }
     u32x4 xh[NC][2], xl[NC][2];
     split_tiles<NC>(x, xh, xl);
+    PSTAMP(35);
+    // (the proj fragments are requested here: the softmax and the PV product cover their latency, and they do not sit in
+    // registers through the norm)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) wp[nc][pl] = ldg16(bp + (nc * 2 + pl) * 1024);
     // rows 0-7 q of my head, rows 8-15 k (the lane's tile rows are rotated so that my head comes first)
     f32x16 qk = zero16(), vt = zero16();
 #pragma unroll
@@ -279,18 +311,19 @@ __device__ __forceinline__ void attn_phase(const Op& op, const Dir& D, const cha
     f32x16 S;
     {
         const float qscale = 1.4426950408889634f * 0.35355339059327373f;  // log2(e) / sqrt(8): softmax in base 2
-        const f32x4 bq = F4(par + 4 * (op.qkv_b + 8 * h + 4 * hf)), bk = F4(par + 4 * (op.qkv_b + c + 8 * h + 4 * hf));
+        const f32x4 bq = F4(par + 4 * (OF(qkv_b) + 8 * h + 4 * hf)), bk = F4(par + 4 * (OF(qkv_b) + c + 8 * h + 4 * hf));
         u32x4 qh, ql, kh, kl;
         quad_frag((qk[0] + bq[0]) * qscale, (qk[1] + bq[1]) * qscale, (qk[2] + bq[2]) * qscale, (qk[3] + bq[3]) * qscale, qh, ql);
         quad_frag(qk[4] + bk[0], qk[5] + bk[1], qk[6] + bk[2], qk[7] + bk[3], kh, kl);
         S = mfma3(kh, kl, qh, ql, zero16());  // S[key][query]: lane = query, registers = keys
     }
     {
-        const float bv = F(par + 4 * (op.qkv_b + 2 * c + 8 * h + (p & 7)));
+        const float bv = F(par + 4 * (OF(qkv_b) + 2 * c + 8 * h + (p & 7)));
 #pragma unroll
         for (int r = 0; r < 16; ++r) vt[r] += bv;  // (lanes >= 8 hold other heads' features: never used)
     }
-    const int bmask = 31 & ~(op.ball - 1);
+    PSTAMP(36);
+    const int bmask = 31 & ~(OF(ball) - 1);
     float m = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -306,6 +339,7 @@ __device__ __forceinline__ void attn_phase(const Op& op, const Dir& D, const cha
         lsum += S[r];
     }
     lsum += __shfl_xor(lsum, 32);
+    PSTAMP(37);
     f32x16 O = zero16();
     {
         u32x4 vh, vl, ph, pl;
@@ -324,26 +358,28 @@ __device__ __forceinline__ void attn_phase(const Op& op, const Dir& D, const cha
 #pragma unroll
         for (int nc = 0; nc < NC; ++nc) y[nc] = mfma3(wp[nc][0], wp[nc][1], oh, ol, zero16());
     }
-    if (active) store_slab<NC>(y, D.slab, item, lane);
-    lds_barrier();
+    PSTAMP(38);
+    if (active) store_slab<NC>(y, DF(slab), item, lane);
+    reduce_phase(tid, dirf, l, c, heads, par + 4 * OF(proj_b), perm);  // x += proj(attention) + b
+    PSTAMP(39);
 }
 
 // MLP phase of a block: x += proj(...) (completing the attention), then SwiGLU up to the w3 product's split-K partials
 template <int NC>
-__device__ __forceinline__ void mlp_phase(const Op& op, const Dir& D, const char* __restrict__ FR, const float* __restrict__ W) {
+__device__ __forceinline__ void mlp_phase(const int tid, const int opf, const int dirf, const char* __restrict__ FR, const float* __restrict__ W,
+                                          bool stamp_on) {
     constexpr int KS = 2 * NC;
-    const int lane = threadIdx.x & 63, p = lane & 31, hf = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int chunks = op.chunks, l = op.lvl, c = op.c;
-    const int nitems = (op.n >> 5) * chunks;
+    const int lane = tid & 63, p = lane & 31, hf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunks = OF(chunks), l = OF(lvl), c = OF(c);
+    const int nitems = (OF(n) >> 5) * chunks;
     const bool active = wave < nitems;
     const int item = active ? wave : nitems - 1;
     const int T = item / chunks, j = item - T * chunks;
     u32x4 w1[KS][2], w2[KS][2], w3[NC][2][2];
     {
-        const char* b1 = FR + op.w1 + (size_t)j * (KS * 2048) + lane * 16;
-        const char* b2 = FR + op.w2 + (size_t)j * (KS * 2048) + lane * 16;
-        const char* b3 = FR + op.w3 + (size_t)j * (NC * 4096) + lane * 16;
+        const char* b1 = FR + OF(w1) + (size_t)j * (KS * 2048) + lane * 16;
+        const char* b2 = FR + OF(w2) + (size_t)j * (KS * 2048) + lane * 16;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -351,46 +387,17 @@ __device__ __forceinline__ void mlp_phase(const Op& op, const Dir& D, const char
                 w1[s][pl] = ldg16(b1 + (s * 2 + pl) * 1024);
                 w2[s][pl] = ldg16(b2 + (s * 2 + pl) * 1024);
             }
-#pragma unroll
-        for (int nc = 0; nc < NC; ++nc)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) w3[nc][s][pl] = ldg16(b3 + ((nc * 2 + s) * 2 + pl) * 1024);
     }
-    const int perm = op.rot ? D.rotm[l] : D.ident;
+    const int perm = OF(rot) ? DFI(rotm, l) : DF(ident);
     const int tau = I(perm + 4 * (32 * T + p));
-    const int par = D.par[op.pbuf] - 4 * op.small_off;
+    const int par = DFI(par, OF(pbuf)) - 4 * OF(small_off);
     f32x16 x[NC];
-    {
-        const Pending pd = {op.heads, par + 4 * op.proj_b, D.ident};  // the heads' partials, in this block's own place order
-        // (place -> place: the identity map; the token's place is 32T + p)
-        const int xrow = D.X[l] + 4 * (tau * D.ld[l] + 4 * hf);
-        const int sl = D.slab + T * pd.np * (NC * 4096) + lane * 16;
-#pragma unroll
-        for (int nc = 0; nc < NC; ++nc)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = F4(xrow + 4 * (32 * nc + 8 * q)) + F4(pd.bias + 4 * (32 * nc + 8 * q + 4 * hf));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) x[nc][4 * q + i] = v[i];
-            }
-        for (int k = 0; k < pd.np; ++k) {
-#pragma unroll
-            for (int nc = 0; nc < NC; ++nc)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = F4(sl + k * (NC * 4096) + (nc * 4 + q) * 1024);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) x[nc][4 * q + i] += v[i];
-                }
-        }
-    }
-    lds_barrier();
-    if (active && j == 0) store_x<NC>(x, D.X[l], D.ld[l], tau, hf);
-    if (op.next_len) {  // the next block's small parameters into the other buffer (its attention phase reads them)
-        const int dst = D.par[op.pbuf ^ 1];
-        for (int i = threadIdx.x * 4; i < op.next_len; i += kThreads * 4) F4(dst + 4 * i) = *(gf4)(W + op.next_off + i);
+    load_x<NC>(x, DFI(X, l), DFI(ld, l), tau, hf);
+    PSTAMP(40);
+    PSTAMP(41);
+    if (OF(next_len)) {  // the next block's small parameters into the other buffer (its attention phase reads them)
+        const int dst = DFI(par, OF(pbuf) ^ 1);
+        for (int i = tid * 4; i < OF(next_len); i += kThreads * 4) F4(dst + 4 * i) = *(gf4)(W + OF(next_off) + i);
     }
     {
         const float rinv = rms_inv<NC>(x, c);
@@ -398,13 +405,24 @@ __device__ __forceinline__ void mlp_phase(const Op& op, const Dir& D, const char
         for (int nc = 0; nc < NC; ++nc)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 w = F4(par + 4 * (op.norm2 + 32 * nc + 8 * q + 4 * hf));
+                const f32x4 w = F4(par + 4 * (OF(norm2) + 32 * nc + 8 * q + 4 * hf));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x[nc][4 * q + i] = x[nc][4 * q + i] * rinv * w[i];
             }
     }
     u32x4 xh[NC][2], xl[NC][2];
     split_tiles<NC>(x, xh, xl);
+    PSTAMP(42);
+    __builtin_amdgcn_sched_barrier(0);
+    {   // (requested here: the w1 / w2 products and the gate cover their latency)
+        const char* b3 = FR + OF(w3) + (size_t)j * (NC * 4096) + lane * 16;
+#pragma unroll
+        for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) w3[nc][s][pl] = ldg16(b3 + ((nc * 2 + s) * 2 + pl) * 1024);
+    }
     f32x16 h1 = zero16(), h2 = zero16();
 #pragma unroll
     for (int nc = 0; nc < NC; ++nc)
@@ -413,10 +431,11 @@ __device__ __forceinline__ void mlp_phase(const Op& op, const Dir& D, const char
             h1 = mfma3(w1[2 * nc + s][0], w1[2 * nc + s][1], xh[nc][s], xl[nc][s], h1);
             h2 = mfma3(w2[2 * nc + s][0], w2[2 * nc + s][1], xh[nc][s], xl[nc][s], h2);
         }
+    PSTAMP(43);
     // g = w2(x^) * silu(w1(x^))                                (mlp.py:17-18)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 b1 = F4(par + 4 * (op.w1_b + 32 * j + 8 * q + 4 * hf)), b2 = F4(par + 4 * (op.w2_b + 32 * j + 8 * q + 4 * hf));
+        const f32x4 b1 = F4(par + 4 * (OF(w1_b) + 32 * j + 8 * q + 4 * hf)), b2 = F4(par + 4 * (OF(w2_b) + 32 * j + 8 * q + 4 * hf));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float v = h1[4 * q + i] + b1[i];
@@ -424,6 +443,7 @@ __device__ __forceinline__ void mlp_phase(const Op& op, const Dir& D, const char
             h1[4 * q + i] = (h2[4 * q + i] + b2[i]) * (v * sig);
         }
     }
+    PSTAMP(44);
     f32x16 y[NC];
     {
         u32x4 gh0, gl0, gh1, gl1;
@@ -435,88 +455,93 @@ __device__ __forceinline__ void mlp_phase(const Op& op, const Dir& D, const char
             y[nc] = mfma3(w3[nc][1][0], w3[nc][1][1], gh1, gl1, y[nc]);
         }
     }
-    if (active) store_slab<NC>(y, D.slab, item, lane);
-    lds_barrier();
-}
-
-// X += pending, for every token of the level (before a pool / unpool / the output reads X as plain rows)
-__device__ __forceinline__ void flush_level(const Dir& D, int l, int c, const Pending& pd) {
-    if (pd.np) {
-        const int n = D.n[l], ld = D.ld[l], X = D.X[l], c4 = c >> 2, nc_l = c >> 5;
-        const int slabB = nc_l * 4096;
-        for (int idx = threadIdx.x; idx < n * c4; idx += kThreads) {
-            const int tau = idx / c4, g = idx - tau * c4;
-            const int pp = I(pd.inv + 4 * tau);
-            const int sl = D.slab + (pp >> 5) * pd.np * slabB + (((g >> 3) * 4 + ((g & 7) >> 1)) * 64 + (pp & 31) + 32 * (g & 1)) * 16;
-            f32x4 v = F4(X + 4 * (tau * ld + 4 * g)) + F4(pd.bias + 16 * g);
-            for (int k = 0; k < pd.np; ++k) v += F4(sl + k * slabB);
-            F4(X + 4 * (tau * ld + 4 * g)) = v;
-        }
-    }
-    lds_barrier();
+    PSTAMP(45);
+    if (active) store_slab<NC>(y, DF(slab), item, lane);
+    reduce_phase(tid, dirf, l, c, chunks, par + 4 * OF(w3_b), perm);  // x += w3(...) + b
+    PSTAMP(46);
 }
 
 // BallPooling (pooling.py:25-40, eval BatchNorm folded) level l -> l+1 and BallUnpooling (pooling.py:58-72) l+1 -> l:
 // item = (32 coarse tokens, 32 outputs); rows are built in registers in natural k order, the weights are the v1 blob's
 // [out][K~] bf16 planes.
 template <bool UNPOOL>
-__device__ __forceinline__ void resample(const Op& op, const Dir& D, const float* __restrict__ W, int d) {
-    const int lane = threadIdx.x & 63, p = lane & 31, hf = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int l = op.lvl, st = op.stride, c = op.c, c2 = op.c2;
-    const int n2 = D.n[l + 1];
+__device__ __forceinline__ void resample(const int tid, const int opf, const int dirf, const float* __restrict__ W, int d) {
+    const int lane = tid & 63, p = lane & 31, hf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = OF(lvl), st = OF(stride), c = OF(c), c2 = OF(c2);
+    const int n2 = DFI(n, l + 1);
     const int K = UNPOOL ? c2 + st * d : st * c + st * d, Kp = round32(K), Oc = UNPOOL ? st * c : c2;
-    const int X0 = D.X[l], ld0 = D.ld[l], X1 = D.X[l + 1], ld1 = D.ld[l + 1], P0 = D.P[l], P1 = D.P[l + 1];
-    const int ksteps = (K + 15) >> 4, otiles = Oc >> 5, nitems = (n2 >> 5) * otiles;
-    const unsigned short* Wh = reinterpret_cast<const unsigned short*>(W + op.w);
+    const int X0 = DFI(X, l), ld0 = DFI(ld, l), X1 = DFI(X, l + 1), ld1 = DFI(ld, l + 1), P0 = DFI(P, l), P1 = DFI(P, l + 1);
+    const int otiles = Oc >> 5, nitems = (n2 >> 5) * otiles;
+    const int lc = c == 64 ? 6 : 5;
+    const unsigned short* Wh = reinterpret_cast<const unsigned short*>(W + OF(w));
     const size_t plane = (size_t)Oc * Kp;
+    // k-steps 0 .. kf-1 are token features (two 16-B LDS reads per lane), k-step kf holds the st * d relative positions
+    // (built element by element: ONE instance of that code, not one per unrolled step -- it was 1100 vector instructions)
+    constexpr int KF = 4;  // feature k-steps held in registers (<= 64 feature columns: make_plan)
+    const int feat = UNPOOL ? c2 : st * c, kf = feat >> 4;
     for (int item = wave; item < nitems; item += kThreads / 64) {
         const int Tt = item / otiles, ot = item - Tt * otiles;
         const int pt = 32 * Tt + p;  // coarse token of this lane
         const unsigned short* wrow = Wh + (size_t)(32 * ot + p) * Kp + 8 * hf;
+        u32x4 ah[KF], al[KF];
+#pragma unroll
+        for (int ks = 0; ks < KF; ++ks) {  // all requested up front (clamped: unconditional loads)
+            const int kk = 16 * min(ks, kf - 1);
+            ah[ks] = *(gv4)(wrow + kk);
+            al[ks] = *(gv4)(wrow + plane + kk);
+        }
+        const u32x4 rh = *(gv4)(wrow + 16 * kf), rl = *(gv4)(wrow + plane + 16 * kf);
+        // bias and folded BatchNorm of this lane's outputs: requested now, used after the product
+        f32x4 eb[4], esc[4], esh[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o4 = 32 * ot + 8 * q + 4 * hf, ch = UNPOOL ? (o4 & (c - 1)) : o4;
+            eb[q] = *(gf4)(W + OF(b) + o4);
+            esc[q] = *(gf4)(W + OF(bn_scale) + ch);
+            esh[q] = *(gf4)(W + OF(bn_shift) + ch);
+        }
         f32x16 acc = zero16();
-        for (int ks = 0; ks < ksteps; ++ks) {
-            const u32x4 ah = *(gv4)(wrow + 16 * ks), al = *(gv4)(wrow + plane + 16 * ks);
-            const int k0 = 16 * ks + 8 * hf;
+        {   // relative positions of the children (pooling.py:30-35,60-63): k = feat + child * d + dim
             float v[8];
-            const int feat = UNPOOL ? c2 : st * c;  // the first `feat` k are token features, the rest relative positions
-            if (k0 + 8 <= feat) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int r = 8 * hf + jj;
+                float t = 0.f;
+                if (r < st * d) {
+                    const int child = r >= d ? 1 : 0, dim = r - child * d;  // (stride 2)
+                    t = F(P0 + 4 * ((pt * st + child) * d + dim)) - F(P1 + 4 * (pt * d + dim));
+                }
+                v[jj] = t;
+            }
+            u32x4 bh, bl;
+            split8(v, bh, bl);
+            acc = mfma3(rh, rl, bh, bl, acc);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KF; ++ks) {
+            if (ks < kf) {  // (wave-uniform)
+                const int k0 = 16 * ks + 8 * hf;
                 int src;
                 if (UNPOOL) {
                     src = X1 + 4 * (pt * ld1 + k0);
                 } else {
-                    const int child = k0 / c, ch = k0 - child * c;
+                    const int child = k0 >> lc, ch = k0 & (c - 1);  // (c is 32 or 64)
                     src = X0 + 4 * ((pt * st + child) * ld0 + ch);
                 }
                 const f32x4 a = F4(src), b = F4(src + 16);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = a[i];
-                    v[4 + i] = b[i];
-                }
-            } else {
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const int r = k0 + jj - feat;
-                    float t = 0.f;
-                    if (r >= 0 && r < st * d) {
-                        const int child = r / d, dim = r - child * d;
-                        t = F(P0 + 4 * ((pt * st + child) * d + dim)) - F(P1 + 4 * (pt * d + dim));
-                    }
-                    v[jj] = t;
-                }
+                const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                u32x4 bh, bl;
+                split8(v, bh, bl);
+                acc = mfma3(ah[ks], al[ks], bh, bl, acc);
             }
-            u32x4 bh, bl;
-            split8(v, bh, bl);
-            acc = mfma3(ah, al, bh, bl, acc);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int o4 = 32 * ot + 8 * q + 4 * hf;
-            const f32x4 b = *(gf4)(W + op.b + o4);
+            const f32x4 b = eb[q], sc = esc[q], sh = esh[q];
             if (UNPOOL) {
-                const int child = o4 / c, ch = o4 - child * c;
-                const f32x4 sc = *(gf4)(W + op.bn_scale + ch), sh = *(gf4)(W + op.bn_shift + ch);
+                const int child = o4 >> lc, ch = o4 & (c - 1);
                 const int dst = X0 + 4 * ((pt * st + child) * ld0 + ch);
                 const f32x4 old = F4(dst);
                 f32x4 yv;
@@ -524,7 +549,6 @@ __device__ __forceinline__ void resample(const Op& op, const Dir& D, const float
                 for (int i = 0; i < 4; ++i) yv[i] = (old[i] + acc[4 * q + i] + b[i]) * sc[i] + sh[i];
                 F4(dst) = yv;
             } else {
-                const f32x4 sc = *(gf4)(W + op.bn_scale + o4), sh = *(gf4)(W + op.bn_shift + o4);
                 f32x4 yv;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) yv[i] = (acc[4 * q + i] + b[i]) * sc[i] + sh[i];
@@ -532,7 +556,7 @@ __device__ __forceinline__ void resample(const Op& op, const Dir& D, const float
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // rel[tok] = P[tok] - mean over its ball (attention.py:35-40); ball b = places [b*ball, ..) of `perm`; power-of-two balls
@@ -549,102 +573,129 @@ __device__ __forceinline__ void ball_rel(int P, int n, int d, int ball, int perm
     }
 }
 
-constexpr int kWarm = 8;  // 16-B loads per thread per builder step of the L2 warm-up
+constexpr int kWarm = 8;  // 16-B loads per thread per builder step of the L2 warm-up (64 KB per step and workgroup)
 
 __global__ __launch_bounds__(kThreads) void erwin2_kernel(const float* __restrict__ tokens, int32_t* __restrict__ tree_idx,
                                                          uint8_t* __restrict__ tree_mask, int32_t* __restrict__ rot,
                                                          const float* __restrict__ W, const char* __restrict__ FR,
-                                                         float* __restrict__ out, WTreeCfg tcfg, float* __restrict__ pos_out) {
-    const Plan& PL = *reinterpret_cast<const Plan*>(FR);
-    const Dir& D = PL.dir;
+                                                         float* __restrict__ out, WTreeCfg tcfg, float* __restrict__ pos_out,
+                                                         Head PL, int warm) {
+    STAMP2(0);
+    const int dirf_all = reinterpret_cast<const int*>(FR + offsetof(Plan, h) + offsetof(Head, dir))[min((int)(threadIdx.x & 63), (int)(sizeof(Dir) / 4) - 1)];
+    const int dirf = dirf_all;
     const int cloud = blockIdx.x, n_clouds = gridDim.x, d = PL.d, nl = PL.n_levels, M = PL.M, c0 = PL.c0;
+    for (int i = threadIdx.x; i < PL.n_ops * kOpInts; i += kThreads)  // the op table (visible after the builder's barriers)
+        I(DF(ops) + 4 * i) = reinterpret_cast<const int*>(FR + offsetof(Plan, ops))[i];
     {
-        const WTreeLds sink = {D.tmap, D.P[0], {D.rotm[0], D.rotm[1], D.rotm[2], D.rotm[3]}};
-        // L2 warm-up under the builder's latency chain (the weight fragments have been evicted by the streaming kernels
-        // since the last forward): step i folds what step i-1 requested into a checksum nothing reads, then requests
+        const WTreeLds sink = {DF(tmap), DFI(P, 0), {DFI(rotm, 0), DFI(rotm, 1), DFI(rotm, 2), DFI(rotm, 3)}};
+        // Optional L2 warm-up under the builder's latency chain (HAET_ERWIN_WARM=1; OFF by default: this kernel requests a
+        // phase's fragments a whole phase ahead, and with the warm-up the builder ran 8-20k cycles longer for blocks that
+        // were not a cycle faster): step i folds what step i-1 requested into a checksum nothing reads, then requests
         // its own pieces -- unconditional, clamped addresses
         u32x4 pend[kWarm];
         unsigned sink_x = 0;
-        const unsigned pieces = PL.total_bytes >> 4;
+        const unsigned pieces = PL.total_bytes >> 4, pieces1 = PL.v1_bytes >> 4;
+        const char* W1 = reinterpret_cast<const char*>(W) + PL.v1_lo;
 #pragma unroll
         for (int k = 0; k < kWarm; ++k) pend[k] = u32x4{0u, 0u, 0u, 0u};
-        auto step = [&](int i) {
+        auto step = [&](int i) {  // pieces 0 .. pieces-1: the fragment blob; then the resample Linears of the v1 blob
+            if (!warm) return;  // (uniform)
 #pragma unroll
             for (int k = 0; k < kWarm; ++k) sink_x ^= pend[k][0];
             const unsigned base = (unsigned)i * (kThreads * kWarm) + threadIdx.x;
 #pragma unroll
-            for (int k = 0; k < kWarm; ++k) pend[k] = ((gv4)FR)[min(base + (unsigned)k * kThreads, pieces - 1)];
+            for (int k = 0; k < kWarm; ++k) {
+                const unsigned pc = base + (unsigned)k * kThreads;
+                const bool second = pc >= pieces;  // (a select between two addresses, not a branch around the load)
+                const char* src = second ? W1 + (size_t)min(pc - pieces, pieces1 - 1) * 16 : FR + (size_t)pc * 16;
+                pend[k] = *(gv4)src;
+            }
         };
         w_tree_build(tcfg, nullptr, tokens, c0, cloud, n_clouds, tree_idx, tree_mask, rot, pos_out, sink, step);
 #pragma unroll
         for (int k = 0; k < kWarm; ++k) sink_x ^= pend[k][0];
         asm volatile("" ::"v"(sink_x));
     }
-    __syncthreads();
-    // the cloud in tree order (erwin_flash.py:176-181), index maps, pooled positions, first block's parameters
+    lds_barrier();
+    STAMP2(1);
+    // the cloud in tree order (erwin_flash.py:176-181), the first block's parameters: requested from HBM now, parked in
+    // LDS after the position work below has covered their latency (<= 2 x 16 B per thread: M * c0 <= 4096)
+    const int ng = M * (c0 >> 2);
+    int first_off, first_len, first_pbuf;
     {
-        const int X0 = D.X[0], ld0 = D.ld[0];
-        for (int i = threadIdx.x; i < M * (c0 >> 2); i += kThreads) {
-            const int slot = i / (c0 >> 2), g = i - slot * (c0 >> 2);
-            F4(X0 + 4 * (slot * ld0 + 4 * g)) = *(gf4)(tokens + ((size_t)cloud * M + I(D.tmap + 4 * slot)) * c0 + 4 * g);
-        }
-        for (int i = threadIdx.x; i < M; i += kThreads) I(D.ident + 4 * i) = i;
-        if (PL.rotate)
-            for (int l = 0; l < nl; ++l)
-                for (int i = threadIdx.x; i < D.n[l]; i += kThreads) I(D.invr[l] + 4 * I(D.rotm[l] + 4 * i)) = i;
-        const Op& first = PL.ops[0];
-        if (first.kind == OP_BLOCK)
-            for (int i = threadIdx.x * 4; i < first.small_len; i += kThreads * 4)
-                F4(D.par[first.pbuf] + 4 * i) = *(gf4)(W + first.small_off + i);
+        const int opf = fetch_op(DF(ops), 0);
+        first_off = OF(small_off), first_len = OF(small_len), first_pbuf = OF(pbuf);
     }
+    f32x4 tokv[2], parv;
+    int tokdst[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = min((int)threadIdx.x + u * kThreads, ng - 1);
+        const int slot = i / (c0 >> 2), g = i - slot * (c0 >> 2);
+        tokv[u] = *(gf4)(tokens + ((size_t)cloud * M + I(DF(tmap) + 4 * slot)) * c0 + 4 * g);
+        tokdst[u] = DFI(X, 0) + 4 * (slot * DFI(ld, 0) + 4 * g);
+    }
+    parv = *(gf4)(W + first_off + min((int)threadIdx.x * 4, first_len - 4));
+    for (int i = threadIdx.x; i < M; i += kThreads) I(DF(ident) + 4 * i) = i;
     for (int l = 0; l + 1 < nl; ++l) {  // pooled positions (pooling.py:29-33): mean of the children, sequential sum
-        const int st = PL.stride[l], n2 = D.n[l + 1];
+        const int st = PL.stride[l], n2 = DFI(n, l + 1);
         for (int i = threadIdx.x; i < n2 * d; i += kThreads) {
             const int pt = i / d, j = i - pt * d;
             float sum = 0.f;
-            for (int q = 0; q < st; ++q) sum += F(D.P[l] + 4 * ((pt * st + q) * d + j));
-            F(D.P[l + 1] + 4 * i) = sum / (float)st;
+            for (int q = 0; q < st; ++q) sum += F(DFI(P, l) + 4 * ((pt * st + q) * d + j));
+            F(DFI(P, l + 1) + 4 * i) = sum / (float)st;
         }
-        __syncthreads();
+        lds_barrier();
     }
-    __syncthreads();
+    if (nl == 1) lds_barrier();  // (the identity map)
     for (int l = 0; l < nl; ++l) {  // relative positions of both partitions of every level
-        ball_rel(D.P[l], D.n[l], d, PL.ball[l], D.ident, D.rel[l][0]);
-        if (PL.rotate) ball_rel(D.P[l], D.n[l], d, PL.ball[l], D.rotm[l], D.rel[l][1]);
+        ball_rel(DFI(P, l), DFI(n, l), d, PL.ball[l], DF(ident), DFI(rel, 2 * (l) + (0)));
+        if (PL.rotate) ball_rel(DFI(P, l), DFI(n, l), d, PL.ball[l], DFI(rotm, l), DFI(rel, 2 * (l) + (1)));
     }
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if ((int)threadIdx.x + u * kThreads < ng) F4(tokdst[u]) = tokv[u];
+    if ((int)threadIdx.x * 4 < first_len) F4(DFI(par, first_pbuf) + 16 * threadIdx.x) = parv;
+    lds_barrier();
 
-    Pending pd = {0, 0, 0};
+    STAMP2(2);
     for (int oi = 0; oi < PL.n_ops; ++oi) {
-        const Op& op = PL.ops[oi];
-        if (op.kind == OP_BLOCK) {
-            if (op.nc == 1) {
-                attn_phase<1>(op, D, FR, d, pd);
-                mlp_phase<1>(op, D, FR, W);
+        const int opf = fetch_op(DF(ops), oi);
+        const int kind = OF(kind);
+        int dirv = dirf_all;  // (opaque copy per op: keeps the compiler from hoisting ~40 loop-invariant v_readlane results
+        asm volatile("" : "+v"(dirv));  //  into scalar registers for the whole loop -- they were spilled to scratch)
+        const int dirf = dirv;
+        int tid = threadIdx.x;  // (the same for the thread index: lane-derived addresses are re-made per op instead of being
+        asm volatile("" : "+v"(tid));  //  hoisted out of the loop and spilled)
+#ifdef HAET_STAMPS
+        const bool stamp_on = oi == haet_stamp2_op;
+#else
+        const bool stamp_on = false;
+#endif
+        if (kind == OP_BLOCK) {
+            if (OF(nc) == 1) {
+                attn_phase<1>(tid, opf, dirf, FR, PL.total_bytes, d, stamp_on);
+                mlp_phase<1>(tid, opf, dirf, FR, W, stamp_on);
             } else {
-                attn_phase<2>(op, D, FR, d, pd);
-                mlp_phase<2>(op, D, FR, W);
+                attn_phase<2>(tid, opf, dirf, FR, PL.total_bytes, d, stamp_on);
+                mlp_phase<2>(tid, opf, dirf, FR, W, stamp_on);
             }
-            pd.np = op.chunks;
-            pd.bias = D.par[op.pbuf] + 4 * (op.w3_b - op.small_off);
-            pd.inv = op.rot ? D.invr[op.lvl] : D.ident;
-        } else if (op.kind == OP_FLUSH) {
-            flush_level(D, op.lvl, op.c, pd);
-            pd.np = 0;
-        } else if (op.kind == OP_POOL) {
-            resample<false>(op, D, W, d);
+        } else if (kind == OP_POOL) {
+            resample<false>(tid, opf, dirf, W, d);
         } else {
-            resample<true>(op, D, W, d);
+            resample<true>(tid, opf, dirf, W, d);
         }
+        STAMP2(3 + oi);
     }
     // node.x[tree_mask][argsort(tree_idx[tree_mask])]  (erwin_flash.py:193); every slot of a power-of-two cloud holds a token
     {
-        const int X0 = D.X[0], ld0 = D.ld[0];
+        const int X0 = DFI(X, 0), ld0 = DFI(ld, 0);
         for (int i = threadIdx.x; i < M * (c0 >> 2); i += kThreads) {
             const int slot = i / (c0 >> 2), g = i - slot * (c0 >> 2);
-            *reinterpret_cast<f32x4*>(out + ((size_t)cloud * M + I(D.tmap + 4 * slot)) * c0 + 4 * g) = F4(X0 + 4 * (slot * ld0 + 4 * g));
+            *reinterpret_cast<f32x4*>(out + ((size_t)cloud * M + I(DF(tmap) + 4 * slot)) * c0 + 4 * g) = F4(X0 + 4 * (slot * ld0 + 4 * g));
         }
     }
+    STAMP2(20);
 }
 
 // --------------------------------------------------------------------------------------------------------------------- packer
@@ -739,7 +790,8 @@ static unsigned block_pieces(const Op& o) {
 
 // false: the shape is outside the fragment kernel's envelope
 static bool make_plan(const haet_erwin_desc& D, int M, Plan* out) {
-    Plan P = {};
+    Plan PP = {};
+    Head& P = PP.h;
     const int nl = D.n_levels;
     if (nl < 1 || nl > HAET_ERWIN_MAX_LEVELS || !D.decode || D.bn_train || (D.d != 2 && D.d != 3)) return false;
     if (M < 32 || M > 64 || (M & (M - 1))) return false;
@@ -769,7 +821,7 @@ static bool make_plan(const haet_erwin_desc& D, int M, Plan* out) {
     // op list (erwin_flash.py:183-192)
     int no = 0;
     auto push = [&](const Op& o) {
-        if (no < kMaxOps) P.ops[no] = o;
+        if (no < kMaxOps) PP.ops[no] = o;
         ++no;
     };
     auto blocks = [&](int l, const haet_erwin_layer& L) {
@@ -790,36 +842,33 @@ static bool make_plan(const haet_erwin_desc& D, int M, Plan* out) {
     };
     for (int l = 0; l < nl; ++l) {
         blocks(l, D.enc[l]);
-        if (l < nl - 1) {
-            simple(OP_FLUSH, l, nullptr);
-            simple(OP_POOL, l, &D.pool[l]);
-        }
+        if (l < nl - 1) simple(OP_POOL, l, &D.pool[l]);
     }
     for (int l = nl - 2; l >= 0; --l) {
-        simple(OP_FLUSH, l + 1, nullptr);
         simple(OP_UNPOOL, l, &D.unpool[l]);
         blocks(l, D.dec[l]);
     }
-    simple(OP_FLUSH, 0, nullptr);
     if (no > kMaxOps) return false;
     P.n_ops = no;
     // parameter buffers alternate over the BLOCK ops; every block stages its successor's group
     int max_small = 4, nb = 0, prev = -1;
     for (int i = 0; i < no; ++i) {
-        Op& o = P.ops[i];
+        Op& o = PP.ops[i];
         if (o.kind != OP_BLOCK) continue;
         o.pbuf = nb & 1;
         ++nb;
         max_small = max_small > o.small_len ? max_small : o.small_len;
-        if (prev >= 0) P.ops[prev].next_off = o.small_off, P.ops[prev].next_len = o.small_len;
+        if (prev >= 0) PP.ops[prev].next_off = o.small_off, PP.ops[prev].next_len = o.small_len;
         prev = i;
     }
-    if (nb == 0) return false;
+    if (nb == 0 || PP.ops[0].kind != OP_BLOCK || max_small > 2048) return false;  // (the prologue parks the first group with one 16-B load per thread)
+    for (int l = 0; l + 1 < nl; ++l)
+        if (2 * D.enc[l].c > 64 || D.enc[l + 1].c > 64 || 2 * D.d > 16) return false;  // resample(): <= 4 feature k-steps + 1
     // fragment sections
     unsigned off = kPlanBytes;
     P.frag_begin = off;
     for (int i = 0; i < no; ++i) {
-        Op& o = P.ops[i];
+        Op& o = PP.ops[i];
         if (o.kind != OP_BLOCK) continue;
         const int KS = 2 * o.nc;
         o.qk = off;
@@ -831,6 +880,19 @@ static bool make_plan(const haet_erwin_desc& D, int M, Plan* out) {
         off = o.qk + block_pieces(o) * 1024u;
     }
     P.total_bytes = off;
+    {   // the resample Linears' planes in the v1 blob ([out][K~] bf16 hi + lo = out * K~ floats), for the warm-up
+        long lo = -1, hi = 0;
+        for (int i = 0; i < no; ++i) {
+            const Op& o = PP.ops[i];
+            if (o.kind == OP_BLOCK) continue;
+            const int K = o.kind == OP_UNPOOL ? o.c2 + 2 * D.d : 2 * o.c + 2 * D.d, Oc = o.kind == OP_UNPOOL ? 2 * o.c : o.c2;
+            const long a = (long)o.w * 4, b = a + (long)Oc * round32(K) * 4;
+            lo = lo < 0 || a < lo ? a : lo;
+            hi = b > hi ? b : hi;
+        }
+        P.v1_lo = lo < 0 ? 0u : (unsigned)lo;
+        P.v1_bytes = lo < 0 ? 16u : (unsigned)(hi - lo);
+    }
     // LDS directory
     Dir& T = P.dir;
     int p = 0, maxslab = 0;
@@ -851,7 +913,6 @@ static bool make_plan(const haet_erwin_desc& D, int M, Plan* out) {
         T.rel[l][0] = take(4 * nlv[l] * D.d);
         T.rel[l][1] = take(4 * nlv[l] * D.d);
         T.rotm[l] = take(4 * nlv[l]);
-        T.invr[l] = take(4 * nlv[l]);
     }
     for (int l = nl; l < HAET_ERWIN_MAX_LEVELS; ++l) T.rotm[l] = -1;
     T.ident = take(4 * M);
@@ -859,9 +920,10 @@ static bool make_plan(const haet_erwin_desc& D, int M, Plan* out) {
     T.par[0] = take(4 * max_small);
     T.par[1] = take(4 * max_small);
     T.slab = take(maxslab);
+    T.ops = take(kMaxOps * (int)sizeof(Op));
     T.total = p;
     if (p + 8 * 1024 > 160 * 1024) return false;  // (+ the tree builder's static tables)
-    *out = P;
+    *out = PP;
     return true;
 }
 
@@ -874,6 +936,16 @@ void rotation_matrix_f32(float angle_deg, int d, float* r9);  // balltree.hip
 
 using namespace haet;
 
+#ifdef HAET_STAMPS
+extern "C" int haet_debug_read_tree_stamps2(unsigned long long* host_out) {  // the builder's stamps inside THIS kernel
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(haet_tree_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1;
+}
+extern "C" int haet_debug_read_stamps2(unsigned long long* host_out, int stamp_op) {
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(e2::haet_stamps2), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(e2::haet_stamp2_op), &stamp_op, sizeof(int)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" size_t haet_erwin_frag_bytes(const haet_erwin_desc* desc, int M) {
     static const bool off = getenv("HAET_ERWIN_V1") != nullptr;  // A/B switch: every shape on erwin.hip
     e2::Plan P;
@@ -881,7 +953,7 @@ extern "C" size_t haet_erwin_frag_bytes(const haet_erwin_desc* desc, int M) {
     int st[3] = {1, 1, 1};
     for (int l = 0; l < desc->n_levels - 1 && l < 3; ++l) st[l] = desc->pool[l].stride;
     if (!balltree_wave_ok(M, desc->n_levels, st)) return 0;
-    return P.total_bytes;
+    return P.h.total_bytes;
 }
 
 extern "C" int haet_erwin_frag_pack(const float* weights, size_t weight_floats, const haet_erwin_desc* desc, int M,
@@ -890,10 +962,10 @@ extern "C" int haet_erwin_frag_pack(const float* weights, size_t weight_floats, 
     if (weight_floats * 4 < sizeof(haet_erwin_desc)) return fail(HAET_E_ARG, "erwin_frag_pack: weight blob smaller than its header");
     e2::Plan P;
     if (!e2::make_plan(*desc, M, &P)) return fail(HAET_E_ARG, "erwin_frag_pack: shape outside the fragment kernel's envelope");
-    if (frag_bytes < P.total_bytes) return fail(HAET_E_ARG, "erwin_frag_pack: %zu bytes given, %u needed", frag_bytes, P.total_bytes);
+    if (frag_bytes < P.h.total_bytes) return fail(HAET_E_ARG, "erwin_frag_pack: %zu bytes given, %u needed", frag_bytes, P.h.total_bytes);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(e2::e2_plan_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<char*>(frags), P);
-    for (int i = 0; i < P.n_ops; ++i) {
+    for (int i = 0; i < P.h.n_ops; ++i) {
         const e2::Op& o = P.ops[i];
         if (o.kind != e2::OP_BLOCK) continue;
         hipLaunchKernelGGL(e2::e2_pack_kernel, dim3(e2::block_pieces(o)), dim3(64), 0, st, weights, reinterpret_cast<char*>(frags), o);
@@ -910,7 +982,7 @@ extern "C" int haet_token_stage_fwd_frag(const float* S, int n_clouds, int M, fl
     e2::Plan P;
     if (!e2::make_plan(*desc, M, &P) || !haet_erwin_frag_bytes(desc, M))
         return fail(HAET_E_ARG, "token_stage_frag: shape outside the fragment kernel's envelope (haet_erwin_frag_bytes)");
-    if (frag_bytes < P.total_bytes) return fail(HAET_E_ARG, "token_stage_frag: fragment blob too small");
+    if (frag_bytes < P.h.total_bytes) return fail(HAET_E_ARG, "token_stage_frag: fragment blob too small");
     if ((tree_idx == nullptr) != (tree_mask == nullptr)) return fail(HAET_E_ARG, "token_stage_frag: tree_idx / tree_mask go together");
     if ((desc->rotate != 0) != (angle_deg > 0.f)) return fail(HAET_E_ARG, "token_stage_frag: desc->rotate and angle disagree");
     WTreeCfg cfg = {};
@@ -926,7 +998,8 @@ extern "C" int haet_token_stage_fwd_frag(const float* S, int n_clouds, int M, fl
         if (l < desc->n_levels - 1) cfg.s[l] = desc->pool[l].stride;
     }
     rotation_matrix_f32(angle_deg, desc->d, cfg.R.r);
-    const size_t bytes = (size_t)P.dir.total;
+    static const int warm = getenv("HAET_ERWIN_WARM") ? atoi(getenv("HAET_ERWIN_WARM")) : 0;
+    const size_t bytes = (size_t)P.h.dir.total;
     static std::atomic<size_t> attr_set[64];
     std::atomic<size_t>& attr_dev = attr_set[PerDeviceOnce::bit()];
     if (bytes > 48 * 1024 && bytes > attr_dev.load(std::memory_order_acquire)) {
@@ -936,6 +1009,6 @@ extern "C" int haet_token_stage_fwd_frag(const float* S, int n_clouds, int M, fl
         attr_dev.store(bytes, std::memory_order_release);
     }
     hipLaunchKernelGGL(e2::erwin2_kernel, dim3(n_clouds), dim3(e2::kThreads), bytes, as_stream(stream), S, tree_idx, tree_mask,
-                       rot, weights, reinterpret_cast<const char*>(frags), out, cfg, pos_out);
+                       rot, weights, reinterpret_cast<const char*>(frags), out, cfg, pos_out, P.h, warm);
     return check_launch("erwin2_kernel");
 }
