@@ -32,6 +32,13 @@ class Physics_Attention_Structured_Mesh_2D(PhysicsAttentionBase):
     def grid_shape(self):
         return (self.H, self.W)
 
+    def project_split(self, x, sp, pre_norm=None):
+        # (a LayerNorm in front cannot ride in the convolution's loader -- the taps read NEIGHBOUR rows -- so
+        # fuses_pre_norm stays False and the caller applies it first)
+        if pre_norm is not None or x.dtype != __import__("torch").float32:
+            return None
+        return self._conv_project_split(x, (self.H, self.W), sp)
+
     def project(self, x):
         B, N, D = x.shape
         y = self._conv_project(x, (self.H, self.W))  # HIP implicit GEMM, channels-last

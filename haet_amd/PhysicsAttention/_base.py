@@ -124,9 +124,20 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
         """Whether `project_split(x, sp, pre_norm=ln)` can take the block's LayerNorm into its loader."""
         return False
 
-    def _conv_project(self, x: torch.Tensor, grid):
+    def _conv_project_split(self, x: torch.Tensor, grid, sp):
+        """The Conv2d / Conv3d projection with Ada-Temp in its epilogue and the output in the fused operand format
+        (ops.SplitPoints), or None where that path does not apply (dim_head != 32, channel counts outside the HIP
+        convolution, a shape the split-format passes do not take)."""
+        B, N, _ = x.shape
+        if (os.environ.get("HAET_NO_SPLIT_FORMAT") or self.dim_head != 32
+                or not ops.slice_split_supported(B, N, self.heads, self.dim_head, self.slice_num)):
+            return None
+        return self._conv_project(x, grid, split=sp)
+
+    def _conv_project(self, x: torch.Tensor, grid, split=None):
         """Conv2d / Conv3d in_project_x as the HIP implicit GEMM over the channels-last points, or None
-        when the channel counts are outside its envelope (the caller then runs the MIOpen conv)."""
+        when the channel counts are outside its envelope (the caller then runs the MIOpen conv).  `split`: the
+        slice parameters -> the result is an ops.SplitPoints (cells + s) instead of fp32 rows."""
         conv = self.in_project_x
         ok = not (os.environ.get("HAET_NO_HIP_CONV") or x.dtype != torch.float32)
         if ok and (not ops.conv_project_supported(conv.in_channels, conv.out_channels) or conv.bias is None
@@ -144,8 +155,10 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
         if "in_project_x" not in cache or cache["in_project_x"][0] != key:
             cache["in_project_x"] = (key, ops.SplitConv(conv.weight, conv.bias))
         w = cache["in_project_x"][1]
+        run = ((lambda xx, gg: ops.conv_project(xx, w, gg)) if split is None
+               else (lambda xx, gg: ops.conv_project_split(xx, w, gg, split, self.heads, self.dim_head)))
         if self.shard_group is None:
-            return ops.conv_project(x, w, grid)
+            return run(x, grid)
         # Slab sharding along the first grid axis: this rank holds whole planes; the convolution needs
         # one plane of halo per side per kernel radius (kernel 3: one plane), fetched from the
         # neighbour ranks; the global faces keep the zero padding.
@@ -163,8 +176,10 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
         prev, nxt = exchange_halo_planes(x, plane, self.shard_group) if rad else (None, None)
         parts = [t for t in (prev, x, nxt) if t is not None]
         x_ext = torch.cat(parts, dim=1) if len(parts) > 1 else x
-        y = ops.conv_project(x_ext, w, (x_ext.shape[1] // plane,) + tuple(grid[1:]))
+        y = run(x_ext, (x_ext.shape[1] // plane,) + tuple(grid[1:]))
         lo = plane if prev is not None else 0
+        if split is not None:  # the halo planes' rows are dropped from cells and s alike
+            return ops.SplitPoints(y.cells[:, lo:lo + n].contiguous(), y.s[:, lo:lo + n].contiguous(), y.H, y.C)
         return y[:, lo:lo + n].contiguous()
 
     def _split_linear_applies(self, lin: nn.Linear, x: torch.Tensor) -> bool:

@@ -94,6 +94,7 @@ SIGNATURES = {
     "haet_conv_project_supported": (c_int, [c_int, c_int]),
     "haet_conv_project_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       _P, _P]),
+    "haet_conv_project_split_fwd": (c_int, [_P, _P, _P, _P, _P, c_float, c_float] + [c_int] * 9 + [_P, _P, _P]),
     "haet_slice_bwd_num_parts": (c_int, [c_int] * 5),
     "haet_slice_bwd_param_floats": (c_size_t, [c_int, c_int]),
     "haet_deslice_bwd_tokens": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P] + [c_int] * 5 + [_P, _P]),

@@ -92,11 +92,19 @@ __device__ __forceinline__ GFrag g_read(int img, int row, int chunk) {
 struct ConvGeom {
     int Cin, Npts, gH, gW, gD, kH, kW, kD;
 };
+// ACT == 4 (CONV): the output leaves in the streaming passes' operand format -- 16-B cells {4 x bf16 hi, 4 x bf16 lo} per
+// 4 channels + s[n][h] = log2(e) / tau(n, h) (Ada-Temp over each 32-channel head, StructuredMesh2D.py:177-181,
+// StructuredMesh3D.py:181-185) -- exactly what gemm_ws_kernel<SPLIT> writes for the Linear projection
+struct ConvSplit {
+    const float* wt;  // ada_temp_linear.weight [32]
+    float bt, base_temp;
+    float* s_out;     // [Nrows][O / 32]
+};
 template <int NCB, int RB, bool CONV = false, int ACT = 0>  // RB = 32-row blocks per wave: workgroup tile = 64*RB rows x 32*NCB columns
 __global__ __launch_bounds__(512) void gemm_x3_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ Whi,
     const unsigned short* __restrict__ Wlo, const float* __restrict__ bias, int Nrows, int K, int O,
-    int n_row_tiles, float* __restrict__ out, ConvGeom cg) {
+    int n_row_tiles, float* __restrict__ out, ConvGeom cg, ConvSplit cs) {
     constexpr int BN = 32 * NCB;
     constexpr int WCB = NCB / 4;  // column blocks per wave (4 waves across the columns)
     constexpr int WPT = NCB / 4;  // 16-B W chunks per thread per plane and k-tile
@@ -127,6 +135,11 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
         w_st[i] = WIMG + ((wrow0 + 128 * i) >> 5) * (2 * GIMG) + g_off(wrow0 & 31, wch);
 
     f32x16 acc[RB][WCB];
+    float wt4[4] = {0.f, 0.f, 0.f, 0.f};  // ACT == 4: Ada-Temp weights of this lane's four channels after the quad transpose
+    if (ACT == 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wt4[q] = cs.wt[(l31 & ~3) + q];
+    }
     float bv[WCB];  // bias of this lane's output columns: loaded (and waited for) once, up front
 #pragma unroll
     for (int j = 0; j < WCB; ++j) bv[j] = (bias && (!kSplitK || blockIdx.z == 0)) ? bias[col0 + 32 * (WCB * wn + j) + l31] : 0.f;
@@ -250,7 +263,51 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
                 float* oc = out + (size_t)(row0 + 32 * RB * wm + 4 * hf) * O + col0 + 32 * (WCB * wn + j) + l31;
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
-                    if (kSplitK) {
+                    if (ACT == 4) {
+                        // (once per row tile, i.e. per K / 32 k-tiles: per-row branches around the stores cost nothing here)
+                        const int cb = WCB * wn + j;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            // registers 4g .. 4g+3 = rows 8g + 4hf + (0..3) of this lane's column; a 4 x 4 transpose across
+                            // the lane quad turns them into ONE row (8g + 4hf + lane % 4) and four consecutive columns
+                            int v[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = __float_as_int(acc[i][j][4 * g + q]);
+                            const bool odd = lane & 1, up = lane & 2;
+#pragma unroll
+                            for (int m = 0; m < 4; m += 2) {
+                                const int send = odd ? v[m] : v[m + 1];
+                                const int recv = __builtin_amdgcn_update_dpp(0, send, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+                                v[m] = odd ? recv : v[m];
+                                v[m + 1] = odd ? v[m + 1] : recv;
+                            }
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) {
+                                const int send = up ? v[m] : v[m + 2];
+                                const int recv = __builtin_amdgcn_update_dpp(0, send, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+                                v[m] = up ? recv : v[m];
+                                v[m + 2] = up ? v[m + 2] : recv;
+                            }
+                            const float f0 = __int_as_float(v[0]), f1 = __int_as_float(v[1]), f2 = __int_as_float(v[2]), f3 = __int_as_float(v[3]);
+                            const unsigned h01 = g_pack(f0, f1), h23 = g_pack(f2, f3);
+                            const u32x4 o4 = {h01, h23,
+                                              g_pack(f0 - __uint_as_float(h01 << 16), f1 - __uint_as_float(h01 & 0xffff0000u)),
+                                              g_pack(f2 - __uint_as_float(h23 << 16), f3 - __uint_as_float(h23 & 0xffff0000u))};
+                            float t = f0 * wt4[0];
+                            t = fmaf(f1, wt4[1], t);
+                            t = fmaf(f2, wt4[2], t);
+                            t = fmaf(f3, wt4[3], t);
+                            t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x124, 0xF, 0xF, false));  // row_ror:4
+                            t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, false));  // row_ror:8
+                            t += __shfl_xor(t, 16);
+                            const float tau = cs.base_temp + fminf(fmaxf(t + cs.bt, -0.4f), 0.4f);
+                            const long long rowi = (long long)row0 + 32 * (RB * wm + i) + 8 * g + 4 * hf + (lane & 3);
+                            if (rowi < Nrows) {
+                                *reinterpret_cast<u32x4*>(out + rowi * O + col0 + 32 * cb + (l31 & ~3)) = o4;
+                                cs.s_out[rowi * (O / 32) + col0 / 32 + cb] = 1.4426950408889634f * __builtin_amdgcn_rcpf(tau);
+                            }
+                        }
+                    } else if (kSplitK) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int rr = 32 * i + (r & 3) + 8 * (r >> 2);
@@ -714,7 +771,7 @@ static int linear_fwd_impl(const float* x, const uint16_t* W_hi, const uint16_t*
             if (e != hipSuccess) return fail(HAET_E_LAUNCH, "linear_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
         }
         hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi, W_lo, bias, Nrows,
-                           K, O, tiles, out, ConvGeom{});
+                           K, O, tiles, out, ConvGeom{}, ConvSplit{});
         return HAET_OK;
     };
     int rc;
@@ -831,9 +888,9 @@ extern "C" int haet_conv_project_supported(int Cin, int O) {
     return (Cin >= 32 && Cin % 32 == 0 && O >= 128 && O % 128 == 0) ? 1 : 0;
 }
 
-extern "C" int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo,
-                                     const float* bias, int B, int gH, int gW, int gD, int Cin, int O,
-                                     int kH, int kW, int kD, float* out, haet_stream_t stream) {
+static int conv_project_impl(const float* x, const uint16_t* W_hi, const uint16_t* W_lo,
+                             const float* bias, int B, int gH, int gW, int gD, int Cin, int O,
+                             int kH, int kW, int kD, float* out, haet_stream_t stream, const ConvSplit* split) {
     if (!x || !W_hi || !W_lo || !out) return fail(HAET_E_ARG, "conv_project_fwd: null pointer");
     if (!haet_conv_project_supported(Cin, O))
         return fail(HAET_E_ARG, "conv_project_fwd: C_in=%d (multiple of 32) / O=%d (multiple of 128) unsupported", Cin, O);
@@ -857,7 +914,7 @@ extern "C" int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const
     const int ncb = Cin / GBK;
     static const bool no_split = getenv("HAET_CONV_NO_SPLITK") != nullptr;
     // (float atomics: the summation order varies from run to run -- not taken in deterministic mode)
-    if (!no_split && !deterministic_mode() && !big && tiles * ny * 4 <= 256 && ncb >= 2) {
+    if (!split && !no_split && !deterministic_mode() && !big && tiles * ny * 4 <= 256 && ncb >= 2) {
         int Z = ncb;
         while (Z > 1 && tiles * ny * Z > 512) Z /= 2;
         if (Z > 1 && ncb % Z == 0) {
@@ -867,7 +924,7 @@ extern "C" int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const
                 if (lds > 64 * 1024)
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 hipLaunchKernelGGL(kern, dim3(tiles, ny, Z), dim3(512), lds, as_stream(stream), x, W_hi, W_lo, bias, Nrows, K, O,
-                                   tiles, out, cg);
+                                   tiles, out, cg, ConvSplit{});
             };
             if (NCBv == 8) launch_z(gemm_x3_kernel<8, 2, true, 3>);
             else launch_z(gemm_x3_kernel<4, 2, true, 3>);
@@ -878,10 +935,33 @@ extern "C" int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), lds, as_stream(stream), x, W_hi, W_lo, bias, Nrows, K, O,
-                           tiles, out, cg);
+                           tiles, out, cg, split ? *split : ConvSplit{});
     };
+    if (split) {  // cells + s instead of fp32 rows
+        if (NCBv == 8) launch(gemm_x3_kernel<8, 2, true, 4>);
+        else launch(gemm_x3_kernel<4, 2, true, 4>);
+        return check_launch("gemm_x3_kernel<conv, split format>");
+    }
     if (big) launch(gemm_x3_kernel<8, 4, true>);
     else if (NCBv == 8) launch(gemm_x3_kernel<8, 2, true>);
     else launch(gemm_x3_kernel<4, 2, true>);
     return check_launch("gemm_x3_kernel<conv>");
+}
+
+extern "C" int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo,
+                                     const float* bias, int B, int gH, int gW, int gD, int Cin, int O,
+                                     int kH, int kW, int kD, float* out, haet_stream_t stream) {
+    return conv_project_impl(x, W_hi, W_lo, bias, B, gH, gW, gD, Cin, O, kH, kW, kD, out, stream, nullptr);
+}
+
+// The same convolution with the output in the fused operand format of the streaming passes (haet_project_split_fwd's):
+// cells [B*N][O] (4-byte slots: per 4 channels {4 x bf16 hi, 4 x bf16 lo}) + s [B*N][O / 32] = log2(e) / tau, tau =
+// base_temp + clamp(x_lin[head] . wt + bt, -0.4, 0.4) per 32-channel head (dim_head = 32).
+extern "C" int haet_conv_project_split_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo,
+                                           const float* bias, const float* wt, float bt, float base_temp, int B, int gH,
+                                           int gW, int gD, int Cin, int O, int kH, int kW, int kD, void* cells,
+                                           float* s_out, haet_stream_t stream) {
+    if (!wt || !s_out) return fail(HAET_E_ARG, "conv_project_split_fwd: null pointer");
+    const ConvSplit cs{wt, bt, base_temp, s_out};
+    return conv_project_impl(x, W_hi, W_lo, bias, B, gH, gW, gD, Cin, O, kH, kW, kD, reinterpret_cast<float*>(cells), stream, &cs);
 }

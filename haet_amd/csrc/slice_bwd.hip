@@ -319,6 +319,12 @@ int slice_bwd_mfma(int mode, const float*, const float*, const float*, const flo
                    const float*, const float*, const float*, const float*, const float*, const float*, int, int, int,
                    int, int, float*, float*, hipStream_t);
 
+// slice_bwd_x3.hip: the same passes on split-bf16 products (C = 32, M in {32, 64}), same records, same chunking
+bool slice_bwd_x3_ok(int C, int M);
+int slice_bwd_x3(int mode, const float*, const float*, const float*, const float*, float, float, float,
+                 const float*, const float*, const float*, const float*, const float*, const float*, int, int, int,
+                 int, int, float*, float*, hipStream_t);
+
 static bool use_bwd_mfma(int C, int M) {  // HAET_FORCE_VALU=1 routes every shape through the generic kernels (tests)
     const char* e = getenv("HAET_FORCE_VALU");
     return !(e && e[0] == '1') && slice_bwd_mfma_ok(C, M);
@@ -387,6 +393,9 @@ extern "C" int haet_deslice_bwd_tokens(const float* x_lin, const float* Ws, cons
         return fail(HAET_E_ARG, "deslice_bwd_tokens: null pointer");
     int rc = slice_shape_ok(B, N, H, C, M);
     if (rc != HAET_OK) return rc;
+    if (use_bwd_mfma(C, M) && slice_bwd_x3_ok(C, M))
+        return slice_bwd_x3(0, x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, g_out, nullptr, nullptr, nullptr,
+                            B, N, H, C, M, nullptr, parts, as_stream(stream));
     if (use_bwd_mfma(C, M))
         return slice_bwd_mfma(0, x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, g_out, nullptr, nullptr,
                               nullptr, B, N, H, C, M, nullptr, parts, as_stream(stream));
@@ -405,6 +414,9 @@ extern "C" int haet_slice_bwd_points(const float* x_lin, const float* Ws, const 
         return fail(HAET_E_ARG, "slice_bwd_points: null pointer");
     int rc = slice_shape_ok(B, N, H, C, M);
     if (rc != HAET_OK) return rc;
+    if (use_bwd_mfma(C, M) && slice_bwd_x3_ok(C, M))
+        return slice_bwd_x3(1, x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, g_out, S2, dS, A, B, N, H, C, M,
+                            dx_lin, param_parts, as_stream(stream));
     if (use_bwd_mfma(C, M))
         return slice_bwd_mfma(1, x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, g_out, S2, dS, A, B, N, H, C, M,
                               dx_lin, param_parts, as_stream(stream));

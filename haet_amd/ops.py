@@ -598,6 +598,25 @@ def deslice_out_split(xs: SplitPoints, p: SliceParams, col_max: Tensor, col_sum:
     return out
 
 
+def conv_project_split(x: Tensor, w: "SplitConv", grid: Tuple[int, ...], p: SliceParams, H: int, C: int) -> SplitPoints:
+    """The convolution projection straight into the streaming passes' operand format + s = log2(e)/tau
+    (haet_conv_project_split_fwd; dim_head C = 32)."""
+    lib = _lib.load()
+    x = _f32(x, "x")
+    B, N, Cin = x.shape
+    gH, gW = grid[0], grid[1]
+    gD = grid[2] if len(grid) > 2 else 1
+    if gH * gW * gD != N or Cin != w.Cin or w.O != H * C or C != 32:
+        raise HaetError("conv_project_split: x does not match the grid / weight (dim_head must be 32)")
+    cells = torch.empty((B, N, w.O), dtype=torch.float32, device=x.device)
+    s = torch.empty((B, N, H), dtype=torch.float32, device=x.device)
+    kH, kW, kD = w.kernel
+    check(lib.haet_conv_project_split_fwd(_p(x), _p(w.lin.hi), _p(w.lin.lo), _p(w.lin.bias), _p(p.wt), p.bt, p.base_temp,
+                                          B, gH, gW, gD, Cin, w.O, kH, kW, kD, _p(cells), _p(s), _stream()),
+          "haet_conv_project_split_fwd")
+    return SplitPoints(cells, s, H, C)
+
+
 # --------------------------------------------------------------------------- structured projection
 class SplitConv:
     """A Conv2d / Conv3d weight [O, C_in, k, k(, k)] as split planes laid out [O][C_in/32][taps][32]

@@ -454,6 +454,14 @@ int haet_conv_project_supported(int Cin, int O);
 int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
                           int B, int gH, int gW, int gD, int Cin, int O, int kH, int kW, int kD,
                           float* out, haet_stream_t stream);
+/* The same convolution with Ada-Temp in its epilogue and the output in the fused operand format of the streaming
+ * passes (what haet_project_split_fwd writes for the Linear projection; StructuredMesh2D.py:173-181,
+ * StructuredMesh3D.py:177-185): cells [B*N][O] 4-byte slots -- per 4 channels {4 x bf16 hi, 4 x bf16 lo} -- and
+ * s [B*N][O / 32] = log2(e) / tau, tau = base_temp + clamp(x_lin[head] . wt + bt, -0.4, 0.4), dim_head = 32.
+ * Always the one-workgroup-per-tile path (no float atomics). */
+int haet_conv_project_split_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
+                                const float* wt, float bt, float base_temp, int B, int gH, int gW, int gD, int Cin,
+                                int O, int kH, int kW, int kD, void* cells, float* s_out, haet_stream_t stream);
 
 /* ------------------------------------------------------------------ stand-alone ErwinFlash on raw point clouds
  * (ErwinTransformer.forward with embed=True / mp_steps>0 on 32k..1M-point clouds,

@@ -31,10 +31,14 @@ def _passes_fp64(x, Ws, bs, wt, bt, base, c0, S2):
 @pytest.mark.parametrize("B,N,H,C,M", [(1, 700, 4, 16, 16), (2, 333, 8, 32, 64), (1, 1, 2, 32, 32), (1, 5000, 8, 32, 64),
                                        (1, 1025, 4, 64, 32), (1, 257, 2, 32, 128), (2, 64, 3, 8, 8), (1, 300, 2, 64, 100),
                                        (1, 4097, 2, 16, 48), (2, 700, 2, 64, 64), (1, 33, 4, 64, 32)])
-@pytest.mark.parametrize("path", ["auto", "valu"])
+@pytest.mark.parametrize("path", ["auto", "valu", "f32"])
 def test_backward_passes_vs_fp64_autograd(B, N, H, C, M, path, hip_device, monkeypatch):
     from haet_amd import ops
 
+    if path == "f32":  # the exact-f32 matrix-core kernels where auto takes the split-bf16 ones (C = 32, M in {32, 64})
+        if not (C == 32 and M in (32, 64)):
+            pytest.skip("auto already runs the f32 / generic kernels for this shape")
+        monkeypatch.setenv("HAET_BWD_F32", "1")
     if path == "valu":  # the generic fp32 vector-ALU kernels for every shape (auto: MFMA kernels where they apply)
         if not ((C == 32 and M in (32, 64, 128)) or (C == 64 and M in (32, 64))):
             pytest.skip("auto already runs the generic kernels for this shape")
@@ -73,10 +77,14 @@ def test_backward_passes_vs_fp64_autograd(B, N, H, C, M, path, hip_device, monke
     go = g_out.reshape(B, N, H * C).to(dev)
     S2d, dSd = S2.reshape(-1, C).to(dev), dS.reshape(-1, C).to(dev)
     dS2 = ops.deslice_bwd_tokens(x_lin, sp, cm, cs, go, H, C, M)
-    assert O.rel_l2(dS2.cpu().double(), gS2.reshape(-1, C)) < 5e-5
+    # C = 32 with M in {32, 64} runs on split-bf16 products (csrc/slice_bwd_x3.hip): the logits carry the forward's
+    # envelope -- an absolute error of ~sum|Ws x| 2^-17 inside the exponential, here |z| up to ~20 -- where the exact-f32
+    # matrix-core kernels (path "f32") and the generic ones have fp32 rounding only
+    x3 = path == "auto" and C == 32 and M in (32, 64)
+    assert O.rel_l2(dS2.cpu().double(), gS2.reshape(-1, C)) < (3e-4 if x3 else 5e-5)
     A = (dS2 * S2d).sum(-1) + (S_hip * dSd).sum(-1)
     dx, dWs, dbs, dwt, dbt = ops.slice_bwd_points(x_lin, sp, cm, cs, go, S2d, dSd, A, H, C, M)
-    tol = 5e-4  # fp32 accumulation over N points with cancellation in (a - A)
+    tol = 1.5e-3 if x3 else 5e-4  # fp32 accumulation over N points with cancellation in (a - A)
     assert O.rel_l2(dx.cpu().double().reshape(B, N, H, C), gx) < tol
     if N == 1:  # softmax over one point: w = 1, dz = 0 -- every parameter gradient is rounding noise around zero
         assert float(dWs.abs().max()) < 2e-2 and float(dbs.abs().max()) < 2e-2 and float(dwt.abs().max()) < 2e-2

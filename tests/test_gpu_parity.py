@@ -616,6 +616,37 @@ def test_split_operand_format_matches_fp32_path(B, N, H, M, hip_device):
     assert O.rel_l2(b2.cpu(), a.cpu()) < 2e-5
 
 
+@pytest.mark.parametrize("B,grid,Cin,O,k", [(2, (9, 7), 32, 128, 3), (1, (16, 16), 64, 256, 3), (1, (5, 6, 7), 32, 256, 3),
+                                           (2, (40, 40), 256, 256, 3)])
+def test_conv_projection_split_epilogue(B, grid, Cin, O, k, hip_device):
+    """haet_conv_project_split_fwd (the structured variants' projection with Ada-Temp in its epilogue, output in the
+    fused operand format) against haet_conv_project_fwd on the same operands: hi + lo of every cell is the fp32
+    projection to 2^-17, s = log2(e) / tau from the fp32 rows; partial last row tile, batch boundaries inside a tile."""
+    from haet_amd import ops
+
+    torch.manual_seed(sum(grid) + Cin + O)
+    nd = len(grid)
+    N = 1
+    for g in grid:
+        N *= g
+    H, C = O // 32, 32
+    dev = hip_device
+    x = torch.randn(B, N, Cin, device=dev)
+    w = ops.SplitConv(torch.randn(O, Cin, *([k] * nd), device=dev) * 0.05, torch.randn(O, device=dev))
+    sp = ops.SliceParams(torch.randn(16, C, device=dev) * 0.3, torch.randn(16, device=dev) * 0.2,
+                         torch.randn(1, C, device=dev) * 0.3, 0.05, 0.5, 1e-6)
+    ref = ops.conv_project(x, w, grid)
+    xs = ops.conv_project_split(x, w, grid, sp, H, C)
+    assert O_rel(xs.to_float().cpu(), ref.cpu()) < 1e-5
+    row_err = (xs.to_float() - ref).norm(dim=-1) / ref.norm(dim=-1)
+    assert float(row_err.max()) < 2e-5, int(row_err.argmax())
+    # tau = base + clamp(t): compared as tau (an absolute error of t -- a 32-term dot product of O(1) values -- shows
+    # 1 : 1 in tau, and near the lower clamp tau = 0.1 that is 10x as much relative to s)
+    t = (ref.double().reshape(B, N, H, C) * sp.wt.double().reshape(1, 1, 1, C)).sum(-1) + sp.bt
+    tau = 0.5 + torch.clamp(t, -0.4, 0.4)
+    assert torch.allclose(1.4426950408889634 / xs.s.double().cpu(), tau.cpu(), rtol=0, atol=2e-5 * float(t.abs().max()))
+
+
 @pytest.mark.parametrize("B,grid,Cin,O,k", [(2, (9, 7), 32, 128, 3), (1, (16, 16), 64, 256, 3), (1, (5, 6, 7), 32, 128, 3),
                                            (2, (8, 8, 8), 64, 256, 3), (1, (40, 40), 256, 256, 3), (1, (6, 5, 4), 32, 128, 5)])
 def test_conv_projection_implicit_gemm_vs_fp64(B, grid, Cin, O, k, hip_device):
@@ -800,14 +831,21 @@ def test_big_config_end_to_end(name, hip_device):
     conv = mod.in_project_x
     assert ops.conv_project_supported(conv.in_channels, conv.out_channels)
     calls = []
-    orig = ops.conv_project
-    ops.conv_project = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    orig, orig_split = ops.conv_project, ops.conv_project_split
+    ops.conv_project = lambda *a, **k: (calls.append("fp32"), orig(*a, **k))[1]
+    ops.conv_project_split = lambda *a, **k: (calls.append("split"), orig_split(*a, **k))[1]
     try:
         with torch.no_grad():
             out, inter = mod(x.to(hip_device), return_intermediates=True)
+            out_default = mod(x.to(hip_device))  # (what the model calls: nothing unfused on request)
     finally:
-        ops.conv_project = orig
+        ops.conv_project, ops.conv_project_split = orig, orig_split
     assert calls, "the HIP implicit-GEMM convolution did not run"
+    # C5's widths (8 x 32, M = 128): the convolution's epilogue writes the fused operand format + Ada-Temp and the two
+    # streaming passes run on it; C1 (M = 8) is outside the split-format passes and stays on fp32 rows
+    want = "split" if ops.slice_split_supported(x.shape[0], x.shape[1], cfg.heads, cfg.dim_head, cfg.slice_num) else "fp32"
+    assert set(calls) == {want}, calls
+    assert O.rel_l2(out_default.cpu(), out.cpu()) < FP32_TOL
     assert O.rel_l2(inter["x_lin"].cpu().index_select(1, rows), exp["x_lin_rows"]) < FP32_TOL
     assert O.rel_l2(inter["eidetic"].cpu(), exp["eidetic_flat"]) < FP32_TOL
     assert torch.allclose(inter["pos"].cpu(), exp["pos"], atol=1e-4)
