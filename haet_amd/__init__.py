@@ -9,6 +9,7 @@ Mirrors the reference's `models` package surface (models/__init__.py:15-17):
 so `import haet_amd as models` drops into the reference's training scripts.
 The compute path is libhaet_hip.so (hand-written HIP for gfx950); see include/haet_hip.h.
 """
+from ._lib import precision, set_precision  # noqa: F401  (arithmetic switch: "bf16x3" default, "fp16x2" opt-in)
 from .HAETransolver_Irregular_Mesh import Model as HAETransolver_Irregular_Mesh
 from .HAETransolver_Structured_Mesh_2D import Model as HAETransolver_Structured_Mesh_2D
 from .HAETransolver_Structured_Mesh_3D import Model as HAETransolver_Structured_Mesh_3D

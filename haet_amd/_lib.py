@@ -95,6 +95,8 @@ SIGNATURES = {
     "haet_conv_project_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       _P, _P]),
     "haet_conv_project_split_fwd": (c_int, [_P, _P, _P, _P, _P, c_float, c_float] + [c_int] * 9 + [_P, _P, _P]),
+    "haet_conv_project_f16_fwd": (c_int, [_P, _P, _P] + [c_int] * 9 + [_P, _P]),
+    "haet_conv_project_split_f16_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float] + [c_int] * 9 + [_P, _P, _P]),
     "haet_slice_bwd_num_parts": (c_int, [c_int] * 5),
     "haet_slice_bwd_param_floats": (c_size_t, [c_int, c_int]),
     "haet_deslice_bwd_tokens": (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P] + [c_int] * 5 + [_P, _P]),
@@ -216,6 +218,22 @@ def _install_registration_hooks():
 
 
 _install_registration_hooks()
+
+
+_precision = [os.environ.get("HAET_PRECISION", "bf16x3")]
+
+
+def precision() -> str:
+    """Arithmetic of the matrix-core products: "bf16x3" (default: split bf16, three products per term, fp32-grade
+    ~5e-6) or "fp16x2" (opt-in: two fp16 products per term where a kernel offers it -- today the convolution
+    projection of the structured variants -- ~2e-4; north_star's bar is 1e-3).  HAET_PRECISION sets the initial value."""
+    return _precision[0]
+
+
+def set_precision(mode: str) -> None:
+    if mode not in ("bf16x3", "fp16x2"):
+        raise ValueError(f"precision {mode!r}: expected 'bf16x3' or 'fp16x2'")
+    _precision[0] = mode
 
 
 def load():

@@ -47,6 +47,26 @@ __device__ __forceinline__ f32x16 g_mfma3(const GFrag& a, const GFrag& b, f32x16
     return c;
 }
 
+// PREC = 1 ("fp16x2", opt-in: haet_conv_project_f16_fwd): the activations as fp16 hi + fp16 lo, the weight as ONE fp16
+// plane -- two v_mfma_f32_32x32x16_f16 per product instead of three bf16 ones.  What it costs: the weight's 11-bit
+// mantissa, ~2e-4 relative on a K = 256 .. 6912 contraction (measured; bf16x3: 4e-6) against north_star's 1e-3 bar and
+// the reference's own fp16-autocast GPU path; BASELINE config C5 names "fp16 MFMA".
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ unsigned g_pack_h(float a, float b) {  // v_cvt_pk_f16_f32 (RNE)
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ f32x2 g_unpack_h(unsigned h) {
+    return __builtin_convertvector(__builtin_bit_cast(f16x2, h), f32x2);
+}
+__device__ __forceinline__ f32x16 g_mfma2h(const GFrag& a, const u32x4 b, f32x16 c) {
+    const f16x8 ah = __builtin_bit_cast(f16x8, a.hi), al = __builtin_bit_cast(f16x8, a.lo), bh = __builtin_bit_cast(f16x8, b);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+    return c;
+}
+
 // optional epilogue activation (ACT = 1): nn.GELU(approximate='none'), the MLPs of the Transolver block
 __device__ __forceinline__ float g_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
@@ -100,7 +120,7 @@ struct ConvSplit {
     float bt, base_temp;
     float* s_out;     // [Nrows][O / 32]
 };
-template <int NCB, int RB, bool CONV = false, int ACT = 0>  // RB = 32-row blocks per wave: workgroup tile = 64*RB rows x 32*NCB columns
+template <int NCB, int RB, bool CONV = false, int ACT = 0, int PREC = 0>  // RB = 32-row blocks per wave: workgroup tile = 64*RB rows x 32*NCB columns
 __global__ __launch_bounds__(512) void gemm_x3_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ Whi,
     const unsigned short* __restrict__ Wlo, const float* __restrict__ bias, int Nrows, int K, int O,
@@ -217,7 +237,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
             for (int i = 0; i < WPT; ++i) {
                 const size_t o = (size_t)(col0 + wrow0 + 128 * i) * K + kk + 8 * wch;
                 d[2 * i] = *reinterpret_cast<const u32x4*>(Whi + o);
-                d[2 * i + 1] = *reinterpret_cast<const u32x4*>(Wlo + o);
+                if (PREC == 0) d[2 * i + 1] = *reinterpret_cast<const u32x4*>(Wlo + o);  // (fp16x2: one weight plane)
             }
         }
         if (++fw_kt == nkt) fw_kt = 0;
@@ -226,10 +246,18 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
             const f32x4 v = xv[i];
-            const unsigned h01 = g_pack(v[0], v[1]), h23 = g_pack(v[2], v[3]);
-            const u32x2 hi = {h01, h23};
-            const u32x2 lo = {g_pack(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u)),
-                              g_pack(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u))};
+            u32x2 hi, lo;
+            if (PREC == 0) {
+                const unsigned h01 = g_pack(v[0], v[1]), h23 = g_pack(v[2], v[3]);
+                hi = u32x2{h01, h23};
+                lo = u32x2{g_pack(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u)),
+                           g_pack(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u))};
+            } else {
+                const unsigned h01 = g_pack_h(v[0], v[1]), h23 = g_pack_h(v[2], v[3]);
+                const f32x2 f01 = g_unpack_h(h01), f23 = g_unpack_h(h23);
+                hi = u32x2{h01, h23};
+                lo = u32x2{g_pack_h(v[0] - f01[0], v[1] - f01[1]), g_pack_h(v[2] - f23[0], v[3] - f23[1])};
+            }
             const int off = buf + x_st0 + i * 2 * (2 * GIMG);  // row + 64 i: two row blocks further
             *reinterpret_cast<u32x2*>(gsm + off) = hi;
             *reinterpret_cast<u32x2*>(gsm + off + GIMG) = lo;
@@ -237,7 +265,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             *reinterpret_cast<u32x4*>(gsm + buf + w_st[i]) = wv[2 * i];
-            *reinterpret_cast<u32x4*>(gsm + buf + w_st[i] + GIMG) = wv[2 * i + 1];
+            if (PREC == 0) *reinterpret_cast<u32x4*>(gsm + buf + w_st[i] + GIMG) = wv[2 * i + 1];
         }
     };
     int c_tile = blockIdx.x, c_kt = 0;
@@ -246,12 +274,15 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
         for (int ks = 0; ks < 2; ++ks) {
             GFrag b[WCB];
 #pragma unroll
-            for (int j = 0; j < WCB; ++j) b[j] = g_read(buf + WIMG + (WCB * wn + j) * (2 * GIMG), l31, hf + 2 * ks);
+            for (int j = 0; j < WCB; ++j) {
+                if (PREC == 0) b[j] = g_read(buf + WIMG + (WCB * wn + j) * (2 * GIMG), l31, hf + 2 * ks);
+                else b[j].hi = *reinterpret_cast<const u32x4*>(gsm + buf + WIMG + (WCB * wn + j) * (2 * GIMG) + g_off(l31, hf + 2 * ks));
+            }
 #pragma unroll
             for (int i = 0; i < RB; ++i) {  // one A fragment at a time: RB = 4 leaves no room for four
                 const GFrag a = g_read(buf + XIMG + (RB * wm + i) * (2 * GIMG), l31, hf + 2 * ks);
 #pragma unroll
-                for (int j = 0; j < WCB; ++j) acc[i][j] = g_mfma3(a, b[j], acc[i][j]);
+                for (int j = 0; j < WCB; ++j) acc[i][j] = PREC == 0 ? g_mfma3(a, b[j], acc[i][j]) : g_mfma2h(a, b[j].hi, acc[i][j]);
             }
         }
         if (++c_kt == nkt) {  // row tile finished: lane = output column, registers = rows
@@ -890,8 +921,8 @@ extern "C" int haet_conv_project_supported(int Cin, int O) {
 
 static int conv_project_impl(const float* x, const uint16_t* W_hi, const uint16_t* W_lo,
                              const float* bias, int B, int gH, int gW, int gD, int Cin, int O,
-                             int kH, int kW, int kD, float* out, haet_stream_t stream, const ConvSplit* split) {
-    if (!x || !W_hi || !W_lo || !out) return fail(HAET_E_ARG, "conv_project_fwd: null pointer");
+                             int kH, int kW, int kD, float* out, haet_stream_t stream, const ConvSplit* split, bool f16 = false) {
+    if (!x || !W_hi || (!W_lo && !f16) || !out) return fail(HAET_E_ARG, "conv_project_fwd: null pointer");
     if (!haet_conv_project_supported(Cin, O))
         return fail(HAET_E_ARG, "conv_project_fwd: C_in=%d (multiple of 32) / O=%d (multiple of 128) unsupported", Cin, O);
     if (B < 1 || gH < 1 || gW < 1 || gD < 1 || kH < 1 || kW < 1 || kD < 1 || !(kH & kW & kD & 1))
@@ -914,7 +945,7 @@ static int conv_project_impl(const float* x, const uint16_t* W_hi, const uint16_
     const int ncb = Cin / GBK;
     static const bool no_split = getenv("HAET_CONV_NO_SPLITK") != nullptr;
     // (float atomics: the summation order varies from run to run -- not taken in deterministic mode)
-    if (!split && !no_split && !deterministic_mode() && !big && tiles * ny * 4 <= 256 && ncb >= 2) {
+    if (!split && !f16 && !no_split && !deterministic_mode() && !big && tiles * ny * 4 <= 256 && ncb >= 2) {
         int Z = ncb;
         while (Z > 1 && tiles * ny * Z > 512) Z /= 2;
         if (Z > 1 && ncb % Z == 0) {
@@ -938,9 +969,19 @@ static int conv_project_impl(const float* x, const uint16_t* W_hi, const uint16_
                            tiles, out, cg, split ? *split : ConvSplit{});
     };
     if (split) {  // cells + s instead of fp32 rows
-        if (NCBv == 8) launch(gemm_x3_kernel<8, 2, true, 4>);
-        else launch(gemm_x3_kernel<4, 2, true, 4>);
+        if (f16) {
+            if (NCBv == 8) launch(gemm_x3_kernel<8, 2, true, 4, 1>);
+            else launch(gemm_x3_kernel<4, 2, true, 4, 1>);
+        } else {
+            if (NCBv == 8) launch(gemm_x3_kernel<8, 2, true, 4>);
+            else launch(gemm_x3_kernel<4, 2, true, 4>);
+        }
         return check_launch("gemm_x3_kernel<conv, split format>");
+    }
+    if (f16) {
+        if (NCBv == 8) launch(gemm_x3_kernel<8, 2, true, 0, 1>);
+        else launch(gemm_x3_kernel<4, 2, true, 0, 1>);
+        return check_launch("gemm_x3_kernel<conv, fp16x2>");
     }
     if (big) launch(gemm_x3_kernel<8, 4, true>);
     else if (NCBv == 8) launch(gemm_x3_kernel<8, 2, true>);
@@ -952,6 +993,20 @@ extern "C" int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const
                                      const float* bias, int B, int gH, int gW, int gD, int Cin, int O,
                                      int kH, int kW, int kD, float* out, haet_stream_t stream) {
     return conv_project_impl(x, W_hi, W_lo, bias, B, gH, gW, gD, Cin, O, kH, kW, kD, out, stream, nullptr);
+}
+
+// fp16x2 arithmetic (opt-in; see PREC above): W_f16 = the weight of haet_conv_project_fwd's layout as ONE fp16 plane
+extern "C" int haet_conv_project_f16_fwd(const float* x, const uint16_t* W_f16, const float* bias, int B, int gH, int gW,
+                                         int gD, int Cin, int O, int kH, int kW, int kD, float* out, haet_stream_t stream) {
+    return conv_project_impl(x, W_f16, nullptr, bias, B, gH, gW, gD, Cin, O, kH, kW, kD, out, stream, nullptr, true);
+}
+extern "C" int haet_conv_project_split_f16_fwd(const float* x, const uint16_t* W_f16, const float* bias, const float* wt,
+                                               float bt, float base_temp, int B, int gH, int gW, int gD, int Cin, int O,
+                                               int kH, int kW, int kD, void* cells, float* s_out, haet_stream_t stream) {
+    if (!wt || !s_out) return fail(HAET_E_ARG, "conv_project_split_f16_fwd: null pointer");
+    const ConvSplit cs{wt, bt, base_temp, s_out};
+    return conv_project_impl(x, W_f16, nullptr, bias, B, gH, gW, gD, Cin, O, kH, kW, kD, reinterpret_cast<float*>(cells), stream,
+                             &cs, true);
 }
 
 // The same convolution with the output in the fused operand format of the streaming passes (haet_project_split_fwd's):

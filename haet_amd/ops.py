@@ -611,6 +611,11 @@ def conv_project_split(x: Tensor, w: "SplitConv", grid: Tuple[int, ...], p: Slic
     cells = torch.empty((B, N, w.O), dtype=torch.float32, device=x.device)
     s = torch.empty((B, N, H), dtype=torch.float32, device=x.device)
     kH, kW, kD = w.kernel
+    if _lib.precision() == "fp16x2":
+        check(lib.haet_conv_project_split_f16_fwd(_p(x), _p(w.f16()), _p(w.lin.bias), _p(p.wt), p.bt, p.base_temp, B, gH, gW, gD,
+                                                  Cin, w.O, kH, kW, kD, _p(cells), _p(s), _stream()),
+              "haet_conv_project_split_f16_fwd")
+        return SplitPoints(cells, s, H, C)
     check(lib.haet_conv_project_split_fwd(_p(x), _p(w.lin.hi), _p(w.lin.lo), _p(w.lin.bias), _p(p.wt), p.bt, p.base_temp,
                                           B, gH, gW, gD, Cin, w.O, kH, kW, kD, _p(cells), _p(s), _stream()),
           "haet_conv_project_split_fwd")
@@ -632,6 +637,13 @@ class SplitConv:
         # [O, C_in, taps] -> [O, C_in/32, 32, taps] -> [O, C_in/32, taps, 32]: channel block, tap, channel
         flat = (w.reshape(self.O, self.Cin // 32, 32, taps).permute(0, 1, 3, 2).reshape(self.O, -1).contiguous())
         self.lin = SplitLinear(flat, bias)
+        self._f16 = None
+
+    def f16(self) -> Tensor:
+        """The weight as ONE fp16 plane (same layout), for the opt-in fp16x2 arithmetic; made on first use."""
+        if self._f16 is None:
+            self._f16 = (self.lin.hi.view(torch.bfloat16).float() + self.lin.lo.view(torch.bfloat16).float()).half().contiguous()
+        return self._f16
 
 
 def conv_project_supported(Cin: int, O: int) -> bool:
@@ -651,6 +663,10 @@ def conv_project(x: Tensor, w: SplitConv, grid: Tuple[int, ...]) -> Tensor:
     kH, kW, kD = w.kernel
     # small grids otherwise split the k-tiles over workgroups that add with float atomics (run-to-run order)
     lib.haet_set_deterministic(1 if (torch.are_deterministic_algorithms_enabled() or os.environ.get("HAET_DETERMINISTIC") == "1") else 0)
+    if _lib.precision() == "fp16x2":
+        check(lib.haet_conv_project_f16_fwd(_p(x), _p(w.f16()), _p(w.lin.bias), B, gH, gW, gD, Cin, w.O, kH, kW, kD, _p(out),
+                                            _stream()), "haet_conv_project_f16_fwd")
+        return out
     check(lib.haet_conv_project_fwd(_p(x), _p(w.lin.hi), _p(w.lin.lo), _p(w.lin.bias), B, gH, gW, gD, Cin, w.O,
                                     kH, kW, kD, _p(out), _stream()), "haet_conv_project_fwd")
     return out

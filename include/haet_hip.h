@@ -462,6 +462,16 @@ int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const uint16_t* 
 int haet_conv_project_split_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
                                 const float* wt, float bt, float base_temp, int B, int gH, int gW, int gD, int Cin,
                                 int O, int kH, int kW, int kD, void* cells, float* s_out, haet_stream_t stream);
+/* Opt-in reduced-term arithmetic for the convolution ("fp16x2": BASELINE config C5 names fp16 MFMA; the reference's own
+ * GPU path is fp16 autocast, velocity-mem-checker.py:49): activations as fp16 hi + fp16 lo (split in the loader), the
+ * weight as ONE fp16 plane W_f16 (same [O][C_in/32][taps][32] layout) -- 2 matrix-core products per term instead of 3.
+ * Measured ~2e-4 relative against fp64 (split-bf16: 4e-6); north_star's bar is 1e-3.  The default everywhere stays
+ * split-bf16; the Python host takes these entry points under haet_amd.set_precision("fp16x2") / HAET_PRECISION=fp16x2. */
+int haet_conv_project_f16_fwd(const float* x, const uint16_t* W_f16, const float* bias, int B, int gH, int gW, int gD,
+                              int Cin, int O, int kH, int kW, int kD, float* out, haet_stream_t stream);
+int haet_conv_project_split_f16_fwd(const float* x, const uint16_t* W_f16, const float* bias, const float* wt, float bt,
+                                    float base_temp, int B, int gH, int gW, int gD, int Cin, int O, int kH, int kW, int kD,
+                                    void* cells, float* s_out, haet_stream_t stream);
 
 /* ------------------------------------------------------------------ stand-alone ErwinFlash on raw point clouds
  * (ErwinTransformer.forward with embed=True / mp_steps>0 on 32k..1M-point clouds,

@@ -647,6 +647,47 @@ def test_conv_projection_split_epilogue(B, grid, Cin, O, k, hip_device):
     assert torch.allclose(1.4426950408889634 / xs.s.double().cpu(), tau.cpu(), rtol=0, atol=2e-5 * float(t.abs().max()))
 
 
+@pytest.fixture
+def fp16x2():
+    """The opt-in reduced-term arithmetic (haet_amd.set_precision): restored after the test."""
+    import haet_amd
+
+    old = haet_amd.precision()
+    haet_amd.set_precision("fp16x2")
+    yield
+    haet_amd.set_precision(old)
+
+
+@pytest.mark.parametrize("B,grid,Cin,O,k", [(2, (9, 7), 32, 128, 3), (1, (12, 10, 9), 256, 256, 3), (2, (40, 40), 256, 256, 3)])
+def test_conv_projection_fp16x2_mode(B, grid, Cin, O, k, hip_device, fp16x2):
+    """haet_conv_project_f16_fwd / haet_conv_project_split_f16_fwd (opt-in "fp16x2": activations fp16 hi + lo, the
+    weight ONE fp16 plane, 2 matrix-core products per term instead of 3) against the fp64 convolution: inside
+    north_star's 1e-3 with margin (measured ~2e-4; the split-bf16 default is held to 2e-5 in the tests above)."""
+    from haet_amd import ops
+
+    torch.manual_seed(sum(grid) + Cin)
+    nd = len(grid)
+    N = 1
+    for g in grid:
+        N *= g
+    x = torch.randn(B, N, Cin)
+    W = torch.randn(O, Cin, *([k] * nd)) * 0.05
+    b = torch.randn(O)
+    xg = x.double().reshape(B, *grid, Cin).permute(0, nd + 1, *range(1, nd + 1))
+    conv = torch.nn.functional.conv2d if nd == 2 else torch.nn.functional.conv3d
+    ref = conv(xg, W.double(), b.double(), padding=k // 2).permute(0, *range(2, nd + 2), 1).reshape(B, N, O)
+    w = ops.SplitConv(W.to(hip_device), b.to(hip_device))
+    out = ops.conv_project(x.to(hip_device), w, grid)
+    err = O_rel(out.cpu(), ref)
+    assert 2e-5 < err < 5e-4, err  # (the lower bound: the fp16 kernel is what ran)
+    if O % 32 == 0:
+        H = O // 32
+        sp = ops.SliceParams(torch.randn(16, 32, device=hip_device) * 0.3, torch.randn(16, device=hip_device) * 0.2,
+                             torch.randn(1, 32, device=hip_device) * 0.3, 0.05, 0.5, 1e-6)
+        xs = ops.conv_project_split(x.to(hip_device), w, grid, sp, H, 32)
+        assert O_rel(xs.to_float().cpu(), ref) < 5e-4
+
+
 @pytest.mark.parametrize("B,grid,Cin,O,k", [(2, (9, 7), 32, 128, 3), (1, (16, 16), 64, 256, 3), (1, (5, 6, 7), 32, 128, 3),
                                            (2, (8, 8, 8), 64, 256, 3), (1, (40, 40), 256, 256, 3), (1, (6, 5, 4), 32, 128, 5)])
 def test_conv_projection_implicit_gemm_vs_fp64(B, grid, Cin, O, k, hip_device):
@@ -853,6 +894,18 @@ def test_big_config_end_to_end(name, hip_device):
     err = O.rel_l2(out.cpu().index_select(1, rows), exp["out_rows"])
     assert err < NORTH_STAR_TOL and err < 10 * FP32_TOL, err
     assert abs(float(out.double().norm()) / float(exp["out_norm"]) - 1.0) < 10 * FP32_TOL
+
+
+def test_c5_widths_under_fp16x2_mode(hip_device, fp16x2):
+    """BASELINE config C5's widths (Structured_Mesh_3D, dim 256 -> 8 x 32, M = 128) end to end with the convolution on
+    the opt-in fp16x2 arithmetic, against the REFERENCE's output: inside north_star's 1e-3."""
+    x, sd, meta, exp, rows = G.load_big("c5_real")
+    mod = _hip_module(meta, sd, hip_device)
+    with torch.no_grad():
+        out = mod(x.to(hip_device))
+    err = O.rel_l2(out.cpu().index_select(1, rows), exp["out_rows"])
+    assert err < NORTH_STAR_TOL, err
+    assert err < 5e-4, err
 
 
 def _conv_rows_fp64(x, weight, bias, grid, rows):
