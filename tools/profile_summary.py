@@ -14,7 +14,8 @@ import sys
 
 SHORT = (("gemm_ws_kernel<8, 4, true", "gemm_ws_split"), ("gemm_ws_kernel", "gemm_ws"), ("deslice_out_kernel", "deslice_out"),
          ("deslice_mfma_kernel", "deslice"), ("slice_mfma_kernel", "slice"), ("slice_merge_kernel", "merge"),
-         ("erwin_kernel<true>", "token_stage"), ("erwin_kernel", "erwin"), ("balltree_wave_kernel", "balltree_wave"),
+         ("erwin2_kernel", "token_stage"), ("erwin_kernel<true>", "token_stage_v1"), ("erwin_kernel", "erwin"),
+         ("slice_bwd_x3_kernel", "slice_bwd_x3"), ("balltree_wave_kernel", "balltree_wave"),
          ("balltree_kernel", "balltree"))
 
 
