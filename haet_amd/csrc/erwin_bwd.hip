@@ -231,6 +231,221 @@ __device__ __forceinline__ void wgrad(float* __restrict__ dW, int ldw, float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the block's Linear products on the bf16 matrix cores (split bf16 x 3, fp32 accumulate: ~2^-16 per product, the
+// forward's grade).  The vector-ALU routines above cost 5-15k cycles per product whatever its size -- a weight-staging
+// round trip through LDS with two barriers, then one LDS read per multiply-add -- and a block has ~40 of them.  Here a wave
+// owns a 32 x 32 output tile: activations come from LDS as 16-B row pieces, weights from the blob copy whose k index is
+// contiguous ([out][in] for y = x W^T, the transposed copy for dx = dy W) as 16-B global loads requested up front,
+// both split to {hi, lo} in registers; no staging, no barrier inside.  Shapes outside 32 | n, 16 | K, 32 | O (the pooling
+// Linears' K = 70) keep the routines above.
+typedef __attribute__((ext_vector_type(8))) __bf16 eb_bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 eb_bf16x2;
+typedef __attribute__((ext_vector_type(16))) float eb_f16v;
+typedef __attribute__((ext_vector_type(4))) float eb_f4;
+typedef __attribute__((ext_vector_type(2))) float eb_f2;
+typedef __attribute__((ext_vector_type(4))) unsigned eb_u4;
+struct EbFrag {
+    eb_u4 hi, lo;
+};
+__device__ __forceinline__ unsigned eb_pack(float a, float b) {
+    eb_f2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, eb_bf16x2));
+}
+__device__ __forceinline__ EbFrag eb_split8(const float (&v)[8]) {
+    EbFrag f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned h = eb_pack(v[2 * i], v[2 * i + 1]);
+        f.hi[i] = h;
+        f.lo[i] = eb_pack(v[2 * i] - __uint_as_float(h << 16), v[2 * i + 1] - __uint_as_float(h & 0xffff0000u));
+    }
+    return f;
+}
+__device__ __forceinline__ EbFrag eb_split(const eb_f4 a, const eb_f4 b) {
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return eb_split8(v);
+}
+__device__ __forceinline__ eb_f16v eb_mfma3(const EbFrag& a, const EbFrag& b, eb_f16v c) {
+    const eb_bf16x8 ah = __builtin_bit_cast(eb_bf16x8, a.hi), al = __builtin_bit_cast(eb_bf16x8, a.lo);
+    const eb_bf16x8 bh = __builtin_bit_cast(eb_bf16x8, b.hi), bl = __builtin_bit_cast(eb_bf16x8, b.lo);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+    return c;
+}
+// One barrier-separated PHASE of independent 32 x 32 tile jobs, dealt round-robin to the eight waves:
+//   gemm part   Y[m][t][o] (=, +=) bias[m][o] + sum_k X[t][k] W[m][o][k]  (+ sum_k X2[t][k] W2[o][k])     m < nmat
+//               (W*: the blob copy with k contiguous; X, Y in LDS; the accumulator is Y^T: rows = outputs, lane = token)
+//   wgrad part  dW[m][o][k] = sum_t A[m][t][o] B[t][k]   -- the contraction runs over the tokens, i.e. over the ROWS of both
+//               LDS buffers: a lane gathers its column's eight tokens of a k-step with eight 4-B reads (consecutive lanes =
+//               consecutive columns: conflict-free); gmode: B = B[t][k] * silu(B2[t][k]) computed in the gather (the
+//               SwiGLU gate is never stored)
+//   db part     db[m][o] = sum_t A[m][t][o]   (eight partial sums per column, three shuffle steps)
+// The weight pieces of a tile are requested in groups of six k-steps, ahead of the activations' LDS reads.  NOT inlined, and
+// the job descriptor travels through LDS (two alternating slots in the idle weight-staging region, written by one thread,
+// read by everybody behind the phase's opening barrier): inlined at its seven call sites the routine was 38k lines of ISA
+// with 161 spill operations, and as a by-value argument the descriptor went through scratch memory.
+struct EbJob {
+    int g_on, Y, Ystep, ldy, X, ldx, X2, n, K, K2, O, nmat, acc, ldk, ldk2;
+    const float *W, *Wb, *W2, *bias, *biasb;
+    int w_on, ldw, A, Astep, lda, B, B2, ldb, wO, wK, wmat, gmode;
+    float *dW, *dWb, *db, *dbb;
+    int stamp;  // (diagnostic build: stamp this phase's inner steps into slots 40..)
+};
+__device__ __forceinline__ int EU(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename P>
+__device__ __forceinline__ P* EUP(P* p) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return reinterpret_cast<P*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void eb_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __attribute__((noinline)) void eb_phase(int JOB) {
+    float* sm = SM();
+    typedef const __attribute__((address_space(1))) eb_f4* gf4;
+#ifdef HAET_STAMPS
+    const unsigned long long st_in = __builtin_amdgcn_s_memtime();
+#endif
+    eb_lds_barrier();  // the job descriptor is in LDS; the producers of the phase's inputs (and the last readers of its outputs) are done
+    const EbJob j = *reinterpret_cast<const EbJob*>(sm + EU(JOB));
+#ifdef HAET_STAMPS
+    const bool st_on = EU(j.stamp) != 0;
+#define ESTAMP(i) do { if (st_on && blockIdx.x == 0 && threadIdx.x == 0 && haet_bwd_stamp_on) haet_bwd_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    if (st_on && blockIdx.x == 0 && threadIdx.x == 0 && haet_bwd_stamp_on) haet_bwd_stamps[52] = st_in;
+    ESTAMP(53);
+#else
+#define ESTAMP(i) do { } while (0)
+#endif
+    // uniform copies
+    const int g_on = EU(j.g_on), Y0 = EU(j.Y), Ystep = EU(j.Ystep), ldy = EU(j.ldy), X = EU(j.X), ldx = EU(j.ldx), X2 = EU(j.X2);
+    const int n = EU(j.n), K = EU(j.K), K2 = EU(j.K2), O = EU(j.O), nmat = EU(j.nmat), accm = EU(j.acc), ldk = EU(j.ldk), ldk2 = EU(j.ldk2);
+    const float *Wa = EUP(j.W), *Wb = EUP(j.Wb), *W2 = EUP(j.W2), *ba = EUP(j.bias), *bb = EUP(j.biasb);
+    const int w_on = EU(j.w_on), ldw = EU(j.ldw), A0 = EU(j.A), Astep = EU(j.Astep), lda = EU(j.lda), B = EU(j.B), B2 = EU(j.B2), ldb = EU(j.ldb);
+    const int wO = EU(j.wO), wK = EU(j.wK), wmat = EU(j.wmat), gmode = EU(j.gmode);
+    float *dWa = EUP(j.dW), *dWb = EUP(j.dWb), *dba = EUP(j.db), *dbb = EUP(j.dbb);
+    const int lane = threadIdx.x & 63, wave = EU(threadIdx.x >> 6), l31 = lane & 31, hf = lane >> 5;
+    constexpr int NWV = kBT / 64, KG = 6;
+    const int wkt = wK >> 5, wtiles = w_on ? wmat * (wO >> 5) * wkt : 0;
+    const int ot_n = O >> 5, gper = (n >> 5) * ot_n, gtiles = g_on ? nmat * gper : 0;
+    const int total = wtiles + gtiles;
+    const int ks1 = K >> 4, ks2 = K2 >> 4, ks_n = ks1 + ks2;  // the k-steps of the second pair follow the first's
+    // decode a gemm tile and fetch one group of its weight pieces
+    struct GT {
+        int m, tt, ot;
+    };
+    auto gdecode = [&](int tile) {
+        GT g;
+        const int r = tile - wtiles;
+        g.m = r / gper;
+        const int q = r - g.m * gper;
+        g.tt = q / ot_n;
+        g.ot = q - g.tt * ot_n;
+        return g;
+    };
+    auto wfetch = [&](const GT& g, int s0, eb_f4 (&w0)[KG], eb_f4 (&w1)[KG]) {
+        const float* r1 = (g.m ? Wb : Wa) + (size_t)(32 * g.ot + l31) * ldk + 8 * hf;
+        const float* r2 = (W2 ? W2 : Wa) + (size_t)(32 * g.ot + l31) * (W2 ? ldk2 : ldk) + 8 * hf;
+#pragma unroll
+        for (int u = 0; u < KG; ++u) {  // (clamped: unconditional loads, an address select instead of a branch)
+            const int s = min(s0 + u, ks_n - 1);
+            const float* wr = s < ks1 ? r1 + 16 * s : r2 + 16 * (s - ks1);
+            w0[u] = *(gf4)wr;
+            w1[u] = *(gf4)(wr + 4);
+        }
+    };
+    eb_f4 w0[KG], w1[KG];
+    ESTAMP(54);
+    for (int tile = wave; tile < total; tile += NWV) {
+        eb_f16v acc;
+        if (tile < wtiles) {
+            // ---- weight-gradient tile
+            const int m = tile / ((wO >> 5) * wkt), q = tile - m * ((wO >> 5) * wkt);
+            const int ot = q / wkt, kt = q - ot * wkt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const int ao = A0 + m * Astep + 32 * ot + l31, bo = B + 32 * kt + l31, bo2 = B2 + 32 * kt + l31;
+            for (int s = 0; s < (n >> 4); ++s) {
+                float av[8], bv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int t = 16 * s + 8 * hf + e;
+                    av[e] = sm[ao + t * lda];
+                    bv[e] = sm[bo + t * ldb];
+                    if (gmode) {  // g = h2 silu(h1): B holds h2, B2 holds h1
+                        const float h1 = sm[bo2 + t * ldb];
+                        bv[e] *= h1 / (1.0f + __expf(-h1));
+                    }
+                }
+                acc = eb_mfma3(eb_split8(av), eb_split8(bv), acc);
+            }
+            float* dW = m ? dWb : dWa;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dW[(size_t)(32 * ot + (r & 3) + 8 * (r >> 2) + 4 * hf) * ldw + 32 * kt + l31] = acc[r];
+        } else {
+            // ---- gemm tile
+            const GT g = gdecode(tile);
+            const int Yb = Y0 + g.m * Ystep, t = 32 * g.tt + l31;
+            const float* bias = g.m ? bb : ba;
+            wfetch(g, 0, w0, w1);  // (ahead of the accumulator's initial values: both are memory round trips)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o4 = 32 * g.ot + 8 * q + 4 * hf;
+                eb_f4 v = {0.f, 0.f, 0.f, 0.f};
+                if (accm) v = *reinterpret_cast<const eb_f4*>(sm + Yb + t * ldy + o4);
+                else if (bias) v = *(gf4)(bias + o4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[4 * q + i] = v[i];
+            }
+            ESTAMP(55);
+            for (int s0 = 0; s0 < ks_n; s0 += KG) {
+                if (s0) wfetch(g, s0, w0, w1);
+                ESTAMP(56);
+#pragma unroll
+                for (int u = 0; u < KG; ++u) {
+                    const int s = s0 + u;
+                    if (s < ks_n) {
+                        const int xr = s < ks1 ? X + t * ldx + 16 * s + 8 * hf : X2 + t * ldx + 16 * (s - ks1) + 8 * hf;
+                        const eb_f4 x0 = *reinterpret_cast<const eb_f4*>(sm + xr);
+                        const eb_f4 x1 = *reinterpret_cast<const eb_f4*>(sm + xr + 4);
+                        acc = eb_mfma3(eb_split(w0[u], w1[u]), eb_split(x0, x1), acc);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const eb_f4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                *reinterpret_cast<eb_f4*>(sm + Yb + t * ldy + 32 * g.ot + 8 * q + 4 * hf) = v;
+            }
+        }
+    }
+    ESTAMP(57);
+    // ---- bias gradients: column sums of A[m] over the tokens, eight partial sums per column
+    if (dba) {
+        for (int idx = threadIdx.x; idx < wmat * wO * 8; idx += kBT) {
+            const int part = idx & 7, col = idx >> 3, m = col / wO, o = col - m * wO;
+            float sacc = 0.f;
+            for (int t = part; t < n; t += 8) sacc += sm[A0 + m * Astep + t * lda + o];
+            sacc += __shfl_xor(sacc, 1);
+            sacc += __shfl_xor(sacc, 2);
+            sacc += __shfl_xor(sacc, 4);
+            if (part == 0) (m ? dbb : dba)[o] = sacc;
+        }
+    }
+    ESTAMP(58);
+}
+// run one phase: descriptor -> LDS slot (alternating: a slot is rewritten only after a full phase has passed), call
+#define EB_RUN(j)                                                                          \
+    do {                                                                                   \
+        const int slot_ = T.WST + (eb_seq & 1) * 64;                                       \
+        ++eb_seq;                                                                          \
+        if (threadIdx.x == 0) *reinterpret_cast<EbJob*>(SM() + slot_) = (j);               \
+        eb_phase(slot_);                                                                   \
+    } while (0)
+static_assert(sizeof(EbJob) <= 64 * 4, "job slot");
+
 struct BwdArgs {
     const float* g_out;
     const float* tape;
@@ -469,7 +684,7 @@ __device__ __forceinline__ void attn_bwd(const BwdDir& T, int QKV, int GO, int D
 }
 
 // one ErwinTransformerBlock, forward recompute + backward; DX (LDS) holds dL/dy on entry, dL/dx on exit
-__device__ __forceinline__ void block_bwd(const BwdArgs& a, const BwdDir& T, const haet_erwin_layer& Ly,
+__device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdDir& T, const haet_erwin_layer& Ly,
                                           const haet_erwin_block_f32& w, float* __restrict__ G, int lvl, int d, int PERM,
                                           const float* __restrict__ tape_in) {
     float* sm = SM();
@@ -478,13 +693,24 @@ __device__ __forceinline__ void block_bwd(const BwdArgs& a, const BwdDir& T, con
     const int DX = T.dX[lvl], XIN = T.XIN, N1 = T.N1, AO = T.AO, XMID = T.XMID, N2 = T.N2, TMP = T.TMP, QKV = T.QKV;
     const int* pm = reinterpret_cast<const int*>(smem) + PERM;
     const float scale = 1.0f / sqrtf((float)hd);
+    // the Linear products as 32 x 32 matrix-core tiles (eb_phase) where the level's shape allows: 32 | tokens, 32 | channels
+    // and hidden width, every buffer 16-B aligned -- the C3 shape at both levels
+    int eb_seq = 0;
+    const bool fast = ((n & 31) | (c & 31) | (hid & 31) | ((DX | XIN | N1 | AO | XMID | N2 | TMP | QKV | T.HREG | a.HB) & 3)) == 0;
     // ---------------- forward recompute
     BSTAMP(0);
     for (int i = threadIdx.x; i < n * c; i += kBT) sm[XIN + i] = tape_in[i];
     rel_pos(T.REL, T.P[lvl], PERM, n, d, ball);  // (ends with a barrier)
     rms_fwd(N1, XIN, T.R1, Wf + w.norm1, n, c, T.REL, d, Wf + w.pe_w, Wf + w.pe_b);
     BSTAMP(1);
-    gemm(T.WST, QKV, 3 * c, N1, c, Wf + w.qkv_wT, 3 * c, Wf + w.qkv_b, n, c, 3 * c, false);
+    if (fast) {
+        EbJob j = {};
+        j.g_on = 1, j.Y = QKV, j.ldy = 3 * c, j.X = N1, j.ldx = c, j.n = n, j.K = c, j.O = 3 * c, j.nmat = 1;
+        j.W = Wf + w.qkv_w, j.ldk = c, j.bias = Wf + w.qkv_b;
+        EB_RUN(j);
+    } else {
+        gemm(T.WST, QKV, 3 * c, N1, c, Wf + w.qkv_wT, 3 * c, Wf + w.qkv_b, n, c, 3 * c, false);
+    }
     __syncthreads();
     BSTAMP(2);
     attn_fwd(T, QKV, AO, n, c, heads, hd, ball, PERM, scale);
@@ -492,7 +718,14 @@ __device__ __forceinline__ void block_bwd(const BwdArgs& a, const BwdDir& T, con
     // x_mid = x + proj(ao)
     for (int i = threadIdx.x; i < n * c; i += kBT) sm[XMID + i] = sm[XIN + i];
     __syncthreads();
-    gemm(T.WST, XMID, c, AO, c, Wf + w.proj_wT, c, nullptr, n, c, c, true);
+    if (fast) {
+        EbJob j = {};
+        j.g_on = 1, j.Y = XMID, j.ldy = c, j.X = AO, j.ldx = c, j.n = n, j.K = c, j.O = c, j.nmat = 1, j.acc = 1;
+        j.W = Wf + w.proj_w, j.ldk = c;
+        EB_RUN(j);
+    } else {
+        gemm(T.WST, XMID, c, AO, c, Wf + w.proj_wT, c, nullptr, n, c, c, true);
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < n * c; i += kBT) sm[XMID + i] += Wf[w.proj_b + i % c];
     __syncthreads();
@@ -500,11 +733,60 @@ __device__ __forceinline__ void block_bwd(const BwdArgs& a, const BwdDir& T, con
     BSTAMP(4);
     // ---------------- SwiGLU backward, hidden width in chunks of hc (three n x hc buffers in the H region)
     for (int i = threadIdx.x; i < n * c; i += kBT) sm[TMP + i] = 0.f;  // dn2 accumulates over the chunks
-    const int hc = min(hid, max(4, (a.HB / n) & ~3));
+    const int hq = a.HB / n;  // chunk width: a multiple of 32 where possible (matrix-core tiles), else of 4
+    const int hc = min(hid, hq >= 32 ? (hq & ~31) : max(4, hq & ~3));
     const int H1 = T.HREG, H2 = T.HREG + a.HB, GG = T.HREG + 2 * a.HB;
     wgrad(nullptr, 0, G + w.w3_b, DX, c, 0, 0, n, c, 0);  // db3 = sum_t dy
     for (int j0 = 0; j0 < hid; j0 += hc) {
         const int hw = min(hc, hid - j0);
+        if (fast && (hw & 31) == 0) {
+            // Four phases per chunk, every 32 x 32 tile of a phase on its own wave (eb_phase):
+            //   A  h1 | h2 = n2 W1c^T + b1 | n2 W2c^T + b2
+            //   C  dW3c = dy^T g  (g = h2 silu(h1) formed in the operand gather, never stored)   ||   dg = dy W3c
+            //   D  dh1, dh2 (element-wise, in place of h1, h2)
+            //   E  dW1c = dh1^T n2, dW2c = dh2^T n2, db1c, db2c   ||   dn2 += dh1 W1c + dh2 W2c
+            if (j0 == 0) BSTAMP(20);
+            {
+                EbJob j = {};
+                j.g_on = 1, j.Y = H1, j.Ystep = H2 - H1, j.ldy = hw, j.X = N2, j.ldx = c, j.n = n, j.K = c, j.O = hw, j.nmat = 2;
+                j.W = Wf + w.w1_w + (size_t)j0 * c, j.Wb = Wf + w.w2_w + (size_t)j0 * c, j.ldk = c;
+                j.bias = Wf + w.w1_b + j0, j.biasb = Wf + w.w2_b + j0;
+                j.stamp = j0 == 0;
+                EB_RUN(j);
+            }
+            if (j0 == 0) BSTAMP(21);
+            if (j0 == 0) BSTAMP(22);
+            {
+                EbJob j = {};
+                j.w_on = 1, j.dW = G + w.w3_w + j0, j.ldw = hid, j.A = DX, j.lda = c, j.B = H2, j.B2 = H1, j.ldb = hw;
+                j.wO = c, j.wK = hw, j.wmat = 1, j.gmode = 1;
+                j.g_on = 1, j.Y = GG, j.ldy = hw, j.X = DX, j.ldx = c, j.n = n, j.K = c, j.O = hw, j.nmat = 1;
+                j.W = Wf + w.w3_wT + (size_t)j0 * c, j.ldk = c;
+                EB_RUN(j);
+            }
+            __syncthreads();
+            if (j0 == 0) BSTAMP(23);
+            if (j0 == 0) BSTAMP(24);
+            for (int i = threadIdx.x; i < n * hw; i += kBT) {
+                const float h1 = sm[H1 + i], h2 = sm[H2 + i], dg = sm[GG + i];
+                const float sg = 1.0f / (1.0f + __expf(-h1));
+                sm[H2 + i] = dg * (h1 * sg);                            // dh2
+                sm[H1 + i] = dg * h2 * (sg * (1.0f + h1 * (1.0f - sg)));  // dh1
+            }
+            if (j0 == 0) BSTAMP(25);
+            {
+                EbJob j = {};
+                j.w_on = 1, j.dW = G + w.w1_w + (size_t)j0 * c, j.dWb = G + w.w2_w + (size_t)j0 * c, j.ldw = c;
+                j.A = H1, j.Astep = H2 - H1, j.lda = hw, j.B = N2, j.ldb = c, j.wO = hw, j.wK = c, j.wmat = 2;
+                j.db = G + w.w1_b + j0, j.dbb = G + w.w2_b + j0;
+                j.g_on = 1, j.Y = TMP, j.ldy = c, j.X = H1, j.X2 = H2, j.ldx = hw, j.n = n, j.K = hw, j.K2 = hw, j.O = c, j.nmat = 1;
+                j.acc = 1, j.W = Wf + w.w1_wT + j0, j.ldk = hid, j.W2 = Wf + w.w2_wT + j0, j.ldk2 = hid;
+                EB_RUN(j);
+            }
+            if (j0 == 0) BSTAMP(26);
+            if (j0 == 0) BSTAMP(27);
+            continue;
+        }
         __syncthreads();
         if (j0 == 0) BSTAMP(20);
         gemm(T.WST, H1, hw, N2, c, Wf + w.w1_wT + j0, hid, Wf + w.w1_b + j0, n, c, hw, false);
@@ -544,16 +826,33 @@ __device__ __forceinline__ void block_bwd(const BwdArgs& a, const BwdDir& T, con
     rms_bwd(DX, TMP, XMID, T.R2, Wf + w.norm2, G + w.norm2, n, c, T.R2 + n);  // DX = dL/dx_mid now
     BSTAMP(6);
     // ---------------- attention branch: x_mid = x + proj(ao) + b
-    wgrad(G + w.proj_w, c, G + w.proj_b, DX, c, AO, c, n, c, c);
-    gemm(T.WST, TMP, c, DX, c, Wf + w.proj_w, c, nullptr, n, c, c, false);  // d ao
+    if (fast) {  // dWp = dx_mid^T ao, dbp   ||   d ao = dx_mid Wp
+        EbJob j = {};
+        j.w_on = 1, j.dW = G + w.proj_w, j.ldw = c, j.A = DX, j.lda = c, j.B = AO, j.ldb = c, j.wO = c, j.wK = c, j.wmat = 1;
+        j.db = G + w.proj_b;
+        j.g_on = 1, j.Y = TMP, j.ldy = c, j.X = DX, j.ldx = c, j.n = n, j.K = c, j.O = c, j.nmat = 1, j.W = Wf + w.proj_wT, j.ldk = c;
+        EB_RUN(j);
+    } else {
+        wgrad(G + w.proj_w, c, G + w.proj_b, DX, c, AO, c, n, c, c);
+        gemm(T.WST, TMP, c, DX, c, Wf + w.proj_w, c, nullptr, n, c, c, false);  // d ao
+    }
     __syncthreads();
     const int DQ = T.HREG;  // dqkv [n][3c] lives in the (now free) H region
     BSTAMP(7);
     attn_bwd(T, QKV, TMP, DQ, n, c, heads, hd, ball, PERM, scale);
     BSTAMP(8);
     // qkv Linear, PE, RMSNorm 1
-    wgrad(G + w.qkv_w, c, G + w.qkv_b, DQ, 3 * c, N1, c, n, 3 * c, c);
-    gemm(T.WST, TMP, c, DQ, 3 * c, Wf + w.qkv_w, c, nullptr, n, 3 * c, c, false);  // dn1
+    if (fast) {  // dWqkv = dqkv^T n1, dbqkv   ||   dn1 = dqkv Wqkv
+        EbJob j = {};
+        j.w_on = 1, j.dW = G + w.qkv_w, j.ldw = c, j.A = DQ, j.lda = 3 * c, j.B = N1, j.ldb = c, j.wO = 3 * c, j.wK = c, j.wmat = 1;
+        j.db = G + w.qkv_b;
+        j.g_on = 1, j.Y = TMP, j.ldy = c, j.X = DQ, j.ldx = 3 * c, j.n = n, j.K = 3 * c, j.O = c, j.nmat = 1;
+        j.W = Wf + w.qkv_wT, j.ldk = 3 * c;
+        EB_RUN(j);
+    } else {
+        wgrad(G + w.qkv_w, c, G + w.qkv_b, DQ, 3 * c, N1, c, n, 3 * c, c);
+        gemm(T.WST, TMP, c, DQ, 3 * c, Wf + w.qkv_w, c, nullptr, n, 3 * c, c, false);  // dn1
+    }
     __syncthreads();
     wgrad(G + w.pe_w, d, G + w.pe_b, TMP, c, T.REL, d, n, c, d);  // d pe_w[k][j] = sum_t dn1[t][k] rel[t][j]
     BSTAMP(9);

@@ -30,3 +30,6 @@ for i in range(1, 11):
 print("first SwiGLU chunk: h1/h2 gemms, g, dW3, dg gemm, dh, dW1+dW2, dn2 gemms:", [t[i + 1] - t[i] for i in range(20, 27)])
 ops = [t[48 - k] for k in range(8)]
 print("per op (reverse order: dec blocks, unpool, bottleneck blocks, pool, enc blocks):", [ops[k + 1] - ops[k] for k in range(7)], "block total", t[10] - t[0])
+
+print("inside eb_phase (phase A of the first chunk, thread 0): entry->barrier+job", t[53] - t[52], "uniform copies", t[54] - t[53],
+      "tile init", t[55] - t[54], "weights requested", t[56] - t[55], "tile done", t[57] - t[56], "db + exit", t[58] - t[57])
