@@ -16,8 +16,8 @@
 //                               d_gamma / d_beta after a grid barrier
 //
 // Positions carry no gradient (attention.py:35, pooling.py:29,59: no_grad in the reference).  Linear layers:
-//   y = x W^T + b   forward   gemm(T.WST, y, x, W^T)      thread = (output, 8 tokens), weights read coalesced from the
-//   dx = dy W       backward  gemm(T.WST, dx, dy, W)      transposed / original fp32 copy in the blob
+//   y = x W^T + b   forward   gemm(T.WSTG, y, x, W^T)      thread = (output, 8 tokens), weights read coalesced from the
+//   dx = dy W       backward  gemm(T.WSTG, dx, dy, W)      transposed / original fp32 copy in the blob
 //   dW = dy^T x                wgrad               thread = one weight, loop over the cloud's tokens in LDS
 // Every parameter gradient of a cloud is produced by exactly one thread in a fixed order and written to that cloud's
 // slice of `grads`; the caller sums the slices.  Cost at the C3 shape: ~0.3 ms for all clouds (8 workgroups), against
@@ -160,7 +160,8 @@ __device__ __forceinline__ void gemm_tile4(int Y, int ldy, int X, int ldx, int W
 __device__ __forceinline__ void gemm(int WST, int Y, int ldy, int X, int ldx, const float* __restrict__ Wg, int ldw,
                                      const float* __restrict__ bias, int n, int K, int O, bool accumulate) {
     float* sm = SM();
-    int ot = kWStage / K;
+    int ot = (WST >> 16) / K;  // WST = offset | stage floats << 16 (BwdDir::WSTG)
+    WST &= 0xffff;
     ot = ot >= 32 ? (ot & ~31) : (ot >= 16 ? 16 : (ot >= 8 ? 8 : (ot > 0 ? ot : 1)));
     for (int o0 = 0; o0 < O; o0 += ot) {
         const int ow = min(ot, O - o0);
@@ -466,7 +467,7 @@ struct BwdArgs {
 struct BwdDir {
     int dX[HAET_ERWIN_MAX_LEVELS], SK[HAET_ERWIN_MAX_LEVELS], P[HAET_ERWIN_MAX_LEVELS], PERM[HAET_ERWIN_MAX_LEVELS];
     int N[HAET_ERWIN_MAX_LEVELS];
-    int IDENT, XIN, N1, AO, XMID, N2, TMP, QKV, HREG, R1, R2, ST, REL, WST, total;
+    int IDENT, XIN, N1, AO, XMID, N2, TMP, QKV, HREG, R1, R2, ST, REL, WST, WSTG, total;
 };
 
 // ---- RMSNorm forward: out[t][k] = x[t][k] r[t] g[k] (+ pe_b[k] + sum_j rel[t][j] pe_w[k][j]),  r -> R[t]
@@ -709,7 +710,7 @@ __device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdD
         j.W = Wf + w.qkv_w, j.ldk = c, j.bias = Wf + w.qkv_b;
         EB_RUN(j);
     } else {
-        gemm(T.WST, QKV, 3 * c, N1, c, Wf + w.qkv_wT, 3 * c, Wf + w.qkv_b, n, c, 3 * c, false);
+        gemm(T.WSTG, QKV, 3 * c, N1, c, Wf + w.qkv_wT, 3 * c, Wf + w.qkv_b, n, c, 3 * c, false);
     }
     __syncthreads();
     BSTAMP(2);
@@ -724,7 +725,7 @@ __device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdD
         j.W = Wf + w.proj_w, j.ldk = c;
         EB_RUN(j);
     } else {
-        gemm(T.WST, XMID, c, AO, c, Wf + w.proj_wT, c, nullptr, n, c, c, true);
+        gemm(T.WSTG, XMID, c, AO, c, Wf + w.proj_wT, c, nullptr, n, c, c, true);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n * c; i += kBT) sm[XMID + i] += Wf[w.proj_b + i % c];
@@ -734,7 +735,8 @@ __device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdD
     // ---------------- SwiGLU backward, hidden width in chunks of hc (three n x hc buffers in the H region)
     for (int i = threadIdx.x; i < n * c; i += kBT) sm[TMP + i] = 0.f;  // dn2 accumulates over the chunks
     const int hq = a.HB / n;  // chunk width: a multiple of 32 where possible (matrix-core tiles), else of 4
-    const int hc = min(hid, hq >= 32 ? (hq & ~31) : max(4, hq & ~3));
+    int hc = min(hid, hq >= 32 ? (hq & ~31) : max(4, hq & ~3));
+    if ((hc & 31) == 0 && (hid & 31) == 0) hc = ((hid / ((hid + hc - 1) / hc) + 31) & ~31);  // equal chunks
     const int H1 = T.HREG, H2 = T.HREG + a.HB, GG = T.HREG + 2 * a.HB;
     wgrad(nullptr, 0, G + w.w3_b, DX, c, 0, 0, n, c, 0);  // db3 = sum_t dy
     for (int j0 = 0; j0 < hid; j0 += hc) {
@@ -789,8 +791,8 @@ __device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdD
         }
         __syncthreads();
         if (j0 == 0) BSTAMP(20);
-        gemm(T.WST, H1, hw, N2, c, Wf + w.w1_wT + j0, hid, Wf + w.w1_b + j0, n, c, hw, false);
-        gemm(T.WST, H2, hw, N2, c, Wf + w.w2_wT + j0, hid, Wf + w.w2_b + j0, n, c, hw, false);
+        gemm(T.WSTG, H1, hw, N2, c, Wf + w.w1_wT + j0, hid, Wf + w.w1_b + j0, n, c, hw, false);
+        gemm(T.WSTG, H2, hw, N2, c, Wf + w.w2_wT + j0, hid, Wf + w.w2_b + j0, n, c, hw, false);
         __syncthreads();
         if (j0 == 0) BSTAMP(21);
         for (int i = threadIdx.x; i < n * hw; i += kBT) {  // g = h2 silu(h1)
@@ -802,7 +804,7 @@ __device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdD
         wgrad(G + w.w3_w + j0, hid, nullptr, DX, c, GG, hw, n, c, hw);  // dW3[o][j0 + j] = sum_t dy[t][o] g[t][j]
         __syncthreads();
         if (j0 == 0) BSTAMP(23);
-        gemm(T.WST, GG, hw, DX, c, Wf + w.w3_w + j0, hid, nullptr, n, c, hw, false);  // dg[t][j] = sum_o dy[t][o] W3[o][j0 + j]
+        gemm(T.WSTG, GG, hw, DX, c, Wf + w.w3_w + j0, hid, nullptr, n, c, hw, false);  // dg[t][j] = sum_o dy[t][o] W3[o][j0 + j]
         __syncthreads();
         if (j0 == 0) BSTAMP(24);
         for (int i = threadIdx.x; i < n * hw; i += kBT) {
@@ -816,9 +818,9 @@ __device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdD
         wgrad(G + w.w1_w + (size_t)j0 * c, c, G + w.w1_b + j0, H1, hw, N2, c, n, hw, c);
         wgrad(G + w.w2_w + (size_t)j0 * c, c, G + w.w2_b + j0, H2, hw, N2, c, n, hw, c);
         if (j0 == 0) BSTAMP(26);
-        gemm(T.WST, TMP, c, H1, hw, Wf + w.w1_w + (size_t)j0 * c, c, nullptr, n, hw, c, true);  // dn2 += dh1 W1[j0.., :]
+        gemm(T.WSTG, TMP, c, H1, hw, Wf + w.w1_w + (size_t)j0 * c, c, nullptr, n, hw, c, true);  // dn2 += dh1 W1[j0.., :]
         __syncthreads();
-        gemm(T.WST, TMP, c, H2, hw, Wf + w.w2_w + (size_t)j0 * c, c, nullptr, n, hw, c, true);
+        gemm(T.WSTG, TMP, c, H2, hw, Wf + w.w2_w + (size_t)j0 * c, c, nullptr, n, hw, c, true);
         if (j0 == 0) BSTAMP(27);
     }
     __syncthreads();
@@ -834,7 +836,7 @@ __device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdD
         EB_RUN(j);
     } else {
         wgrad(G + w.proj_w, c, G + w.proj_b, DX, c, AO, c, n, c, c);
-        gemm(T.WST, TMP, c, DX, c, Wf + w.proj_w, c, nullptr, n, c, c, false);  // d ao
+        gemm(T.WSTG, TMP, c, DX, c, Wf + w.proj_w, c, nullptr, n, c, c, false);  // d ao
     }
     __syncthreads();
     const int DQ = T.HREG;  // dqkv [n][3c] lives in the (now free) H region
@@ -851,7 +853,7 @@ __device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdD
         EB_RUN(j);
     } else {
         wgrad(G + w.qkv_w, c, G + w.qkv_b, DQ, 3 * c, N1, c, n, 3 * c, c);
-        gemm(T.WST, TMP, c, DQ, 3 * c, Wf + w.qkv_w, c, nullptr, n, 3 * c, c, false);  // dn1
+        gemm(T.WSTG, TMP, c, DQ, 3 * c, Wf + w.qkv_w, c, nullptr, n, 3 * c, c, false);  // dn1
     }
     __syncthreads();
     wgrad(G + w.pe_w, d, G + w.pe_b, TMP, c, T.REL, d, n, c, d);  // d pe_w[k][j] = sum_t dn1[t][k] rel[t][j]
@@ -1019,7 +1021,7 @@ __global__ __launch_bounds__(kBT) void erwin_bwd_kernel(BwdArgs a, BwdDir T) {
                 sm[ROWS + i] = v;
             }
             __syncthreads();
-            gemm(T.WST, U, st * c, ROWS, K, a.Wf + rw.wT, st * c, a.Wf + rw.b, n2, K, st * c, false);
+            gemm(T.WSTG, U, st * c, ROWS, K, a.Wf + rw.wT, st * c, a.Wf + rw.b, n2, K, st * c, false);
             __syncthreads();
             // s (pre-BatchNorm) [n][c] = children.x + 'n (m d) -> (n m) d' of u
             for (int i = threadIdx.x; i < n * c; i += kBT) {
@@ -1038,7 +1040,7 @@ __global__ __launch_bounds__(kBT) void erwin_bwd_kernel(BwdArgs a, BwdDir T) {
             __syncthreads();
             wgrad(G + rw.w, K, G + rw.b, U, st * c, ROWS, K, n2, st * c, K);
             // dx (level l+1) = du W[:, :c2]
-            gemm(T.WST, T.dX[l + 1], c2, U, st * c, a.Wf + rw.w, K, nullptr, n2, st * c, c2, false);
+            gemm(T.WSTG, T.dX[l + 1], c2, U, st * c, a.Wf + rw.w, K, nullptr, n2, st * c, c2, false);
             __syncthreads();
         } else {
             // ---- BallPooling (pooling.py:25-40), level l -> l+1: z = BN(proj([x_(n s) c -> n (s c), rel]))
@@ -1061,12 +1063,12 @@ __global__ __launch_bounds__(kBT) void erwin_bwd_kernel(BwdArgs a, BwdDir T) {
                 sm[ROWS + i] = v;
             }
             __syncthreads();
-            gemm(T.WST, Yb, c2, ROWS, K, a.Wf + rw.wT, c2, a.Wf + rw.b, n2, K, c2, false);
+            gemm(T.WSTG, Yb, c2, ROWS, K, a.Wf + rw.wT, c2, a.Wf + rw.b, n2, K, c2, false);
             __syncthreads();
             bn_bwd(a, T, T.dX[l + 1], c2, Yb, n2, c2, rw, D.pool[l].bn_eps, train, 2 * l, cloud, n_clouds, epoch, total);
             wgrad(G + rw.w, K, G + rw.b, T.dX[l + 1], c2, ROWS, K, n2, c2, K);
             // d rows[:, :st*c] -> dL/dx (level l), plus the skip gradient of the unpool
-            gemm(T.WST, T.TMP, st * c, T.dX[l + 1], c2, a.Wf + rw.w, K, nullptr, n2, c2, st * c, false);
+            gemm(T.WSTG, T.TMP, st * c, T.dX[l + 1], c2, a.Wf + rw.w, K, nullptr, n2, c2, st * c, false);
             __syncthreads();
             for (int i = threadIdx.x; i < n * c; i += kBT) {
                 const int t = i / c, k = i - t * c;
@@ -1127,14 +1129,33 @@ static bool bwd_directory(const haet_erwin_desc& D, int Mp, BwdDir* T, int* HB_o
         need = need > k2 ? need : k2;
     }
     while (3 * HB < need) HB += 256;
+    int st_floats = 3 * hmax;
+    st_floats = st_floats > 4 * cmax ? st_floats : 4 * cmax;
+    // Where every level has the matrix-core shape (block_bwd's `fast`), only the resampling Linears still stage their
+    // weights through LDS: half the staging tile goes to the H region, and the H region then grows as far as 160 KB
+    // allows -- wider SwiGLU chunks are fewer, fatter eb_phase phases (C3: 64 / 128 hidden columns per chunk, not 32 / 96)
+    int wstage = kWStage;
+    bool mc = true;
+    for (int l = 0; l < D.n_levels; ++l) {
+        mc = mc && ((T->N[l] | D.enc[l].c | D.enc[l].hidden) & 31) == 0;
+        if (l < D.n_levels - 1 && D.dec[l].depth > 0) mc = mc && ((D.dec[l].c | D.dec[l].hidden) & 31) == 0;
+    }
+    if (mc) wstage = kWStage / 2;
+    const int fixed = p + 4 * nmax + st_floats + ((nmax * d + 3) & ~3) + wstage;
+    int hb_cap = 0;  // no use beyond the widest n x hidden
+    for (int l = 0; l < D.n_levels; ++l) {
+        int hid = D.enc[l].hidden;
+        if (l < D.n_levels - 1 && D.dec[l].depth > 0 && D.dec[l].hidden > hid) hid = D.dec[l].hidden;
+        hb_cap = hb_cap > T->N[l] * hid ? hb_cap : T->N[l] * hid;
+    }
+    while (mc && HB + 256 <= hb_cap && (size_t)(fixed + 3 * (HB + 256)) * 4 <= 160 * 1024) HB += 256;
     T->HREG = p; p += 3 * HB;
     T->R1 = p; p += 2 * nmax;
     T->R2 = p; p += 2 * nmax;
-    int st_floats = 3 * hmax;
-    st_floats = st_floats > 4 * cmax ? st_floats : 4 * cmax;
     T->ST = p; p += st_floats;
     T->REL = p; p += (nmax * d + 3) & ~3;
-    T->WST = p; p += kWStage;
+    T->WST = p; p += wstage;
+    T->WSTG = T->WST | wstage << 16;
     T->total = p;
     *HB_out = HB;
     *cmax_out = cmax;
