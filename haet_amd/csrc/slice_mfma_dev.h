@@ -40,15 +40,33 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
+// Two fp32 -> their split-bf16 pair: hi = RNE(a), RNE(b) packed; lo = RNE(a - hi_a), RNE(b - hi_b) packed.  The
+// residuals come from v_dot2c_f32_bf16 (a + hi . {-1, 0}, b + hi . {0, -1}: both exact, the residual of an 8-bit
+// rounding has at most 16 significant bits): four vector instructions per pair instead of five with shift / mask /
+// subtract -- these passes are bound by the vector issue port as much as by the matrix pipe.
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const f32x2 v = {a, b};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    // (the selectors {-1, 0} / {0, -1} as opaque scalar bit patterns: left to the compiler the first becomes the INLINE
+    // constant -1.0, whose expansion for a packed-bf16 operand is not the pattern 0x0000bf80)
+    unsigned k0, k1;
+    asm("s_mov_b32 %0, 0xbf80" : "=s"(k0));
+    asm("s_mov_b32 %0, 0xbf800000" : "=s"(k1));
+    const float la = __builtin_amdgcn_fdot2_f32_bf16(h, __builtin_bit_cast(bf16x2, k0), a, false);
+    const float lb = __builtin_amdgcn_fdot2_f32_bf16(h, __builtin_bit_cast(bf16x2, k1), b, false);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = pack_bf16(la, lb);
+}
+
 // 8 fp32 -> split-bf16 operand fragment (element j in bf16 slot j)
 __device__ __forceinline__ Frag split8(const float (&v)[8]) {
     Frag f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const unsigned h = pack_bf16(v[2 * i], v[2 * i + 1]);
-        const float h0 = __uint_as_float(h << 16), h1 = __uint_as_float(h & 0xffff0000u);
+        unsigned h, l;
+        split2(v[2 * i], v[2 * i + 1], h, l);
         f.hi[i] = h;
-        f.lo[i] = pack_bf16(v[2 * i] - h0, v[2 * i + 1] - h1);
+        f.lo[i] = l;
     }
     return f;
 }
