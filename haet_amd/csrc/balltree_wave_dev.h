@@ -242,12 +242,14 @@ __device__ __forceinline__ void w_barrier() { asm volatile("s_waitcnt lgkmcnt(0)
 // EVERY wave of the workgroup calls this the same number of times (the barrier is the workgroup's);
 // `work` = false just keeps the barrier count.
 __device__ __forceinline__ void w_shared_level(LaneArr& a, float cx, float cy, float cz, int nd, int n, int sz,
-                                               bool work, int me, int nw, int ex) {  // ex: index into haet_wex
+                                               bool work, int me, int nw, int ex, int sb = -1) {  // ex: index into haet_wex
     const int lane = threadIdx.x & 63;
     if (work) {
         w_level_keys(a, cx, cy, cz, nd, sz);
+        if (sb >= 0) TSTAMP(sb);
         const int nodes = n / sz;
         for (int j = me; j < nodes; j += nw) w_select_nth(a, j * sz, j * sz + sz / 2, j * sz + sz);
+        if (sb >= 0) TSTAMP(sb + 1);
         if (lane < n && (lane / sz) % nw == me) haet_wex[ex + lane] = a.idx;
     }
     w_barrier();
@@ -365,7 +367,7 @@ __device__ __forceinline__ void w_tree_build(const WTreeCfg& cfg, const float* _
         int lv = 0;
         for (int sz = M; sz > 2; sz >>= 1, par ^= 1) {
             step(istep++);
-            w_shared_level(a, cx, cy, cz, nd, M, sz, true, wave, TW, par * 64);
+            w_shared_level(a, cx, cy, cz, nd, M, sz, true, wave, TW, par * 64, 16 + 2 * lv);
             TSTAMP(2 + lv);
             ++lv;
             (void)lv;

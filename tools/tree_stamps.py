@@ -22,6 +22,7 @@ assert lib.haet_debug_read_tree_stamps(buf) == 0
 t = list(buf)
 print("token positions:", t[1] - t[0], "cycles")
 print("main tree levels (64, 32, 16, 8, 4):", [t[2 + i] - t[1 + i] for i in range(5)])
+print("  inside each main level [keys, selects, exchange + barrier]:", [[t[16 + 2 * i] - t[1 + i], t[17 + 2 * i] - t[16 + 2 * i], t[2 + i] - t[17 + 2 * i]] for i in range(5)])
 print("to the start of the rotated re-partitions:", t[10] - t[6])
 print("rotated levels (two hierarchy levels at once):", [t[11 + i] - t[10 + i] for i in range(4)])
 print("total:", t[14] - t[0], "cycles")
