@@ -81,6 +81,13 @@ int haet_linear_fwd(const float* x /*[Nrows,K]*/, const uint16_t* W_hi, const ui
  * x_lin [B, N, H*C] is the output of in_project_x in its natural layout (the
  * reference's permute to [B,H,N,C], IrregularMesh.py:157-164, is never done).
  *
+ * ACCURACY DOMAIN (declared): at the C = 32 shapes the logits come from split-bf16 products (operand error ~2^-16) and
+ * enter an exponential, so the relative error of a slice weight grows with the logit: measured end to end against
+ * the fp32 reference 6e-6 at the trained-weight scale (|z| up to ~15), <= 1e-3 -- the bar of this path -- for
+ * |z| <~ 60, 4e-3 at |z| ~ 300 (tests/test_gpu_parity.py::test_c3_module_small_and_scaled_clouds).
+ * Inputs beyond that are served by the exact-f32 families, which every shape can be routed to: HAET_FORCE_F32_MFMA=1
+ * (v_mfma_f32_32x32x2_f32, exact f32 products) or HAET_FORCE_VALU=1 (generic fp32 kernels), read when the library loads.
+ *
  * The pass produces `P = haet_slice_num_parts(...)` partial records, one per
  * point chunk.  A record holds, for every (b,h,g):  m = max_n z, l = sum_n
  * exp(z - m), St[c] = sum_n exp(z - m) x[n,c]  with z = (x.Ws[g] + bs[g] - c0)/tau_n,
