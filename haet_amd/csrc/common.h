@@ -94,4 +94,22 @@ __device__ __forceinline__ float ada_temp(float t, float base_temp) {
     return base_temp + fminf(fmaxf(t, -0.4f), 0.4f);
 }
 
+#if defined(__HIPCC__)
+// Two fp32 -> their split-bf16 pair: hi = {RNE(a), RNE(b)} packed, lo = {RNE(a - hi_a), RNE(b - hi_b)} packed
+// (five vector instructions: v_cvt_pk, shift, mask, v_pk_add, v_cvt_pk).
+__device__ __forceinline__ void split_bf16_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 sp_bf16x2;
+    typedef __attribute__((ext_vector_type(2))) float sp_f32x2;
+    const sp_f32x2 v = {a, b};
+    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, sp_bf16x2));
+    const sp_f32x2 l = {a - __uint_as_float(hb << 16), b - __uint_as_float(hb & 0xffff0000u)};
+    hi = hb;
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(l, sp_bf16x2));
+}
+// (Measured and rejected, round 3: the residuals from v_dot2c_f32_bf16 -- a + hi . {-1, 0}, b + hi . {0, -1}, exact, four
+// instructions per pair -- are no faster anywhere and slower in the GEMM loader and the slice pass; packed v_pk_fma_f32
+// exponent arguments likewise.  The dot-product selector also must not be left to hipcc: 0x0000bf80 becomes the INLINE
+// constant -1.0, which the hardware expands to another bit pattern for a packed-bf16 operand.  DESIGN.md 5b.)
+#endif
+
 }  // namespace haet

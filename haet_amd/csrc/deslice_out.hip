@@ -223,10 +223,10 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
         Frag pf, pn;  // operand of the running M(s) / being built by V(s + 1)
         // V(0) alone
 #pragma unroll
-        for (int j = 0; j < 4; j += 2) {  // (v_pk_fma_f32: two arguments per instruction)
+        for (int j = 0; j < 4; j += 2) {  // (plain v_fma_f32: the packed v_pk_fma_f32 measured 1.4 % slower)
             const f32x2 ya = {Y[j], Y[j + 1]}, yc = {Y[4 + j], Y[5 + j]};
-            const f32x2 m0 = {ma[j], ma[j + 1]}, m1 = {mb[j], mb[j + 1]}, s2 = {sn, sn};
-            const f32x2 ea = __builtin_elementwise_fma(ya, s2, -m0), ec = __builtin_elementwise_fma(yc, s2, -m1);
+            const f32x2 m0 = {ma[j], ma[j + 1]}, m1 = {mb[j], mb[j + 1]};
+            const f32x2 ea = {fmaf(ya[0], sn, -m0[0]), fmaf(ya[1], sn, -m0[1])}, ec = {fmaf(yc[0], sn, -m1[0]), fmaf(yc[1], sn, -m1[1])};
             pv[j] = __builtin_amdgcn_exp2f(ea[0]), pv[j + 1] = __builtin_amdgcn_exp2f(ea[1]);
             pv[4 + j] = __builtin_amdgcn_exp2f(ec[0]), pv[5 + j] = __builtin_amdgcn_exp2f(ec[1]);
         }
@@ -243,10 +243,10 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
             if (more) {
                 sfl = *reinterpret_cast<const u32x4*>(smem + sfo + (s_ + 1) * 2048 + 1024);  // next stage's lo plane
 #pragma unroll
-                for (int j = 0; j < 4; j += 2) {  // (v_pk_fma_f32: two arguments per instruction)
+                for (int j = 0; j < 4; j += 2) {  // (plain v_fma_f32: the packed v_pk_fma_f32 measured 1.4 % slower)
                     const f32x2 ya = {Y[yb + j], Y[yb + j + 1]}, yc = {Y[yb + 4 + j], Y[yb + 5 + j]};
-                    const f32x2 m0 = {ma[j], ma[j + 1]}, m1 = {mb[j], mb[j + 1]}, s2 = {sn, sn};
-                    const f32x2 ea = __builtin_elementwise_fma(ya, s2, -m0), ec = __builtin_elementwise_fma(yc, s2, -m1);
+                    const f32x2 m0 = {ma[j], ma[j + 1]}, m1 = {mb[j], mb[j + 1]};
+                    const f32x2 ea = {fmaf(ya[0], sn, -m0[0]), fmaf(ya[1], sn, -m0[1])}, ec = {fmaf(yc[0], sn, -m1[0]), fmaf(yc[1], sn, -m1[1])};
                     pv[j] = __builtin_amdgcn_exp2f(ea[0]), pv[j + 1] = __builtin_amdgcn_exp2f(ea[1]);
                     pv[4 + j] = __builtin_amdgcn_exp2f(ec[0]), pv[5 + j] = __builtin_amdgcn_exp2f(ec[1]);
                 }

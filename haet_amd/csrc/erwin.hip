@@ -543,9 +543,9 @@ __device__ __forceinline__ unsigned pack2_bf16(float a, float b) {  // v_cvt_pk_
 __device__ __forceinline__ void split8v(const float (&v)[8], u32x4& hi, u32x4& lo) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const unsigned h = pack2_bf16(v[2 * i], v[2 * i + 1]);
-        hi[i] = h;
-        lo[i] = pack2_bf16(v[2 * i] - __uint_as_float(h << 16), v[2 * i + 1] - __uint_as_float(h & 0xffff0000u));
+        unsigned h, l;
+        split_bf16_pair(v[2 * i], v[2 * i + 1], h, l);
+        hi[i] = h, lo[i] = l;
     }
 }
 __device__ __forceinline__ f32x16 mfma3_32(u32x4 ah, u32x4 al, u32x4 bh, u32x4 bl, f32x16 c) {

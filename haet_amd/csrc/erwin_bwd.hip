@@ -257,9 +257,9 @@ __device__ __forceinline__ EbFrag eb_split8(const float (&v)[8]) {
     EbFrag f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const unsigned h = eb_pack(v[2 * i], v[2 * i + 1]);
-        f.hi[i] = h;
-        f.lo[i] = eb_pack(v[2 * i] - __uint_as_float(h << 16), v[2 * i + 1] - __uint_as_float(h & 0xffff0000u));
+        unsigned h, l;
+        split_bf16_pair(v[2 * i], v[2 * i + 1], h, l);
+        f.hi[i] = h, f.lo[i] = l;
     }
     return f;
 }

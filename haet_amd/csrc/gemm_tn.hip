@@ -28,9 +28,9 @@ __device__ __forceinline__ unsigned tn_pack(float a, float b) {  // v_cvt_pk_bf1
 __device__ __forceinline__ void tn_split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const unsigned h = tn_pack(v[2 * i], v[2 * i + 1]);
-        hi[i] = h;
-        lo[i] = tn_pack(v[2 * i] - __uint_as_float(h << 16), v[2 * i + 1] - __uint_as_float(h & 0xffff0000u));
+        unsigned h, l;
+        split_bf16_pair(v[2 * i], v[2 * i + 1], h, l);
+        hi[i] = h, lo[i] = l;
     }
 }
 
@@ -267,10 +267,11 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const float* __restrict
         }
     };
     auto put = [&](int base, int row, const f4v v) {  // 4 consecutive columns of one row -> the 8-B {hi} and {lo} pieces
-        const unsigned h01 = tn_pack(v[0], v[1]), h23 = tn_pack(v[2], v[3]);
+        unsigned h01, l01, h23, l23;
+        split_bf16_pair(v[0], v[1], h01, l01);
+        split_bf16_pair(v[2], v[3], h23, l23);
         const tn_u32x2 hi = {h01, h23};
-        const tn_u32x2 lo = {tn_pack(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xffff0000u)),
-                             tn_pack(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xffff0000u))};
+        const tn_u32x2 lo = {l01, l23};
         const int off = base + tn_img_off(row, q8 >> 1) + ((q8 & 1) << 3);
         *reinterpret_cast<tn_u32x2*>(tsm + off) = hi;
         *reinterpret_cast<tn_u32x2*>(tsm + off + kImg) = lo;

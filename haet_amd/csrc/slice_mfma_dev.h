@@ -40,23 +40,7 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
-// Two fp32 -> their split-bf16 pair: hi = RNE(a), RNE(b) packed; lo = RNE(a - hi_a), RNE(b - hi_b) packed.  The
-// residuals come from v_dot2c_f32_bf16 (a + hi . {-1, 0}, b + hi . {0, -1}: both exact, the residual of an 8-bit
-// rounding has at most 16 significant bits): four vector instructions per pair instead of five with shift / mask /
-// subtract -- these passes are bound by the vector issue port as much as by the matrix pipe.
-__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-    const f32x2 v = {a, b};
-    const bf16x2 h = __builtin_convertvector(v, bf16x2);
-    // (the selectors {-1, 0} / {0, -1} as opaque scalar bit patterns: left to the compiler the first becomes the INLINE
-    // constant -1.0, whose expansion for a packed-bf16 operand is not the pattern 0x0000bf80)
-    unsigned k0, k1;
-    asm("s_mov_b32 %0, 0xbf80" : "=s"(k0));
-    asm("s_mov_b32 %0, 0xbf800000" : "=s"(k1));
-    const float la = __builtin_amdgcn_fdot2_f32_bf16(h, __builtin_bit_cast(bf16x2, k0), a, false);
-    const float lb = __builtin_amdgcn_fdot2_f32_bf16(h, __builtin_bit_cast(bf16x2, k1), b, false);
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = pack_bf16(la, lb);
-}
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) { split_bf16_pair(a, b, hi, lo); }  // (common.h)
 
 // 8 fp32 -> split-bf16 operand fragment (element j in bf16 slot j)
 __device__ __forceinline__ Frag split8(const float (&v)[8]) {
@@ -64,7 +48,7 @@ __device__ __forceinline__ Frag split8(const float (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         unsigned h, l;
-        split2(v[2 * i], v[2 * i + 1], h, l);
+        split_bf16_pair(v[2 * i], v[2 * i + 1], h, l);
         f.hi[i] = h;
         f.lo[i] = l;
     }
@@ -200,11 +184,11 @@ struct Loader {
                 t += dpp<0xB1>(t);   // quad_perm [1,0,3,2]
                 t += dpp<0x4E>(t);   // quad_perm [2,3,0,1]
                 t += dpp<0x141>(t);  // row_half_mirror: the other quad of the 8-lane group
-                const unsigned h01 = pack_bf16(v[0], v[1]), h23 = pack_bf16(v[2], v[3]);
-                const float a0 = __uint_as_float(h01 << 16), a1 = __uint_as_float(h01 & 0xffff0000u);
-                const float a2 = __uint_as_float(h23 << 16), a3 = __uint_as_float(h23 & 0xffff0000u);
+                unsigned h01, l01, h23, l23;
+                split_bf16_pair(v[0], v[1], h01, l01);
+                split_bf16_pair(v[2], v[3], h23, l23);
                 const u32x2 hi = {h01, h23};
-                const u32x2 lo = {pack_bf16(v[0] - a0, v[1] - a1), pack_bf16(v[2] - a2, v[3] - a3)};
+                const u32x2 lo = {l01, l23};
                 *reinterpret_cast<u32x2*>(smem + buf + loff[i]) = hi;
                 *reinterpret_cast<u32x2*>(smem + buf + loff[i] + IMG) = lo;
                 if (q8 == 0)  // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division
