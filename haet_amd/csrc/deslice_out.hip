@@ -17,8 +17,9 @@
 //       Ot overwrites it as the head's O image [hi|lo][32 points][32 channels] (split bf16).
 //   -- ONE workgroup barrier per tile; two buffers of 8 x {hi, lo} images --
 //   [B] wave w: out^T[o,n] = b_o + sum_{h,c} W_out[o, 32h+c] O_h[n,c]  (A = W_out rows o = 32w.., kept in 128 VGPRs
-//       for the lifetime of the kernel like gemm_ws_kernel's; B = rows of the O image), 48 MFMAs, then four 16-B
-//       stores per lane (its point's 16 outputs of this wave's 32 columns).
+//       for the lifetime of the kernel like gemm_ws_kernel's; B = rows of the O image) as four 16 x 16 tiles on
+//       v_mfma_f32_16x16x32_bf16 (96 MFMAs of 16 cycles; same matrix-pipe cycles as 48 of the 32x32x16 shape, but the
+//       chip holds a higher clock under it: 0.594 -> 0.578 ms, same-box A/B), then four 16-B stores per lane.
 // Round 3: [A] of tile t + 1 and [B] of tile t are independent, so the two waves of a SIMD (w, w + 4) run them half a
 // tile apart -- waves 4-7 take the barrier BEFORE their [B] -- and inside [A] the instruction order is pinned by hand
 // (vector work behind the MFMA it shadows, LDS reads a stage early); see the loop.  Measured with the stamped build
@@ -82,14 +83,20 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
     for (int i = threadIdx.x; i < kDO; i += 512) *reinterpret_cast<float*>(smem + boL + 4 * i) = bias_out ? bias_out[i] : 0.f;
     stage_ws(wimg, Ws, M);
 
-    // stationary A fragments of the GEMM: rows o = 32 wave + l31 of W_out, k-step ks (16 wide): k = 16 ks + 8 hf ..
+    // stationary A fragments of the GEMM ([B] runs v_mfma_f32_16x16x32_bf16: the chip holds a higher clock under this
+    // shape than under 32x32x16 at equal cycles per flop, MI355X_MICROARCH.md 'DVFS give-back' (7)): rows
+    // o = 32 wave + 16 io + lane % 16 of W_out, k-step ks = head (32 wide): k = 32 ks + 8 (lane / 16) ..
+    const int l15 = lane & 15, kg = lane >> 4;
     u32x4 wh[16], wl[16];
     {
-        const size_t o = (size_t)(32 * wave + l31) * kDO + 8 * hf;
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            wh[ks] = *reinterpret_cast<const u32x4*>(Whi + o + 16 * ks);
-            wl[ks] = *reinterpret_cast<const u32x4*>(Wlo + o + 16 * ks);
+        for (int io = 0; io < 2; ++io) {
+            const size_t o = (size_t)(32 * wave + 16 * io + l15) * kDO + 8 * kg;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                wh[2 * ks + io] = *reinterpret_cast<const u32x4*>(Whi + o + 32 * ks);
+                wl[2 * ks + io] = *reinterpret_cast<const u32x4*>(Wlo + o + 32 * ks);
+            }
         }
     }
     // S'/l fragments of this wave's head (A operand of the de-slice product: row c = l31, k = g in accumulator order)
@@ -309,37 +316,48 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
     //      (the next head's four fragment reads are issued before this head's six MFMAs: ~190 cycles of cover)
     auto phaseB = [&](int ob_, int t, bool real) {
         const int nvalid = real ? N - t * TN : 0;  // (a ghost turn: a descriptor of zero rows drops the stores)
-        f32x16 acc;
+        // four 16 x 16 tiles: acc[io][jn][r] = out^T[o = 32 wave + 16 io + 4 kg + r][n = 16 jn + lane % 16]
+        f32x4 acc[2][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(smem + boL + 4 * (32 * wave + 8 * i + 4 * hf));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[4 * i + q] = b4[q];
+        for (int io = 0; io < 2; ++io) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(smem + boL + 4 * (32 * wave + 16 * io + 4 * kg));
+            acc[io][0] = b4, acc[io][1] = b4;
         }
-        // residual rows of this lane's point (the block's `Attn(ln_1(fx)) + fx`, HAETransolver_Irregular_Mesh.py:125)
-        f32x4 res[4];
-        Frag oc0 = read_rows(ob_, l31, hf), oc1 = read_rows(ob_, l31, 2 + hf);
+        // residual rows of this lane's points (the block's `Attn(ln_1(fx)) + fx`, HAETransolver_Irregular_Mesh.py:125)
+        f32x4 res[2][2];
+        // B operand of k-step h (= head h): column n = 16 jn + lane % 16, k = 8 kg .. 8 kg + 7 of the head's 32 channels
+        Frag oc0 = read_rows(ob_, l15, kg), oc1 = read_rows(ob_, 16 + l15, kg);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             Frag on0, on1;
             if (h + 1 < H) {
-                on0 = read_rows(ob_ + (h + 1) * (2 * IMG), l31, hf);
-                on1 = read_rows(ob_ + (h + 1) * (2 * IMG), l31, 2 + hf);
+                on0 = read_rows(ob_ + (h + 1) * (2 * IMG), l15, kg);
+                on1 = read_rows(ob_ + (h + 1) * (2 * IMG), 16 + l15, kg);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!(dbg & 2)) {
-                Frag wf;
-                wf.hi = wh[2 * h], wf.lo = wl[2 * h];
-                acc = mfma3(wf, oc0, acc);
-                wf.hi = wh[2 * h + 1], wf.lo = wl[2 * h + 1];
-                acc = mfma3(wf, oc1, acc);
+#pragma unroll
+                for (int io = 0; io < 2; ++io) {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[2 * h + io]), al = __builtin_bit_cast(bf16x8, wl[2 * h + io]);
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn) {
+                        const Frag& of = jn ? oc1 : oc0;
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, of.hi), bl = __builtin_bit_cast(bf16x8, of.lo);
+                        acc[io][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[io][jn], 0, 0, 0);
+                        acc[io][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[io][jn], 0, 0, 0);
+                        acc[io][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[io][jn], 0, 0, 0);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (h + 1 < H) oc0 = on0, oc1 = on1;
-            if (RES && h == 1) {  // requested behind the first 12 MFMAs (registers), added after the last (rows past the end: clamped, never stored)
-                const float* rrow = rb + (size_t)min((real ? t : t_begin) * TN + l31, N - 1) * kDO + 32 * wave + 4 * hf;
+            if (RES && h == 1) {  // requested behind the first MFMAs (registers), added after the last (rows past the end: clamped, never stored)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) res[i] = *reinterpret_cast<const f32x4*>(rrow + 8 * i);
+                for (int jn = 0; jn < 2; ++jn) {
+                    const float* rrow = rb + (size_t)min((real ? t : t_begin) * TN + 16 * jn + l15, N - 1) * kDO + 32 * wave + 4 * kg;
+#pragma unroll
+                    for (int io = 0; io < 2; ++io) res[io][jn] = *reinterpret_cast<const f32x4*>(rrow + 16 * io);
+                }
             }
         }
         // Stores through a buffer descriptor over THIS tile's valid rows: rows past the end of the cloud fall outside
@@ -348,13 +366,15 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
         const int rows = nvalid < TN ? nvalid : TN;
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<char*>(ob) + (size_t)(real ? t : t_begin) * TN * (kDO * 4), 0, rows * (kDO * 4), 0x00020000);
-        const int voff = l31 * (kDO * 4) + (32 * wave + 4 * hf) * 4;
+        const int voff = l15 * (kDO * 4) + (32 * wave + 4 * kg) * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 v = {acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]};
-            if (RES) v += res[i];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff, 32 * i, 0);
-        }
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int io = 0; io < 2; ++io) {
+                f32x4 v = acc[io][jn];
+                if (RES) v += res[io][jn];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff, 16 * jn * (kDO * 4) + 64 * io, 0);
+            }
     };
 
     // ---- the loop.  Two buffers of 8 x {hi, lo} images and ONE workgroup barrier per tile.  A turn of the loop:
@@ -379,10 +399,10 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
         const int rows0 = N - t_begin * TN < TN ? N - t_begin * TN : TN;
         __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
             reinterpret_cast<char*>(ob) + (size_t)t_begin * TN * (kDO * 4), 0, rows0 * (kDO * 4), 0x00020000);
-        const int voff = l31 * (kDO * 4) + (32 * wave + 4 * hf) * 4;
+        const int voff = l15 * (kDO * 4) + (32 * wave + 4 * kg) * 4;
         const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(z, r0, voff, 32 * i, 0);
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(z, r0, voff, 16 * (i >> 1) * (kDO * 4) + 64 * (i & 1), 0);
     }
     __syncthreads();  // constants (bias, m2, Ws images) staged by all threads
     int cur = 0, nxt = oimg0;
@@ -423,6 +443,15 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
     asm volatile("" ::"v"(touch_acc));
 }
 
+static int do_dbg() {  // HAET_DO_DBG: ablation switches of the stamped build (read per launch there, ignored otherwise)
+#ifdef HAET_STAMPS
+    const char* e = getenv("HAET_DO_DBG");
+    return e ? atoi(e) : 0;
+#else
+    return 0;
+#endif
+}
+
 template <int MB>
 static int deslice_out_launch(const float* x, const float* s_in, const float* Ws, const float* bs, float c0,
                               const float* cm, const float* cs, const float* S2, const unsigned short* Whi,
@@ -445,7 +474,7 @@ static int deslice_out_launch(const float* x, const float* s_in, const float* Ws
     if (wgs < 1) wgs = 1;
     dim3 grid(n_tiles < wgs ? n_tiles : wgs, B);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, x, s_in, Ws, bs, c0, cm, cs, S2, Whi, Wlo, bias, residual, N, out,
-                       getenv("HAET_DO_DBG") ? atoi(getenv("HAET_DO_DBG")) : 0);
+                       do_dbg());
     return check_launch("deslice_out_kernel");
 }
 
@@ -460,7 +489,8 @@ extern "C" int haet_debug_read_do_stamps(unsigned long long* host_out) {
 #endif
 
 extern "C" int haet_deslice_out_supported(int H, int C, int M, int O) {
-    return H == 8 && C == 32 && O == 256 && (M == 32 || M == 64) && !getenv("HAET_NO_DESLICE_OUT");
+    static const bool off = getenv("HAET_NO_DESLICE_OUT") != nullptr;  // A/B switch, read once
+    return H == 8 && C == 32 && O == 256 && (M == 32 || M == 64) && !off;
 }
 
 extern "C" int haet_deslice_out_fwd_split(const float* cells, const float* s, const float* Ws, const float* bs, float c0,
