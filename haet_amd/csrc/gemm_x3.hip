@@ -47,6 +47,15 @@ __device__ __forceinline__ f32x16 g_mfma3(const GFrag& a, const GFrag& b, f32x16
     return c;
 }
 
+__device__ __forceinline__ f32x4 g_mfma3s(const GFrag& a, const GFrag& b, f32x4 c) {  // the same three products on 16x16x32 tiles
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, a.hi), al = __builtin_bit_cast(bf16x8, a.lo);
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi), bl = __builtin_bit_cast(bf16x8, b.lo);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    return c;
+}
+
 // PREC = 1 ("fp16x2", opt-in: haet_conv_project_f16_fwd): the activations as fp16 hi + fp16 lo, the weight as ONE fp16
 // plane -- two v_mfma_f32_32x32x16_f16 per product instead of three bf16 ones.  What it costs: the weight's 11-bit
 // mantissa, ~2e-4 relative on a K = 256 .. 6912 contraction (measured; bf16x3: 4e-6) against north_star's 1e-3 bar and
@@ -64,6 +73,13 @@ __device__ __forceinline__ f32x16 g_mfma2h(const GFrag& a, const u32x4 b, f32x16
     const f16x8 ah = __builtin_bit_cast(f16x8, a.hi), al = __builtin_bit_cast(f16x8, a.lo), bh = __builtin_bit_cast(f16x8, b);
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+    return c;
+}
+
+__device__ __forceinline__ f32x4 g_mfma2hs(const GFrag& a, const u32x4 b, f32x4 c) {  // fp16x2 on 16x16x32 tiles
+    const f16x8 ah = __builtin_bit_cast(f16x8, a.hi), al = __builtin_bit_cast(f16x8, a.lo), bh = __builtin_bit_cast(f16x8, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
     return c;
 }
 
@@ -154,21 +170,45 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
     for (int i = 0; i < WPT; ++i)
         w_st[i] = WIMG + ((wrow0 + 128 * i) >> 5) * (2 * GIMG) + g_off(wrow0 & 31, wch);
 
-    f32x16 acc[RB][WCB];
-    float wt4[4] = {0.f, 0.f, 0.f, 0.f};  // ACT == 4: Ada-Temp weights of this lane's four channels after the quad transpose
+    // Accumulators: every 32 x 32 block (i, j) of the wave's output as four 16 x 16 tiles of v_mfma_f32_16x16x32_bf16 --
+    // acc[i][j][in][jo][r] = out[row 32 i + 16 in + 4 kg + r][column 32 j + 16 jo + lane % 16].  Same matrix-pipe cycles per
+    // flop as 32x32x16, same LDS reads (a 32-wide k-tile is ONE k-step), but the chip holds a higher clock under this shape in
+    // an MFMA-bound loop fed from LDS (MI355X_MICROARCH.md, 'DVFS give-back' item 7).
+    const int l15 = lane & 15, kg = lane >> 4;
+    f32x4 acc[RB][WCB][2][2];
+    float wt4[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // ACT == 4: Ada-Temp weights of this lane's four channels (per jo) after the quad transpose
     if (ACT == 4) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wt4[q] = cs.wt[(l31 & ~3) + q];
-    }
-    float bv[WCB];  // bias of this lane's output columns: loaded (and waited for) once, up front
+        for (int jo = 0; jo < 2; ++jo)
 #pragma unroll
-    for (int j = 0; j < WCB; ++j) bv[j] = (bias && (!kSplitK || blockIdx.z == 0)) ? bias[col0 + 32 * (WCB * wn + j) + l31] : 0.f;
+            for (int q = 0; q < 4; ++q) wt4[jo][q] = cs.wt[16 * jo + (l15 & ~3) + q];
+    }
+    f32x16 accL[RB == 4 ? RB : 1][WCB];  // (RB == 4 only, see compute32)
+    float bvL[WCB];
+#pragma unroll
+    for (int j = 0; j < WCB; ++j) bvL[j] = (bias && (!kSplitK || blockIdx.z == 0)) ? bias[col0 + 32 * (WCB * wn + j) + l31] : 0.f;
+    if (RB == 4) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int j = 0; j < WCB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accL[RB == 4 ? i : 0][j][r] = bvL[j];
+    }
+    float bv[WCB][2];  // bias of this lane's output columns: loaded (and waited for) once, up front
+#pragma unroll
+    for (int j = 0; j < WCB; ++j)
+#pragma unroll
+        for (int jo = 0; jo < 2; ++jo)
+            bv[j][jo] = (bias && (!kSplitK || blockIdx.z == 0)) ? bias[col0 + 32 * (WCB * wn + j) + 16 * jo + l15] : 0.f;
 #pragma unroll
     for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < WCB; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = bv[j];  // accumulate on top of the bias
+            for (int in = 0; in < 2; ++in)
+#pragma unroll
+                for (int jo = 0; jo < 2; ++jo) acc[i][j][in][jo] = f32x4{bv[j][jo], bv[j][jo], bv[j][jo], bv[j][jo]};  // accumulate on top of the bias
 
     // fetch streams (x three items ahead, W two items ahead), each with its own (tile, kt) cursor
     f32x4 xs0[XPT], xs1[XPT], xs2[XPT];
@@ -270,7 +310,8 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
         }
     };
     int c_tile = blockIdx.x, c_kt = 0;
-    auto compute = [&](int buf) {
+    auto compute32 = [&](int buf) __attribute__((always_inline)) {  // RB == 4 (256-row tiles): the 32x32x16 form -- eight B fragments of the 16 x 16 form do not fit beside 128 accumulators
+        if constexpr (RB == 4) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             GFrag b[WCB];
@@ -283,7 +324,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
             for (int i = 0; i < RB; ++i) {  // one A fragment at a time: RB = 4 leaves no room for four
                 const GFrag a = g_read(buf + XIMG + (RB * wm + i) * (2 * GIMG), l31, hf + 2 * ks);
 #pragma unroll
-                for (int j = 0; j < WCB; ++j) acc[i][j] = PREC == 0 ? g_mfma3(a, b[j], acc[i][j]) : g_mfma2h(a, b[j].hi, acc[i][j]);
+                for (int j = 0; j < WCB; ++j) accL[i][j] = PREC == 0 ? g_mfma3(a, b[j], accL[i][j]) : g_mfma2h(a, b[j].hi, accL[i][j]);
             }
         }
         if (++c_kt == nkt) {  // row tile finished: lane = output column, registers = rows
@@ -304,7 +345,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
                             // the lane quad turns them into ONE row (8g + 4hf + lane % 4) and four consecutive columns
                             int v[4];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) v[q] = __float_as_int(acc[i][j][4 * g + q]);
+                            for (int q = 0; q < 4; ++q) v[q] = __float_as_int(accL[i][j][4 * g + q]);
                             const bool odd = lane & 1, up = lane & 2;
 #pragma unroll
                             for (int m = 0; m < 4; m += 2) {
@@ -325,10 +366,10 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
                             split_bf16_pair(f0, f1, h01, l01);
                             split_bf16_pair(f2, f3, h23, l23);
                             const u32x4 o4 = {h01, h23, l01, l23};
-                            float t = f0 * wt4[0];
-                            t = fmaf(f1, wt4[1], t);
-                            t = fmaf(f2, wt4[2], t);
-                            t = fmaf(f3, wt4[3], t);
+                            float t = f0 * wt4[0][0];
+                            t = fmaf(f1, wt4[0][1], t);
+                            t = fmaf(f2, wt4[0][2], t);
+                            t = fmaf(f3, wt4[0][3], t);
                             t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x124, 0xF, 0xF, false));  // row_ror:4
                             t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, false));  // row_ror:8
                             t += __shfl_xor(t, 16);
@@ -343,27 +384,144 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int rr = 32 * i + (r & 3) + 8 * (r >> 2);
-                            if (row0 + 32 * RB * wm + 4 * hf + rr < Nrows) atomicAdd(oc + (size_t)rr * O, acc[i][j][r]);
+                            if (row0 + 32 * RB * wm + 4 * hf + rr < Nrows) atomicAdd(oc + (size_t)rr * O, accL[i][j][r]);
                         }
                     } else if (full) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            oc[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * O] = ACT == 1 ? g_gelu(acc[i][j][r]) : acc[i][j][r];
+                            oc[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * O] = ACT == 1 ? g_gelu(accL[i][j][r]) : accL[i][j][r];
                     } else {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int rr = 32 * i + (r & 3) + 8 * (r >> 2);
                             if (row0 + 32 * RB * wm + 4 * hf + rr < Nrows)
-                                oc[(size_t)rr * O] = ACT == 1 ? g_gelu(acc[i][j][r]) : acc[i][j][r];
+                                oc[(size_t)rr * O] = ACT == 1 ? g_gelu(accL[i][j][r]) : accL[i][j][r];
                         }
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = bv[j];
+                    for (int r = 0; r < 16; ++r) accL[i][j][r] = bvL[j];
                 }
             }
             c_kt = 0;
             c_tile += gridDim.x;
         }
+        }
+    };
+
+
+    auto compute16 = [&](int buf) __attribute__((always_inline)) {
+        {
+            // B fragments (W): column 16 jo + lane % 16 of block j, k = 8 kg .. 8 kg + 7 of the 32-wide k-tile
+            GFrag b[WCB][2];
+#pragma unroll
+            for (int j = 0; j < WCB; ++j)
+#pragma unroll
+                for (int jo = 0; jo < 2; ++jo) {
+                    const int wi = buf + WIMG + (WCB * wn + j) * (2 * GIMG);
+                    if (PREC == 0) b[j][jo] = g_read(wi, 16 * jo + l15, kg);
+                    else b[j][jo].hi = *reinterpret_cast<const u32x4*>(gsm + wi + g_off(16 * jo + l15, kg));
+                }
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int in = 0; in < 2; ++in) {  // one A fragment at a time
+                    const GFrag a = g_read(buf + XIMG + (RB * wm + i) * (2 * GIMG), 16 * in + l15, kg);
+#pragma unroll
+                    for (int j = 0; j < WCB; ++j)
+#pragma unroll
+                        for (int jo = 0; jo < 2; ++jo)
+                            acc[i][j][in][jo] = PREC == 0 ? g_mfma3s(a, b[j][jo], acc[i][j][in][jo]) : g_mfma2hs(a, b[j][jo].hi, acc[i][j][in][jo]);
+                }
+        }
+        if (++c_kt == nkt) {  // row tile finished: lane = output column (two per block), registers = four consecutive rows
+            const int row0 = c_tile * BM;
+            const bool full = row0 + BM <= Nrows;  // wave-uniform: no per-store branch (a branch per
+            // store made hipcc wait vmcnt(0) -- prefetch stream included -- before every store)
+#pragma unroll
+            for (int j = 0; j < WCB; ++j) {
+                const int cb = WCB * wn + j;
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+#pragma unroll
+                    for (int in = 0; in < 2; ++in) {
+                        const long long rbase = (long long)row0 + 32 * (RB * wm + i) + 16 * in + 4 * kg;  // first of this lane's 4 rows
+                        if (ACT == 4) {
+                            // (once per row tile, i.e. per K / 32 k-tiles: per-row branches around the stores cost nothing here)
+                            // A 4 x 4 transpose across the lane quad turns a tile's four rows of ONE column into ONE row
+                            // (rbase + lane % 4) and four consecutive columns = one 16-B cell {4 x hi, 4 x lo}; the Ada-Temp dot over
+                            // the head's 32 channels = both column halves of this lane + the other three quads of its 16-lane row.
+                            const long long rowi = rbase + (lane & 3);
+                            float t = 0.f;
+                            u32x4 o4[2];
+#pragma unroll
+                            for (int jo = 0; jo < 2; ++jo) {
+                                int v[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) v[q] = __float_as_int(acc[i][j][in][jo][q]);
+                                const bool odd = lane & 1, up = lane & 2;
+#pragma unroll
+                                for (int m = 0; m < 4; m += 2) {
+                                    const int send = odd ? v[m] : v[m + 1];
+                                    const int recv = __builtin_amdgcn_update_dpp(0, send, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+                                    v[m] = odd ? recv : v[m];
+                                    v[m + 1] = odd ? v[m + 1] : recv;
+                                }
+#pragma unroll
+                                for (int m = 0; m < 2; ++m) {
+                                    const int send = up ? v[m] : v[m + 2];
+                                    const int recv = __builtin_amdgcn_update_dpp(0, send, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+                                    v[m] = up ? recv : v[m];
+                                    v[m + 2] = up ? v[m + 2] : recv;
+                                }
+                                const float f0 = __int_as_float(v[0]), f1 = __int_as_float(v[1]), f2 = __int_as_float(v[2]), f3 = __int_as_float(v[3]);
+                                unsigned h01, l01, h23, l23;
+                                split_bf16_pair(f0, f1, h01, l01);
+                                split_bf16_pair(f2, f3, h23, l23);
+                                o4[jo] = u32x4{h01, h23, l01, l23};
+                                t = fmaf(f0, wt4[jo][0], t);
+                                t = fmaf(f1, wt4[jo][1], t);
+                                t = fmaf(f2, wt4[jo][2], t);
+                                t = fmaf(f3, wt4[jo][3], t);
+                            }
+                            t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x124, 0xF, 0xF, false));  // row_ror:4
+                            t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, false));  // row_ror:8
+                            const float tau = cs.base_temp + fminf(fmaxf(t + cs.bt, -0.4f), 0.4f);
+                            if (rowi < Nrows) {
+#pragma unroll
+                                for (int jo = 0; jo < 2; ++jo)
+                                    *reinterpret_cast<u32x4*>(out + rowi * O + col0 + 32 * cb + 16 * jo + (l15 & ~3)) = o4[jo];
+                                cs.s_out[rowi * (O / 32) + col0 / 32 + cb] = 1.4426950408889634f * __builtin_amdgcn_rcpf(tau);
+                            }
+                        } else {
+#pragma unroll
+                            for (int jo = 0; jo < 2; ++jo) {
+                                float* oc = out + rbase * O + col0 + 32 * cb + 16 * jo + l15;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float v = acc[i][j][in][jo][r];
+                                    if (kSplitK) {
+                                        if (rbase + r < Nrows) atomicAdd(oc + (size_t)r * O, v);
+                                    } else if (full) {
+                                        oc[(size_t)r * O] = ACT == 1 ? g_gelu(v) : v;
+                                    } else if (rbase + r < Nrows) {
+                                        oc[(size_t)r * O] = ACT == 1 ? g_gelu(v) : v;
+                                    }
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int jo = 0; jo < 2; ++jo) acc[i][j][in][jo] = f32x4{bv[j][jo], bv[j][jo], bv[j][jo], bv[j][jo]};
+                    }
+                }
+            }
+            c_kt = 0;
+            c_tile += gridDim.x;
+        }
+    };
+
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (RB == 4) compute32(buf);
+        else compute16(buf);
     };
 
     // prologue: x items 0,1,2 and W items 0,1 in flight; item 0 staged; then x item 3 / W item 2
