@@ -94,6 +94,8 @@ SIGNATURES = {
     "haet_conv_project_supported": (c_int, [c_int, c_int]),
     "haet_conv_project_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       _P, _P]),
+    "haet_conv_project_det_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      _P, _P]),
     "haet_conv_project_split_fwd": (c_int, [_P, _P, _P, _P, _P, c_float, c_float] + [c_int] * 9 + [_P, _P, _P]),
     "haet_conv_project_f16_fwd": (c_int, [_P, _P, _P] + [c_int] * 9 + [_P, _P]),
     "haet_conv_project_split_f16_fwd": (c_int, [_P, _P, _P, _P, c_float, c_float] + [c_int] * 9 + [_P, _P, _P]),
@@ -220,7 +222,8 @@ def _install_registration_hooks():
 _install_registration_hooks()
 
 
-_precision = [os.environ.get("HAET_PRECISION", "bf16x3")]
+_PRECISIONS = ("bf16x3", "fp16x2")
+_precision = ["bf16x3"]
 
 
 def precision() -> str:
@@ -231,9 +234,20 @@ def precision() -> str:
 
 
 def set_precision(mode: str) -> None:
-    if mode not in ("bf16x3", "fp16x2"):
+    """Range contract of "fp16x2": weights and activations inside the fp16 range (|v| <= 65504; a layer whose weight
+    exceeds it stays on bf16x3 -- ops.SplitConv.f16_ok; activations are the caller's: post-LayerNorm inputs are O(1))."""
+    if mode not in _PRECISIONS:
         raise ValueError(f"precision {mode!r}: expected 'bf16x3' or 'fp16x2'")
     _precision[0] = mode
+
+
+# the environment's initial value goes through the same validation: a typo ("fp16") raises at import instead of
+# silently running bf16x3
+if "HAET_PRECISION" in os.environ:
+    try:
+        set_precision(os.environ["HAET_PRECISION"])
+    except ValueError as e:
+        raise ValueError(f"HAET_PRECISION: {e}") from None
 
 
 def load():

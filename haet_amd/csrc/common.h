@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/haet_hip.h"
 
@@ -27,6 +28,22 @@ inline int check_launch(const char* what) {
 bool deterministic_mode();
 
 inline hipStream_t as_stream(haet_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Points per workgroup of the slice / de-slice BACKWARD passes (slice_bwd.hip, slice_bwd_mfma.hip, slice_bwd_x3.hip):
+// ~256 chunks at large N, so that the per-workgroup partial records stay small next to the stream.  ONE definition:
+// haet_slice_bwd_num_parts sizes the caller's `parts` buffer from it and all three kernel families index that buffer
+// with it.
+inline int slice_bwd_pick_chunk(int N) {
+    int c = (N + 255) / 256;
+    c = ((c + 255) / 256) * 256;
+    return c < 256 ? 256 : c;
+}
+
+// "1"-valued environment switch, read per call (the tests flip them between calls)
+inline bool env_flag(const char* name) {
+    const char* e = getenv(name);
+    return e && e[0] == '1';
+}
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is PER DEVICE: a process-wide "already set" flag skips the
 // call on a second device and the > 64 KiB launch fails there.  One bit per device ordinal, set atomically

@@ -97,6 +97,7 @@ struct Head {
     int ball[HAET_ERWIN_MAX_LEVELS], stride[HAET_ERWIN_MAX_LEVELS];
     unsigned frag_begin, total_bytes;
     unsigned v1_lo, v1_bytes;  // byte range of the v1 blob that holds the pooling / unpooling Linears (L2 warm-up)
+    unsigned stamp;            // FNV-1a over the whole Plan (this field zero): the kernel checks the blob's against its argument's
     Dir dir;
 };
 struct Plan {
@@ -581,6 +582,13 @@ __global__ __launch_bounds__(kThreads) void erwin2_kernel(const float* __restric
                                                          float* __restrict__ out, WTreeCfg tcfg, float* __restrict__ pos_out,
                                                          Head PL, int warm) {
     STAMP2(0);
+    // The directory and the op table are read from the blob's own copy of the Plan: refuse a blob that was packed for
+    // another descriptor or M (uniform exit before any barrier; the output goes out as NaN so that the caller SEES it --
+    // with foreign offsets the kernel would address LDS and weights out of bounds instead)
+    if (*reinterpret_cast<const unsigned*>(FR + offsetof(Plan, h) + offsetof(Head, stamp)) != PL.stamp) {
+        for (int i = threadIdx.x; i < PL.M * PL.c0; i += kThreads) out[(size_t)blockIdx.x * PL.M * PL.c0 + i] = __int_as_float(0x7fc00000);
+        return;
+    }
     const int dirf_all = reinterpret_cast<const int*>(FR + offsetof(Plan, h) + offsetof(Head, dir))[min((int)(threadIdx.x & 63), (int)(sizeof(Dir) / 4) - 1)];
     const int dirf = dirf_all;
     const int cloud = blockIdx.x, n_clouds = gridDim.x, d = PL.d, nl = PL.n_levels, M = PL.M, c0 = PL.c0;
@@ -923,6 +931,14 @@ static bool make_plan(const haet_erwin_desc& D, int M, Plan* out) {
     T.ops = take(kMaxOps * (int)sizeof(Op));
     T.total = p;
     if (p + 8 * 1024 > 160 * 1024) return false;  // (+ the tree builder's static tables)
+    {   // the blob carries a copy of this Plan (directory + op table, read by the kernel from the blob): stamp it, so that a
+        // blob packed for another descriptor / M -- large enough to pass the size check -- is recognised by the kernel
+        P.stamp = 0;
+        unsigned hsh = 2166136261u;
+        const unsigned char* b = reinterpret_cast<const unsigned char*>(&PP);
+        for (size_t i = 0; i < sizeof(Plan); ++i) hsh = (hsh ^ b[i]) * 16777619u;
+        P.stamp = hsh ? hsh : 1u;
+    }
     *out = PP;
     return true;
 }

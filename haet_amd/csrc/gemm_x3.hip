@@ -1081,7 +1081,8 @@ extern "C" int haet_conv_project_supported(int Cin, int O) {
 
 static int conv_project_impl(const float* x, const uint16_t* W_hi, const uint16_t* W_lo,
                              const float* bias, int B, int gH, int gW, int gD, int Cin, int O,
-                             int kH, int kW, int kD, float* out, haet_stream_t stream, const ConvSplit* split, bool f16 = false) {
+                             int kH, int kW, int kD, float* out, haet_stream_t stream, const ConvSplit* split, bool f16 = false,
+                             bool fixed_order = false) {
     if (!x || !W_hi || (!W_lo && !f16) || !out) return fail(HAET_E_ARG, "conv_project_fwd: null pointer");
     if (!haet_conv_project_supported(Cin, O))
         return fail(HAET_E_ARG, "conv_project_fwd: C_in=%d (multiple of 32) / O=%d (multiple of 128) unsupported", Cin, O);
@@ -1105,7 +1106,7 @@ static int conv_project_impl(const float* x, const uint16_t* W_hi, const uint16_
     const int ncb = Cin / GBK;
     static const bool no_split = getenv("HAET_CONV_NO_SPLITK") != nullptr;
     // (float atomics: the summation order varies from run to run -- not taken in deterministic mode)
-    if (!split && !f16 && !no_split && !deterministic_mode() && !big && tiles * ny * 4 <= 256 && ncb >= 2) {
+    if (!split && !f16 && !no_split && !fixed_order && !deterministic_mode() && !big && tiles * ny * 4 <= 256 && ncb >= 2) {
         int Z = ncb;
         while (Z > 1 && tiles * ny * Z > 512) Z /= 2;
         if (Z > 1 && ncb % Z == 0) {
@@ -1152,6 +1153,14 @@ extern "C" int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const
                                      const float* bias, int B, int gH, int gW, int gD, int Cin, int O,
                                      int kH, int kW, int kD, float* out, haet_stream_t stream) {
     return conv_project_impl(x, W_hi, W_lo, bias, B, gH, gW, gD, Cin, O, kH, kW, kD, out, stream, nullptr);
+}
+
+// The fixed-summation-order variant as a PER-CALL choice (never the split-k / float-atomics path), whatever the
+// process-wide haet_set_deterministic says: what a host passes torch.use_deterministic_algorithms(True) through.
+extern "C" int haet_conv_project_det_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo,
+                                         const float* bias, int B, int gH, int gW, int gD, int Cin, int O,
+                                         int kH, int kW, int kD, float* out, haet_stream_t stream) {
+    return conv_project_impl(x, W_hi, W_lo, bias, B, gH, gW, gD, Cin, O, kH, kW, kD, out, stream, nullptr, false, true);
 }
 
 // fp16x2 arithmetic (opt-in; see PREC above): W_f16 = the weight of haet_conv_project_fwd's layout as ONE fp16 plane

@@ -46,12 +46,6 @@ __device__ __forceinline__ void point_eval(float xv, int s, const float (&w)[NG]
     }
 }
 
-int pick_chunk(int N) {  // ~256 chunks at large N: the per-workgroup partial records stay small next to the stream
-    int c = (N + 255) / 256;
-    c = ((c + 255) / 256) * 256;
-    return c < 256 ? 256 : c;
-}
-
 }  // namespace
 
 // ----------------------------------------------------------------------------- pass 1
@@ -326,8 +320,13 @@ int slice_bwd_x3(int mode, const float*, const float*, const float*, const float
                  int, int, float*, float*, hipStream_t);
 
 static bool use_bwd_mfma(int C, int M) {  // HAET_FORCE_VALU=1 routes every shape through the generic kernels (tests)
-    const char* e = getenv("HAET_FORCE_VALU");
-    return !(e && e[0] == '1') && slice_bwd_mfma_ok(C, M);
+    return !env_flag("HAET_FORCE_VALU") && slice_bwd_mfma_ok(C, M);
+}
+// the split-bf16 passes (C = 32, M in {32, 64}) unless the caller asked for exact-f32 products: HAET_FORCE_F32_MFMA=1 is the
+// library-wide "no split-bf16 envelope" switch of include/haet_hip.h (forward AND backward), HAET_BWD_F32=1 the
+// backward-only one
+static bool use_bwd_x3(int C, int M) {
+    return use_bwd_mfma(C, M) && !env_flag("HAET_FORCE_F32_MFMA") && !env_flag("HAET_BWD_F32") && slice_bwd_x3_ok(C, M);
 }
 
 template <int C, int NG>
@@ -379,7 +378,7 @@ using namespace haet;
 
 extern "C" int haet_slice_bwd_num_parts(int B, int N, int H, int C, int M) {
     if (slice_shape_ok(B, N, H, C, M) != HAET_OK) return HAET_E_ARG;
-    const int chunk = pick_chunk(N);
+    const int chunk = slice_bwd_pick_chunk(N);
     return (N + chunk - 1) / chunk;
 }
 
@@ -393,13 +392,13 @@ extern "C" int haet_deslice_bwd_tokens(const float* x_lin, const float* Ws, cons
         return fail(HAET_E_ARG, "deslice_bwd_tokens: null pointer");
     int rc = slice_shape_ok(B, N, H, C, M);
     if (rc != HAET_OK) return rc;
-    if (use_bwd_mfma(C, M) && slice_bwd_x3_ok(C, M))
+    if (use_bwd_x3(C, M))
         return slice_bwd_x3(0, x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, g_out, nullptr, nullptr, nullptr,
                             B, N, H, C, M, nullptr, parts, as_stream(stream));
     if (use_bwd_mfma(C, M))
         return slice_bwd_mfma(0, x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, g_out, nullptr, nullptr,
                               nullptr, B, N, H, C, M, nullptr, parts, as_stream(stream));
-    const int chunk = pick_chunk(N);
+    const int chunk = slice_bwd_pick_chunk(N);
     dim3 grid((N + chunk - 1) / chunk, B * H);
     HAET_BWD_DISPATCH(launch_tokens, grid, as_stream(stream), x_lin, Ws, bs, wt, bt, base_temp, c0, col_max,
                       col_sum, g_out, N, H, M, chunk, parts);
@@ -414,13 +413,13 @@ extern "C" int haet_slice_bwd_points(const float* x_lin, const float* Ws, const 
         return fail(HAET_E_ARG, "slice_bwd_points: null pointer");
     int rc = slice_shape_ok(B, N, H, C, M);
     if (rc != HAET_OK) return rc;
-    if (use_bwd_mfma(C, M) && slice_bwd_x3_ok(C, M))
+    if (use_bwd_x3(C, M))
         return slice_bwd_x3(1, x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, g_out, S2, dS, A, B, N, H, C, M,
                             dx_lin, param_parts, as_stream(stream));
     if (use_bwd_mfma(C, M))
         return slice_bwd_mfma(1, x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, g_out, S2, dS, A, B, N, H, C, M,
                               dx_lin, param_parts, as_stream(stream));
-    const int chunk = pick_chunk(N);
+    const int chunk = slice_bwd_pick_chunk(N);
     dim3 grid((N + chunk - 1) / chunk, B * H);
     HAET_BWD_DISPATCH(launch_points, grid, as_stream(stream), x_lin, Ws, bs, wt, bt, base_temp, c0, col_max,
                       col_sum, g_out, S2, dS, A, N, H, M, chunk, dx_lin, param_parts);

@@ -43,12 +43,6 @@ __device__ __forceinline__ void wave_lds_fence() {  // wave-private LDS hand-off
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-int pick_chunk(int N) {
-    int c = (N + 255) / 256;
-    c = ((c + 255) / 256) * 256;
-    return c < 256 ? 256 : c;
-}
-
 }  // namespace
 
 // MODE 0: pass 1 (dS2 partials).  MODE 1: pass 2 (dx_lin + parameter-gradient partials).
@@ -382,7 +376,7 @@ int slice_bwd_mfma(int mode, const float* x, const float* Ws, const float* bs, c
                    float base_temp, float c0, const float* cm, const float* cs, const float* go, const float* S2,
                    const float* dS, const float* A, int B, int N, int H, int C, int M, float* dx, float* parts,
                    hipStream_t st) {
-    const int chunk = pick_chunk(N);
+    const int chunk = slice_bwd_pick_chunk(N);
     dim3 grid((N + chunk - 1) / chunk, B * H);
 #define HAET_BWD_MFMA(CB, MB, NW)                                                                                     \
     return mode ? launch<CB, MB, NW, 1>(grid, st, x, Ws, bs, wt, bt, base_temp, c0, cm, cs, go, S2, dS, A, N, H, chunk, \

@@ -108,12 +108,6 @@ __device__ __forceinline__ float xb_half_sum(float v) {  // sum over the 32 lane
     return v;
 }
 
-int xb_pick_chunk(int N) {
-    int c = (N + 255) / 256;
-    c = ((c + 255) / 256) * 256;
-    return c < 256 ? 256 : c;
-}
-
 }  // namespace
 
 // MODE 0: pass 1 (dS2 partials).  MODE 1: pass 2 (dx_lin + parameter-gradient partials).  C = 32, M = 32 MB.
@@ -439,18 +433,15 @@ static int x3_launch(dim3 grid, hipStream_t st, const float* x, const float* Ws,
     return check_launch(MODE ? "slice_bwd_x3_kernel<points>" : "slice_bwd_x3_kernel<tokens>");
 }
 
-// C = 32 with M in {32, 64}; HAET_BWD_F32=1 keeps every shape on the exact-f32 matrix-core kernels (A/B, tests)
-bool slice_bwd_x3_ok(int C, int M) {
-    const char* e = getenv("HAET_BWD_F32");  // (read per call: the tests switch it)
-    return !(e && e[0] == '1') && C == 32 && (M == 32 || M == 64);
-}
+// the shapes this family covers (the precision switches are the dispatcher's business: slice_bwd.hip use_bwd_x3)
+bool slice_bwd_x3_ok(int C, int M) { return C == 32 && (M == 32 || M == 64); }
 
 // same contract (and the same record layout and chunking) as slice_bwd_mfma
 int slice_bwd_x3(int mode, const float* x, const float* Ws, const float* bs, const float* wt, float bt,
                  float base_temp, float c0, const float* cm, const float* cs, const float* go, const float* S2,
                  const float* dS, const float* A, int B, int N, int H, int C, int M, float* dx, float* parts,
                  hipStream_t st) {
-    const int chunk = xb_pick_chunk(N);
+    const int chunk = slice_bwd_pick_chunk(N);
     dim3 grid((N + chunk - 1) / chunk, B * H);
 #define HAET_BWD_X3(MB)                                                                                            \
     return mode ? x3_launch<MB, 8, 1>(grid, st, x, Ws, bs, wt, bt, base_temp, c0, cm, cs, go, S2, dS, A, N, H, chunk, \

@@ -611,7 +611,7 @@ def conv_project_split(x: Tensor, w: "SplitConv", grid: Tuple[int, ...], p: Slic
     cells = torch.empty((B, N, w.O), dtype=torch.float32, device=x.device)
     s = torch.empty((B, N, H), dtype=torch.float32, device=x.device)
     kH, kW, kD = w.kernel
-    if _lib.precision() == "fp16x2":
+    if _lib.precision() == "fp16x2" and w.f16_ok():
         check(lib.haet_conv_project_split_f16_fwd(_p(x), _p(w.f16()), _p(w.lin.bias), _p(p.wt), p.bt, p.base_temp, B, gH, gW, gD,
                                                   Cin, w.O, kH, kW, kD, _p(cells), _p(s), _stream()),
               "haet_conv_project_split_f16_fwd")
@@ -639,10 +639,23 @@ class SplitConv:
         self.lin = SplitLinear(flat, bias)
         self._f16 = None
 
+    def _f16_make(self) -> None:
+        w = self.lin.hi.view(torch.bfloat16).float() + self.lin.lo.view(torch.bfloat16).float()
+        # fp16 range guard (one reduction per weight version): beyond 65504 the single plane would hold inf, and the
+        # activations' fp16 hi + lo split inherits the same range -- such a layer stays on bf16x3
+        self._f16_in_range = bool(torch.isfinite(w).all()) and float(w.abs().max()) <= 65504.0
+        self._f16 = w.half().contiguous() if self._f16_in_range else False
+
+    def f16_ok(self) -> bool:
+        """Whether the opt-in fp16x2 arithmetic may serve this weight (all |w| inside the fp16 range)."""
+        if self._f16 is None:
+            self._f16_make()
+        return self._f16 is not False
+
     def f16(self) -> Tensor:
         """The weight as ONE fp16 plane (same layout), for the opt-in fp16x2 arithmetic; made on first use."""
-        if self._f16 is None:
-            self._f16 = (self.lin.hi.view(torch.bfloat16).float() + self.lin.lo.view(torch.bfloat16).float()).half().contiguous()
+        if not self.f16_ok():
+            raise HaetError("fp16x2: weight outside the fp16 range")
         return self._f16
 
 
@@ -661,12 +674,14 @@ def conv_project(x: Tensor, w: SplitConv, grid: Tuple[int, ...]) -> Tensor:
         raise HaetError("conv_project: x does not match the grid / weight")
     out = torch.empty((B, N, w.O), dtype=torch.float32, device=x.device)
     kH, kW, kD = w.kernel
-    # small grids otherwise split the k-tiles over workgroups that add with float atomics (run-to-run order)
-    lib.haet_set_deterministic(1 if (torch.are_deterministic_algorithms_enabled() or os.environ.get("HAET_DETERMINISTIC") == "1") else 0)
-    if _lib.precision() == "fp16x2":
+    if _lib.precision() == "fp16x2" and w.f16_ok():
         check(lib.haet_conv_project_f16_fwd(_p(x), _p(w.f16()), _p(w.lin.bias), B, gH, gW, gD, Cin, w.O, kH, kW, kD, _p(out),
                                             _stream()), "haet_conv_project_f16_fwd")
         return out
-    check(lib.haet_conv_project_fwd(_p(x), _p(w.lin.hi), _p(w.lin.lo), _p(w.lin.bias), B, gH, gW, gD, Cin, w.O,
-                                    kH, kW, kD, _p(out), _stream()), "haet_conv_project_fwd")
+    # small grids otherwise split the k-tiles over workgroups that add with float atomics (run-to-run order): under
+    # torch.use_deterministic_algorithms(True) the fixed-order entry point is called -- a per-call choice; the library's
+    # process-wide flag (haet_set_deterministic / HAET_DETERMINISTIC, read by the library itself) is never written here
+    fn = "haet_conv_project_det_fwd" if torch.are_deterministic_algorithms_enabled() else "haet_conv_project_fwd"
+    check(getattr(lib, fn)(_p(x), _p(w.lin.hi), _p(w.lin.lo), _p(w.lin.bias), B, gH, gW, gD, Cin, w.O,
+                           kH, kW, kD, _p(out), _stream()), fn)
     return out

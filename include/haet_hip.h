@@ -50,8 +50,9 @@ const char* haet_last_error_string(void);
 /* Deterministic mode (process-wide; default: environment HAET_DETERMINISTIC=1, else off): entry points that have a
  * faster variant whose floating-point summation ORDER varies from run to run take the fixed-order variant instead.
  * Today that is the split-k convolution projection of small grids (haet_conv_project_fwd: k-tiles over several
- * workgroups added with float atomics; deterministic mode runs one workgroup per output tile).  The Python host
- * sets it from torch.are_deterministic_algorithms_enabled() before every convolution launch.  Every other FORWARD
+ * workgroups added with float atomics; deterministic mode runs one workgroup per output tile).  The Python host does
+ * NOT write this process-wide flag: under torch.use_deterministic_algorithms(True) it calls the per-call entry point
+ * haet_conv_project_det_fwd, so an explicit setting made by a C caller or another thread is never overridden.  Every other FORWARD
  * entry point sums in a fixed order always; the backward of the stand-alone point-cloud MPNN
  * (haet_pc_mpnn_message_bwd) adds sender gradients with float atomics and has no fixed-order variant. */
 void haet_set_deterministic(int on);
@@ -86,7 +87,8 @@ int haet_linear_fwd(const float* x /*[Nrows,K]*/, const uint16_t* W_hi, const ui
  * the fp32 reference 6e-6 at the trained-weight scale (|z| up to ~15), <= 1e-3 -- the bar of this path -- for
  * |z| <~ 60, 4e-3 at |z| ~ 300 (tests/test_gpu_parity.py::test_c3_module_small_and_scaled_clouds).
  * Inputs beyond that are served by the exact-f32 families, which every shape can be routed to: HAET_FORCE_F32_MFMA=1
- * (v_mfma_f32_32x32x2_f32, exact f32 products) or HAET_FORCE_VALU=1 (generic fp32 kernels), read when the library loads.
+ * (v_mfma_f32_32x32x2_f32, exact f32 products) or HAET_FORCE_VALU=1 (generic fp32 kernels); both are read PER CALL and
+ * apply to the forward passes AND to the backward passes below (haet_deslice_bwd_tokens / haet_slice_bwd_points).
  *
  * The pass produces `P = haet_slice_num_parts(...)` partial records, one per
  * point chunk.  A record holds, for every (b,h,g):  m = max_n z, l = sum_n
@@ -373,7 +375,15 @@ int haet_deslice_fwd_split(const void* x_split, const float* s, const float* Ws,
  *   dx_lin [B,N,H*C] (complete gradient w.r.t. x_lin: de-slice + slice + Ada-Temp terms) and
  *   param_parts [P][B*H][M*C + M + C + 1] = per-workgroup partials of
  *   (d in_project_slice.weight [M,C], d in_project_slice.bias [M], d ada_temp_linear.weight [C],
- *   d ada_temp_linear.bias), to be summed over P and B*H by the caller.                            */
+ *   d ada_temp_linear.bias), to be summed over P and B*H by the caller.
+ * ARITHMETIC / ACCURACY (declared).  At C = 32 with M in {32, 64} (the C3 shape) both passes run on split-bf16 products
+ * (slice_bwd_x3.hip: 3 bf16 MFMAs per fp32 product, fp32 accumulate), so the gradients carry the forward's logit envelope
+ * (|z| * 2^-16 inside the exponential).  Measured against fp64 autograd on the kernel-level shapes of
+ * tests/test_gpu_backward.py (unit-scale inputs, |z| <~ 10; the tests print and bound these): dS2 <= 3e-4, dx_lin / dW_s /
+ * db_s <= 1.5e-3, dw_t / db_t <= 7.5e-3 relative L2 (the last two are sums of clamp-masked terms with heavy cancellation).
+ * The exact-f32 matrix-core kernels (slice_bwd_mfma.hip: v_mfma_f32_32x32x2_f32; what M = 128 and C = 64 always run)
+ * hold 5e-5 / 5e-4 / 2.5e-3 on the same shapes and are selected for every shape by HAET_BWD_F32=1 (backward only) or
+ * HAET_FORCE_F32_MFMA=1 (forward and backward), the generic fp32 vector kernels by HAET_FORCE_VALU=1; all read per call. */
 int haet_slice_bwd_num_parts(int B, int N, int H, int C, int M);
 size_t haet_slice_bwd_param_floats(int C, int M);
 int haet_deslice_bwd_tokens(const float* x_lin, const float* Ws, const float* bs, const float* wt,
@@ -461,6 +471,11 @@ int haet_conv_project_supported(int Cin, int O);
 int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
                           int B, int gH, int gW, int gD, int Cin, int O, int kH, int kW, int kD,
                           float* out, haet_stream_t stream);
+/* Same contract, fixed summation order as a PER-CALL choice: never the split-k / float-atomics variant, independent of
+ * (and without touching) the process-wide haet_set_deterministic.  Two calls on the same operands are bit-identical. */
+int haet_conv_project_det_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
+                              int B, int gH, int gW, int gD, int Cin, int O, int kH, int kW, int kD,
+                              float* out, haet_stream_t stream);
 /* The same convolution with Ada-Temp in its epilogue and the output in the fused operand format of the streaming
  * passes (what haet_project_split_fwd writes for the Linear projection; StructuredMesh2D.py:173-181,
  * StructuredMesh3D.py:177-185): cells [B*N][O] 4-byte slots -- per 4 channels {4 x bf16 hi, 4 x bf16 lo} -- and
@@ -473,7 +488,10 @@ int haet_conv_project_split_fwd(const float* x, const uint16_t* W_hi, const uint
  * GPU path is fp16 autocast, velocity-mem-checker.py:49): activations as fp16 hi + fp16 lo (split in the loader), the
  * weight as ONE fp16 plane W_f16 (same [O][C_in/32][taps][32] layout) -- 2 matrix-core products per term instead of 3.
  * Measured ~2e-4 relative against fp64 (split-bf16: 4e-6); north_star's bar is 1e-3.  The default everywhere stays
- * split-bf16; the Python host takes these entry points under haet_amd.set_precision("fp16x2") / HAET_PRECISION=fp16x2. */
+ * split-bf16; the Python host takes these entry points under haet_amd.set_precision("fp16x2") / HAET_PRECISION=fp16x2.
+ * RANGE CONTRACT: every weight and activation must lie inside the fp16 range, |v| <= 65504 (beyond it hi = inf and
+ * lo = v - inf: the output is NaN; below ~6e-5 fp16 is subnormal and the operand loses bits).  The Python host checks
+ * the weight once per version and keeps a layer whose weight is out of range on bf16x3; activations are the caller's. */
 int haet_conv_project_f16_fwd(const float* x, const uint16_t* W_f16, const float* bias, int B, int gH, int gW, int gD,
                               int Cin, int O, int kH, int kW, int kD, float* out, haet_stream_t stream);
 int haet_conv_project_split_f16_fwd(const float* x, const uint16_t* W_f16, const float* bias, const float* wt, float bt,

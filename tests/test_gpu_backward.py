@@ -16,6 +16,20 @@ pytestmark = pytest.mark.gpu
 K_NORM = 1.0 / (1.0 + 1e-5)
 
 
+def _record_errors(rec):
+    """Append the measured errors of one case (best effort: the file is a by-product, never a condition)."""
+    import json
+    import os
+
+    try:
+        root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(root, exist_ok=True)
+        with open(os.path.join(root, "bwd_errors.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+
+
 def _passes_fp64(x, Ws, bs, wt, bt, base, c0, S2):
     """x [B,N,H,C] -> (w [B,H,N,M], S [B,H,M,C], out [B,N,H,C]); fp64."""
     xp = x.permute(0, 2, 1, 3)
@@ -31,14 +45,16 @@ def _passes_fp64(x, Ws, bs, wt, bt, base, c0, S2):
 @pytest.mark.parametrize("B,N,H,C,M", [(1, 700, 4, 16, 16), (2, 333, 8, 32, 64), (1, 1, 2, 32, 32), (1, 5000, 8, 32, 64),
                                        (1, 1025, 4, 64, 32), (1, 257, 2, 32, 128), (2, 64, 3, 8, 8), (1, 300, 2, 64, 100),
                                        (1, 4097, 2, 16, 48), (2, 700, 2, 64, 64), (1, 33, 4, 64, 32)])
-@pytest.mark.parametrize("path", ["auto", "valu", "f32"])
+@pytest.mark.parametrize("path", ["auto", "valu", "f32", "f32_global"])
 def test_backward_passes_vs_fp64_autograd(B, N, H, C, M, path, hip_device, monkeypatch):
     from haet_amd import ops
 
-    if path == "f32":  # the exact-f32 matrix-core kernels where auto takes the split-bf16 ones (C = 32, M in {32, 64})
+    if path in ("f32", "f32_global"):  # the exact-f32 matrix-core kernels where auto takes the split-bf16 ones (C = 32, M in {32, 64})
         if not (C == 32 and M in (32, 64)):
             pytest.skip("auto already runs the f32 / generic kernels for this shape")
-        monkeypatch.setenv("HAET_BWD_F32", "1")
+        # HAET_BWD_F32: the backward-only switch; HAET_FORCE_F32_MFMA: the library-wide "no split-bf16 envelope" switch of
+        # include/haet_hip.h, which must move the backward off the split-bf16 passes too (the exact-f32 bounds below prove it)
+        monkeypatch.setenv("HAET_BWD_F32" if path == "f32" else "HAET_FORCE_F32_MFMA", "1")
     if path == "valu":  # the generic fp32 vector-ALU kernels for every shape (auto: MFMA kernels where they apply)
         if not ((C == 32 and M in (32, 64, 128)) or (C == 64 and M in (32, 64))):
             pytest.skip("auto already runs the generic kernels for this shape")
@@ -81,21 +97,32 @@ def test_backward_passes_vs_fp64_autograd(B, N, H, C, M, path, hip_device, monke
     # envelope -- an absolute error of ~sum|Ws x| 2^-17 inside the exponential, here |z| up to ~20 -- where the exact-f32
     # matrix-core kernels (path "f32") and the generic ones have fp32 rounding only
     x3 = path == "auto" and C == 32 and M in (32, 64)
-    assert O.rel_l2(dS2.cpu().double(), gS2.reshape(-1, C)) < (3e-4 if x3 else 5e-5)
+    # The bounds are the ones include/haet_hip.h DECLARES for the two arithmetic families (section "backward of the two
+    # passes"); the errors actually measured are recorded per case (gpurun_out/bwd_errors.jsonl -> profiles/) so that a
+    # bound is never just widened to fit
+    tol_s2, tol = (3e-4, 1.5e-3) if x3 else (5e-5, 5e-4)  # (fp32 accumulation over N points with cancellation in (a - A))
+    err = {"case": [B, N, H, C, M], "path": path, "family": "bf16x3" if x3 else "f32", "max_abs_logit": float(z.abs().max())}
+    err["dS2"] = O.rel_l2(dS2.cpu().double(), gS2.reshape(-1, C))
     A = (dS2 * S2d).sum(-1) + (S_hip * dSd).sum(-1)
     dx, dWs, dbs, dwt, dbt = ops.slice_bwd_points(x_lin, sp, cm, cs, go, S2d, dSd, A, H, C, M)
-    tol = 1.5e-3 if x3 else 5e-4  # fp32 accumulation over N points with cancellation in (a - A)
-    assert O.rel_l2(dx.cpu().double().reshape(B, N, H, C), gx) < tol
+    err["dx"] = O.rel_l2(dx.cpu().double().reshape(B, N, H, C), gx)
+    if N > 1:
+        err["dWs"] = O.rel_l2(dWs.cpu().double(), gWs)
+        # sum_n dlogit cancels almost completely (exactly, for a constant tau): measured on the scale of its terms,
+        # which is the scale of dWs = sum_n dlogit x_n with unit-variance x
+        err["dbs"] = float((dbs.cpu().double() - gbs).norm()) / max(float(gbs.norm()), float(gWs.norm()) / C ** 0.5)
+        if 0.0 < float(inside):
+            err["dwt"] = O.rel_l2(dwt.cpu().double(), gwt)
+            err["dbt"] = abs(float(dbt) - float(gbt)) / max(1.0, abs(float(gbt)), float(gwt.norm()))
+    _record_errors(err)
+    assert err["dS2"] < tol_s2, err
+    assert err["dx"] < tol, err
     if N == 1:  # softmax over one point: w = 1, dz = 0 -- every parameter gradient is rounding noise around zero
         assert float(dWs.abs().max()) < 2e-2 and float(dbs.abs().max()) < 2e-2 and float(dwt.abs().max()) < 2e-2
         return
-    assert O.rel_l2(dWs.cpu().double(), gWs) < tol
-    # sum_n dlogit cancels almost completely (exactly, for a constant tau): measured on the scale of its terms,
-    # which is the scale of dWs = sum_n dlogit x_n with unit-variance x
-    assert float((dbs.cpu().double() - gbs).norm()) / max(float(gbs.norm()), float(gWs.norm()) / C ** 0.5) < tol
-    if 0.0 < float(inside):
-        assert O.rel_l2(dwt.cpu().double(), gwt) < 5 * tol
-        assert abs(float(dbt) - float(gbt)) < 5 * tol * max(1.0, abs(float(gbt)), float(gwt.norm()))
+    assert err["dWs"] < tol and err["dbs"] < tol, err
+    if "dwt" in err:
+        assert err["dwt"] < 5 * tol and err["dbt"] < 5 * tol, err
 
 
 @pytest.mark.parametrize("kind", ["irregular_c3", "structured2d", "structured3d", "structured2d_wide", "structured3d_wide",
