@@ -33,11 +33,14 @@ class Physics_Attention_Structured_Mesh_3D(PhysicsAttentionBase):
         return (self.H, self.W, self.D)
 
     def project_split(self, x, sp, pre_norm=None):
-        # (a LayerNorm in front cannot ride in the convolution's loader -- the taps read NEIGHBOUR rows -- so
-        # fuses_pre_norm stays False and the caller applies it first)
-        if pre_norm is not None or x.dtype != __import__("torch").float32:
+        # A LayerNorm in front cannot ride in the convolution's own loader (the taps read NEIGHBOUR rows); it rides in the
+        # pre-split pass of the LDS-DMA convolution instead (ops.conv_presplit), where that kernel applies: fuses_pre_norm
+        if x.dtype != __import__("torch").float32 or (pre_norm is not None and not self.fuses_pre_norm(x, pre_norm)):
             return None
-        return self._conv_project_split(x, (self.H, self.W, self.D), sp)
+        return self._conv_project_split(x, (self.H, self.W, self.D), sp, pre_norm)
+
+    def fuses_pre_norm(self, x, ln):
+        return self._conv_fuses_pre_norm(x, ln)
 
     def project(self, x):
         B, N, Dm = x.shape

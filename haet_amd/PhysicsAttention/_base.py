@@ -18,6 +18,7 @@ merge is replicated.
 """
 from __future__ import annotations
 
+import math
 import os
 from typing import Optional
 
@@ -124,7 +125,24 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
         """Whether `project_split(x, sp, pre_norm=ln)` can take the block's LayerNorm into its loader."""
         return False
 
-    def _conv_project_split(self, x: torch.Tensor, grid, sp):
+    def _conv_fuses_pre_norm(self, x: torch.Tensor, ln) -> bool:
+        """The block's LayerNorm inside the pre-split pass of the LDS-DMA convolution (haet_conv_presplit): C_in = 256, the
+        shapes that kernel serves, the split operand format downstream."""
+        conv = self.in_project_x
+        B, N, _ = x.shape
+        return (ln.elementwise_affine and ln.bias is not None and tuple(ln.normalized_shape) == (conv.in_channels,)
+                and conv.in_channels == 256 and x.dtype == torch.float32 and not os.environ.get("HAET_NO_HIP_CONV")
+                and not os.environ.get("HAET_NO_SPLIT_FORMAT") and self.dim_head == 32 and self._conv_is_plain(conv)
+                and ops.conv_cells_applies(conv.in_channels, conv.out_channels, B * N, math.prod(conv.kernel_size))
+                and ops.slice_split_supported(B, N, self.heads, self.dim_head, self.slice_num))
+
+    @staticmethod
+    def _conv_is_plain(conv) -> bool:
+        return not (conv.bias is None or any(s != 1 for s in conv.stride) or any(d != 1 for d in conv.dilation)
+                    or conv.groups != 1 or any(k % 2 == 0 or p != k // 2 for k, p in zip(conv.kernel_size, conv.padding))
+                    or conv.padding_mode != "zeros")
+
+    def _conv_project_split(self, x: torch.Tensor, grid, sp, pre_norm=None):
         """The Conv2d / Conv3d projection with Ada-Temp in its epilogue and the output in the fused operand format
         (ops.SplitPoints), or None where that path does not apply (dim_head != 32, channel counts outside the HIP
         convolution, a shape the split-format passes do not take)."""
@@ -132,18 +150,15 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
         if (os.environ.get("HAET_NO_SPLIT_FORMAT") or self.dim_head != 32
                 or not ops.slice_split_supported(B, N, self.heads, self.dim_head, self.slice_num)):
             return None
-        return self._conv_project(x, grid, split=sp)
+        return self._conv_project(x, grid, split=sp, pre_norm=pre_norm)
 
-    def _conv_project(self, x: torch.Tensor, grid, split=None):
+    def _conv_project(self, x: torch.Tensor, grid, split=None, pre_norm=None):
         """Conv2d / Conv3d in_project_x as the HIP implicit GEMM over the channels-last points, or None
         when the channel counts are outside its envelope (the caller then runs the MIOpen conv).  `split`: the
         slice parameters -> the result is an ops.SplitPoints (cells + s) instead of fp32 rows."""
         conv = self.in_project_x
         ok = not (os.environ.get("HAET_NO_HIP_CONV") or x.dtype != torch.float32)
-        if ok and (not ops.conv_project_supported(conv.in_channels, conv.out_channels) or conv.bias is None
-                or any(s != 1 for s in conv.stride) or any(d != 1 for d in conv.dilation) or conv.groups != 1
-                or any(k % 2 == 0 or p != k // 2 for k, p in zip(conv.kernel_size, conv.padding))
-                or conv.padding_mode != "zeros"):
+        if ok and (not ops.conv_project_supported(conv.in_channels, conv.out_channels) or not self._conv_is_plain(conv)):
             ok = False
         if not ok:
             if self.shard_group is not None:
@@ -155,8 +170,9 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
         if "in_project_x" not in cache or cache["in_project_x"][0] != key:
             cache["in_project_x"] = (key, ops.SplitConv(conv.weight, conv.bias))
         w = cache["in_project_x"][1]
-        run = ((lambda xx, gg: ops.conv_project(xx, w, gg)) if split is None
-               else (lambda xx, gg: ops.conv_project_split(xx, w, gg, split, self.heads, self.dim_head)))
+        ln = None if pre_norm is None else (pre_norm.weight, pre_norm.bias, pre_norm.eps)  # (only where _conv_fuses_pre_norm)
+        run = ((lambda xx, gg: ops.conv_project(xx, w, gg, ln)) if split is None
+               else (lambda xx, gg: ops.conv_project_split(xx, w, gg, split, self.heads, self.dim_head, ln)))
         if self.shard_group is None:
             return run(x, grid)
         # Slab sharding along the first grid axis: this rank holds whole planes; the convolution needs

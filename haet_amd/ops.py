@@ -598,7 +598,7 @@ def deslice_out_split(xs: SplitPoints, p: SliceParams, col_max: Tensor, col_sum:
     return out
 
 
-def conv_project_split(x: Tensor, w: "SplitConv", grid: Tuple[int, ...], p: SliceParams, H: int, C: int) -> SplitPoints:
+def conv_project_split(x: Tensor, w: "SplitConv", grid: Tuple[int, ...], p: SliceParams, H: int, C: int, ln=None) -> SplitPoints:
     """The convolution projection straight into the streaming passes' operand format + s = log2(e)/tau
     (haet_conv_project_split_fwd; dim_head C = 32)."""
     lib = _lib.load()
@@ -608,6 +608,8 @@ def conv_project_split(x: Tensor, w: "SplitConv", grid: Tuple[int, ...], p: Slic
     gD = grid[2] if len(grid) > 2 else 1
     if gH * gW * gD != N or Cin != w.Cin or w.O != H * C or C != 32:
         raise HaetError("conv_project_split: x does not match the grid / weight (dim_head must be 32)")
+    if ln is not None or conv_cells_applies(Cin, w.O, B * N, w.taps):
+        return conv_project_cells_split(x, w, grid, p, H, C, ln)
     cells = torch.empty((B, N, w.O), dtype=torch.float32, device=x.device)
     s = torch.empty((B, N, H), dtype=torch.float32, device=x.device)
     kH, kW, kD = w.kernel
@@ -637,6 +639,7 @@ class SplitConv:
         # [O, C_in, taps] -> [O, C_in/32, 32, taps] -> [O, C_in/32, taps, 32]: channel block, tap, channel
         flat = (w.reshape(self.O, self.Cin // 32, 32, taps).permute(0, 1, 3, 2).reshape(self.O, -1).contiguous())
         self.lin = SplitLinear(flat, bias)
+        self.taps = taps
         self._f16 = None
 
     def _f16_make(self) -> None:
@@ -659,12 +662,76 @@ class SplitConv:
         return self._f16
 
 
+# --------------------------------------------------------------------------- LDS-DMA convolution (csrc/conv8.hip)
+CONV_CELLS_MIN_ROWS = 32768  # below this the grid is a latency case: the split-k path of the streaming kernel serves it
+
+
+def conv_cells_applies(Cin: int, O: int, rows: int, taps: int = 27) -> bool:
+    """Whether the LDS-DMA implicit GEMM (haet_conv_project_cells_fwd: x pre-split into k-tile cells once per forward)
+    serves this convolution: O = 256, C_in % 32 = 0, at most 32 kernel taps, a grid large enough to fill the chip, default
+    bf16x3 arithmetic."""
+    if os.environ.get("HAET_CONV_V1") or _lib.precision() != "bf16x3" or rows < CONV_CELLS_MIN_ROWS or taps > 32:
+        return False
+    return bool(_lib.load().haet_conv_cells_supported(int(Cin), int(O)))
+
+
+def conv_presplit(x: Tensor, ln=None) -> Tensor:
+    """x [B, N, C_in] fp32 -> the convolution's operand cells [(B*N + 1), C_in] (4-byte slots: per row and 32-channel block
+    {32 x bf16 hi | 32 x bf16 lo}; the extra last row is zeros = the padding every out-of-grid tap reads).
+    `ln` = (weight, bias, eps): nn.LayerNorm(C_in) applied to every row first (C_in = 256)."""
+    lib = _lib.load()
+    x = _f32(x, "x")
+    B, N, Cin = x.shape
+    cells = torch.empty((B * N + 1, Cin), dtype=torch.float32, device=x.device)
+    g = b = None
+    eps = 0.0
+    if ln is not None:
+        g, b, eps = _f32(ln[0].detach(), "ln.weight"), _f32(ln[1].detach(), "ln.bias"), float(ln[2])
+    check(lib.haet_conv_presplit(_p(x), B * N, Cin, _p(cells), _p(g), _p(b), eps, _stream()), "haet_conv_presplit")
+    return cells
+
+
+def _grid3(grid, N):
+    gH, gW = grid[0], grid[1]
+    gD = grid[2] if len(grid) > 2 else 1
+    if gH * gW * gD != N:
+        raise HaetError("convolution: x does not match the grid")
+    return gH, gW, gD
+
+
+def conv_project_cells(x: Tensor, w: "SplitConv", grid: Tuple[int, ...], ln=None) -> Tensor:
+    lib = _lib.load()
+    B, N, Cin = x.shape
+    gH, gW, gD = _grid3(grid, N)
+    cells = conv_presplit(x, ln)
+    out = torch.empty((B, N, w.O), dtype=torch.float32, device=x.device)
+    kH, kW, kD = w.kernel
+    check(lib.haet_conv_project_cells_fwd(_p(cells), _p(w.lin.hi), _p(w.lin.lo), _p(w.lin.bias), B, gH, gW, gD, Cin, w.O,
+                                          kH, kW, kD, _p(out), _stream()), "haet_conv_project_cells_fwd")
+    return out
+
+
+def conv_project_cells_split(x: Tensor, w: "SplitConv", grid: Tuple[int, ...], p: SliceParams, H: int, C: int, ln=None) -> SplitPoints:
+    lib = _lib.load()
+    B, N, Cin = x.shape
+    gH, gW, gD = _grid3(grid, N)
+    xc = conv_presplit(x, ln)
+    cells = torch.empty((B, N, w.O), dtype=torch.float32, device=x.device)
+    s = torch.empty((B, N, H), dtype=torch.float32, device=x.device)
+    kH, kW, kD = w.kernel
+    check(lib.haet_conv_project_cells_split_fwd(_p(xc), _p(w.lin.hi), _p(w.lin.lo), _p(w.lin.bias), _p(p.wt), p.bt, p.base_temp,
+                                                B, gH, gW, gD, Cin, w.O, kH, kW, kD, _p(cells), _p(s), _stream()),
+          "haet_conv_project_cells_split_fwd")
+    return SplitPoints(cells, s, H, C)
+
+
 def conv_project_supported(Cin: int, O: int) -> bool:
     return bool(_lib.load().haet_conv_project_supported(int(Cin), int(O)))
 
 
-def conv_project(x: Tensor, w: SplitConv, grid: Tuple[int, ...]) -> Tensor:
-    """x [B, N, C_in] channels-last over grid (H, W[, D]) -> [B, N, O]; same-padded convolution."""
+def conv_project(x: Tensor, w: SplitConv, grid: Tuple[int, ...], ln=None) -> Tensor:
+    """x [B, N, C_in] channels-last over grid (H, W[, D]) -> [B, N, O]; same-padded convolution.
+    `ln` = (weight, bias, eps): a LayerNorm over C_in applied first (only where conv_cells_applies: the pre-split pass)."""
     lib = _lib.load()
     x = _f32(x, "x")
     B, N, Cin = x.shape
@@ -672,6 +739,8 @@ def conv_project(x: Tensor, w: SplitConv, grid: Tuple[int, ...]) -> Tensor:
     gD = grid[2] if len(grid) > 2 else 1
     if gH * gW * gD != N or Cin != w.Cin:
         raise HaetError("conv_project: x does not match the grid / weight")
+    if ln is not None or conv_cells_applies(Cin, w.O, B * N, w.taps):
+        return conv_project_cells(x, w, grid, ln)
     out = torch.empty((B, N, w.O), dtype=torch.float32, device=x.device)
     kH, kW, kD = w.kernel
     if _lib.precision() == "fp16x2" and w.f16_ok():

@@ -476,6 +476,27 @@ int haet_conv_project_fwd(const float* x, const uint16_t* W_hi, const uint16_t* 
 int haet_conv_project_det_fwd(const float* x, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
                               int B, int gH, int gW, int gD, int Cin, int O, int kH, int kW, int kD,
                               float* out, haet_stream_t stream);
+/* ---- Round 4: the wide convolution (O = 256) around LDS-DMA (csrc/conv8.hip).  Same arithmetic (split-bf16 x 3, fp32
+ * accumulate), same weight planes; the ACTIVATIONS arrive pre-split, once per forward instead of once per tap:
+ *   x_cells [(rows + 1)][C_in] 4-byte slots: per row and 32-channel block 128 B = {32 x bf16 hi | 32 x bf16 lo}
+ *   (hi = RNE(x), lo = RNE(x - hi)); row `rows` is all zeros -- the padding every out-of-grid tap reads.
+ * haet_conv_presplit writes that buffer (haet_conv_cells_bytes(rows, C_in) bytes, caller-owned) from fp32 rows and can
+ * apply nn.LayerNorm(C_in) to each row on the way (ln_g / ln_b non-NULL; C_in = 256): ln_1 in front of the projection
+ * (models/HAETransolver_Structured_Mesh_3D.py block; StructuredMesh3D.py:177-193) never exists in HBM.
+ * haet_conv_project_cells_fwd / _split_fwd: the contracts of haet_conv_project_fwd / haet_conv_project_split_fwd on that
+ * operand.  Workgroup tile 256 rows x 256 columns, both operands HBM/L2 -> LDS by global_load_lds_dwordx4, two 64-KB
+ * stages, one barrier per 32-channel k-tile, fixed summation order.  Supported: haet_conv_cells_supported (C_in % 32
+ * = 0, O = 256), odd kernels, rows < 2^31 - 256.                                                                  */
+int haet_conv_cells_supported(int Cin, int O);
+size_t haet_conv_cells_bytes(long long rows, int Cin);
+int haet_conv_presplit(const float* x /*[rows, C_in]*/, long long rows, int Cin, void* x_cells,
+                       const float* ln_g /*[C_in] or NULL*/, const float* ln_b, float ln_eps, haet_stream_t stream);
+int haet_conv_project_cells_fwd(const void* x_cells, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
+                                int B, int gH, int gW, int gD, int Cin, int O, int kH, int kW, int kD,
+                                float* out, haet_stream_t stream);
+int haet_conv_project_cells_split_fwd(const void* x_cells, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
+                                      const float* wt, float bt, float base_temp, int B, int gH, int gW, int gD, int Cin,
+                                      int O, int kH, int kW, int kD, void* cells, float* s_out, haet_stream_t stream);
 /* The same convolution with Ada-Temp in its epilogue and the output in the fused operand format of the streaming
  * passes (what haet_project_split_fwd writes for the Linear projection; StructuredMesh2D.py:173-181,
  * StructuredMesh3D.py:177-185): cells [B*N][O] 4-byte slots -- per 4 channels {4 x bf16 hi, 4 x bf16 lo} -- and

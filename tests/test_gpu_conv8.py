@@ -1,0 +1,147 @@
+"""GPU: the LDS-DMA implicit-GEMM convolution of round 4 (csrc/conv8.hip: haet_conv_presplit,
+haet_conv_project_cells_fwd, haet_conv_project_cells_split_fwd) against the fp64 convolution
+(models/PhysicsAttention/StructuredMesh2D.py:173-189, StructuredMesh3D.py:177-193: Conv2d / Conv3d, kernel k,
+padding k // 2, channels-last points), through the C ABI.  Tolerance: the split-bf16 GEMMs' 2e-5 rel-L2 (bar of the
+path: 1e-3)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+def _conv_fp64(x, W, b, grid, k):
+    B, N, Cin = x.shape
+    nd = len(grid)
+    xg = x.double().reshape(B, *grid, Cin).permute(0, nd + 1, *range(1, nd + 1))
+    conv = torch.nn.functional.conv2d if nd == 2 else torch.nn.functional.conv3d
+    return conv(xg, W.double(), b.double(), padding=k // 2).permute(0, *range(2, nd + 2), 1).reshape(B, N, W.shape[0])
+
+
+CASES = [
+    # B, grid, Cin, k: rows not a multiple of the 256-row tile, batch boundaries inside a tile, every face / edge / corner
+    (2, (9, 7), 32, 3),
+    (1, (16, 16), 64, 3),
+    (3, (5, 6, 7), 32, 3),
+    (2, (8, 8, 8), 64, 3),
+    (1, (40, 40), 256, 3),
+    (1, (12, 11), 32, 5),        # 25 taps
+    (1, (3, 300), 96, 3),        # a tile that spans whole grid lines
+    (1, (20, 20, 20), 256, 3),   # C5's widths: 8 channel blocks x 27 taps = 216 k-tiles, 32 row tiles
+]
+
+
+@pytest.mark.parametrize("B,grid,Cin,k", CASES)
+def test_cells_convolution_vs_fp64(B, grid, Cin, k, hip_device):
+    from haet_amd import ops
+
+    torch.manual_seed(sum(grid) + Cin + k)
+    N = 1
+    for g in grid:
+        N *= g
+    O = 256
+    x = torch.randn(B, N, Cin)
+    W = torch.randn(O, Cin, *([k] * len(grid))) * 0.05
+    b = torch.randn(O)
+    ref = _conv_fp64(x, W, b, grid, k)
+    w = ops.SplitConv(W.to(hip_device), b.to(hip_device))
+    out = ops.conv_project_cells(x.to(hip_device), w, grid).cpu()
+    assert _rel(out, ref) < 2e-5
+    row_err = (out.double() - ref).norm(dim=2) / ref.norm(dim=2)
+    assert float(row_err.max()) < 1e-4
+    # against the streaming kernel of rounds 1-3 on the same operands (same arithmetic, another summation order)
+    old = ops.conv_project(x.to(hip_device), w, grid).cpu()
+    assert _rel(out, old) < 1e-5
+
+
+def test_more_than_32_taps_are_refused_and_routed_to_the_streaming_kernel(hip_device):
+    """One validity bit per tap and row: a 5 x 5 x 5 kernel (125 taps) is outside the LDS-DMA kernel -- the entry point says
+    so, the dispatcher keeps the streaming kernel."""
+    from haet_amd import ops
+    from haet_amd._lib import HaetError
+
+    W = torch.randn(256, 32, 5, 5, 5, device=hip_device) * 0.05
+    w = ops.SplitConv(W, torch.zeros(256, device=hip_device))
+    assert not ops.conv_cells_applies(32, 256, 10 ** 6, w.taps)
+    with pytest.raises(HaetError):
+        ops.conv_project_cells(torch.randn(1, 6 * 5 * 4, 32, device=hip_device), w, (6, 5, 4))
+
+
+def test_presplit_cells_layout_and_zero_row(hip_device):
+    """haet_conv_presplit: hi + lo of every cell is the fp32 value to 2^-16, hi = RNE-bf16(x) exactly, the layout is
+    [row][channel block][hi 32 | lo 32], and the row after the last is zeros."""
+    from haet_amd import ops
+
+    torch.manual_seed(3)
+    x = torch.randn(2, 333, 96)
+    cells = ops.conv_presplit(x.to(hip_device)).cpu()
+    assert cells.shape == (2 * 333 + 1, 96)
+    raw = cells.view(torch.bfloat16).reshape(2 * 333 + 1, 3, 2, 32).float()  # [row][cb][plane][32]
+    assert float(raw[-1].abs().max()) == 0.0
+    hi, lo = raw[:-1, :, 0], raw[:-1, :, 1]
+    xr = x.reshape(-1, 3, 32)
+    assert torch.equal(hi, xr.bfloat16().float())
+    assert float(((hi + lo) - xr).abs().max() / xr.abs().max()) < 2.0 ** -15
+
+
+def test_presplit_fused_layernorm(hip_device):
+    from haet_amd import ops
+
+    torch.manual_seed(4)
+    x = torch.randn(1, 1000, 256) * 3 + 0.5
+    ln = torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.uniform_(-0.2, 0.2)
+    ref = ln(x).detach()
+    cells = ops.conv_presplit(x.to(hip_device), (ln.weight.to(hip_device), ln.bias.to(hip_device), ln.eps)).cpu()
+    raw = cells.view(torch.bfloat16).reshape(1001, 8, 2, 32).float()
+    got = (raw[:-1, :, 0] + raw[:-1, :, 1]).reshape(1, 1000, 256)
+    assert _rel(got, ref) < 1e-5
+
+
+@pytest.mark.parametrize("B,grid,k", [(1, (24, 24), 3), (2, (6, 7, 8), 3)])
+def test_cells_convolution_split_format(B, grid, k, hip_device):
+    """The split-format epilogue (cells + s = log2(e) / tau, Ada-Temp per 32-channel head) against the fp32 epilogue of the
+    same kernel and the fp64 Ada-Temp (StructuredMesh3D.py:181-185)."""
+    from haet_amd import ops
+
+    torch.manual_seed(sum(grid))
+    N = 1
+    for g in grid:
+        N *= g
+    Cin, H = 64, 8
+    x = torch.randn(B, N, Cin)
+    W = torch.randn(256, Cin, *([k] * len(grid))) * 0.08
+    b = torch.randn(256) * 0.1
+    ref = _conv_fp64(x, W, b, grid, k)
+    w = ops.SplitConv(W.to(hip_device), b.to(hip_device))
+    wt = torch.randn(1, 32) * 0.3
+    sp = ops.SliceParams(torch.randn(64, 32, device=hip_device), torch.randn(64, device=hip_device), wt.to(hip_device), 0.05, 0.5, 1e-6)
+    xs = ops.conv_project_cells_split(x.to(hip_device), w, grid, sp, H, 32)
+    assert _rel(xs.to_float().cpu(), ref) < 2e-5
+    t = (ref.reshape(B, N, H, 32) * wt.double().reshape(1, 1, 1, 32)).sum(-1) + 0.05
+    tau = 0.5 + t.clamp(-0.4, 0.4)
+    s_ref = 1.4426950408889634 / tau
+    assert _rel(xs.s.cpu(), s_ref) < 3e-5  # (tau from the 2e-5-grade x_lin, v_rcp_f32)
+
+
+def test_dispatch_takes_the_cells_kernel_at_c5_widths(hip_device, monkeypatch):
+    """ops.conv_project routes the wide shapes (O = 256, >= 32768 rows) to the LDS-DMA kernel and HAET_CONV_V1=1 back to the
+    streaming one; both agree."""
+    from haet_amd import ops
+
+    torch.manual_seed(9)
+    grid = (32, 32, 32)
+    x = torch.randn(1, 32768, 64, device=hip_device)
+    W = torch.randn(256, 64, 3, 3, 3, device=hip_device) * 0.05
+    w = ops.SplitConv(W, torch.randn(256, device=hip_device))
+    assert ops.conv_cells_applies(64, 256, 32768)
+    a = ops.conv_project(x, w, grid)
+    monkeypatch.setenv("HAET_CONV_V1", "1")
+    assert not ops.conv_cells_applies(64, 256, 32768)
+    b = ops.conv_project(x, w, grid)
+    assert _rel(a.cpu(), b.cpu()) < 1e-5
