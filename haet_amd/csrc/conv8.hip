@@ -36,6 +36,7 @@ constexpr int kThreads = 512;
 constexpr int BM = 256, BN = 256;
 constexpr int kAStage = BM * 128, kWStage = BN * 128, kStage = kAStage + kWStage;  // 64 KB
 constexpr int kLds = 2 * kStage;
+constexpr int kDefaultVar = 5;
 
 struct Geom {
     int Cin, Npts, gH, gW, gD, kH, kW, kD;
@@ -119,9 +120,14 @@ __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__
 }
 
 // ACT 0: out fp32 [rows][256] (+ bias); ACT 1: cells + s (the streaming passes' operand format, gemm_ws_kernel<SPLIT>'s)
-// VAR (A/B switch HAET_C8_VAR): bit 0 = waves 4-7 issue their DMAs in the MIDDLE of the k-tile instead of right behind the
-// barrier (the two waves of a SIMD then do not stand in the DMA issue queue together while the matrix pipe idles)
-template <int ACT, int VAR>
+// Schedule parameters (A/B switch HAET_C8_VAR, tools/conv8_probe.py; the shipped choice is kDefaultVar):
+//   P0 / P1: the A-fragment step of the k-tile behind which waves 0-3 / 4-7 issue their DMAs (-1: right behind the barrier).
+//     With both halves right behind the barrier the two waves of every SIMD stand in the DMA issue queue together while the
+//     matrix pipe idles;
+//   PRIO: 1 = static s_setprio 1 for waves 4-7 (the second-dispatched half loses the arbitration otherwise:
+//     MI355X_MICROARCH.md, two waves per SIMD, item 4), 2 = for waves 0-3 instead;
+//   SPL: the four W DMAs two steps behind the four A DMAs instead of with them.
+template <int ACT, int P0, int P1, int PRIO, int SPL>
 __global__ __launch_bounds__(kThreads) void conv8_kernel(const char* __restrict__ xc, const unsigned short* __restrict__ Whi,
                                                          const unsigned short* __restrict__ Wlo, const float* __restrict__ bias,
                                                          int Nrows, int n_row_tiles, float* __restrict__ out, Geom cg, Split cs) {
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(kThreads) void conv8_kernel(const char* __restrict_
         }
     };
     tile_masks(f_tile);
-    auto fetch = [&](int stage) {
+    auto fetch_a = [&](int stage) {
         const int shift = ((f_a - (cg.kH >> 1)) * cg.gW + (f_b - (cg.kW >> 1))) * cg.gD + (f_c - (cg.kD >> 1));
         const int cb_off = f_cb * 128, r0 = f_tile * BM + rloc + shift;
 #pragma unroll
@@ -183,6 +189,8 @@ __global__ __launch_bounds__(kThreads) void conv8_kernel(const char* __restrict_
             const int sr = (tapmask[j] >> f_tap) & 1u ? r0 + 8 * j : Nrows;
             dma16(xc + (size_t)sr * rowB + cb_off + (aq0 ^ ((j & 1) << 6)), stage + a_lds0 + j * 1024);
         }
+    };
+    auto fetch_w = [&](int stage) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             dma16(((j & 1) ? w_odd : w_even) + (size_t)j * 8 * K * 2 + (size_t)f_kt * 64, stage + w_lds0 + j * 1024);
@@ -227,18 +235,30 @@ __global__ __launch_bounds__(kThreads) void conv8_kernel(const char* __restrict_
             for (int q = 0; q < 4; ++q) wt4[j][q] = cs.wt[16 * (j & 1) + (l15 & ~3) + q];
     }
 
-    fetch(0);
+    fetch_a(0);
+    fetch_w(0);
     advance();
-    if (VAR & 2) {
-        if (wr == 1) __builtin_amdgcn_s_setprio(1);  // static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-    }
+    if (PRIO && wr == (PRIO == 1 ? 1 : 0)) __builtin_amdgcn_s_setprio(1);
     int c_tile = t_lo + widx, c_kt = 0;
     for (int it = 0; it < total; ++it) {
         const int st = (it & 1) * kStage;
         // tile `it` has landed (this wave's DMAs), then: everyone's have, and everyone is done reading the other stage
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (!(VAR & 1) || wr == 0) fetch(st ^ kStage);  // (unconditional: the item past the end is a ghost into the stage nobody reads again)
+        // (the fetches are unconditional: the item past the end is a ghost into the stage nobody reads again)
+        if (P0 == P1 && P0 < 0) {
+            fetch_a(st ^ kStage);
+            if (!SPL) fetch_w(st ^ kStage);
+        } else {
+            if (P0 < 0 && wr == 0) {
+                fetch_a(st ^ kStage);
+                if (!SPL) fetch_w(st ^ kStage);
+            }
+            if (P1 < 0 && wr == 1) {
+                fetch_a(st ^ kStage);
+                if (!SPL) fetch_w(st ^ kStage);
+            }
+        }
 
         u32x4 bh[4], bl[4];
 #pragma unroll
@@ -254,7 +274,24 @@ __global__ __launch_bounds__(kThreads) void conv8_kernel(const char* __restrict_
                 nh = lds16(st + a_rd + (i + 1) * 2048);
                 nl = lds16(st + (a_rd ^ 64) + (i + 1) * 2048);
             }
-            if ((VAR & 1) && i == 3 && wr == 1) fetch(st ^ kStage);
+            if (P0 == P1) {
+                if (i == P0) {
+                    fetch_a(st ^ kStage);
+                    if (!SPL) fetch_w(st ^ kStage);
+                }
+                if (SPL && i == P0 + 2) fetch_w(st ^ kStage);
+            } else {
+                if (i == P0 && wr == 0) {
+                    fetch_a(st ^ kStage);
+                    if (!SPL) fetch_w(st ^ kStage);
+                }
+                if (SPL && i == P0 + 2 && wr == 0) fetch_w(st ^ kStage);
+                if (i == P1 && wr == 1) {
+                    fetch_a(st ^ kStage);
+                    if (!SPL) fetch_w(st ^ kStage);
+                }
+                if (SPL && i == P1 + 2 && wr == 1) fetch_w(st ^ kStage);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = mfma3(ah, al, bh[j], bl[j], acc[i][j]);
             ah = nh, al = nl;
@@ -379,7 +416,7 @@ static int conv_cells_impl(const void* xc, const uint16_t* W_hi, const uint16_t*
     int grid = ((tiles + 7) / 8) * 8;
     if (grid > cus) grid = cus;
     const c8::Geom cg{Cin, gH * gW * gD, gH, gW, gD, kH, kW, kD};
-    static PerDeviceOnce once[8];
+    static PerDeviceOnce once[16];
     auto launch = [&](auto kern, int which) {
         if (!once[which].done()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, c8::kLds);
@@ -393,12 +430,19 @@ static int conv_cells_impl(const void* xc, const uint16_t* W_hi, const uint16_t*
     const int taps = kH * kW * kD;
     if (taps > 32) return fail(HAET_E_ARG, "conv_project_cells_fwd: %d taps (at most 32: one validity bit per tap)", taps);
     const char* ve = getenv("HAET_C8_VAR");  // A/B switch, read per call (tools/conv8_probe.py)
-    const int var = ve ? atoi(ve) : 0;
-    switch (var & 3) {
-        case 1: return split ? launch(c8::conv8_kernel<1, 1>, 3) : launch(c8::conv8_kernel<0, 1>, 2);
-        case 2: return split ? launch(c8::conv8_kernel<1, 2>, 5) : launch(c8::conv8_kernel<0, 2>, 4);
-        case 3: return split ? launch(c8::conv8_kernel<1, 3>, 7) : launch(c8::conv8_kernel<0, 3>, 6);
-        default: return split ? launch(c8::conv8_kernel<1, 0>, 1) : launch(c8::conv8_kernel<0, 0>, 0);
+    const int var = ve ? atoi(ve) : c8::kDefaultVar;
+    if (split) return launch(c8::conv8_kernel<1, -1, 4, 1, 0>, 15);
+    switch (var) {
+        case 0: return launch(c8::conv8_kernel<0, -1, -1, 0, 0>, 0);
+        case 1: return launch(c8::conv8_kernel<0, -1, 3, 0, 0>, 1);
+        case 2: return launch(c8::conv8_kernel<0, -1, -1, 1, 0>, 2);
+        case 4: return launch(c8::conv8_kernel<0, -1, 2, 1, 0>, 4);
+        case 6: return launch(c8::conv8_kernel<0, 0, 4, 1, 0>, 6);
+        case 7: return launch(c8::conv8_kernel<0, -1, 3, 1, 1>, 7);
+        case 8: return launch(c8::conv8_kernel<0, -1, 3, 2, 0>, 8);
+        case 9: return launch(c8::conv8_kernel<0, 3, -1, 1, 0>, 9);
+        case 3: return launch(c8::conv8_kernel<0, -1, 3, 1, 0>, 3);
+        default: return launch(c8::conv8_kernel<0, -1, 4, 1, 0>, 5);
     }
 }
 

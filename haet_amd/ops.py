@@ -663,7 +663,7 @@ class SplitConv:
 
 
 # --------------------------------------------------------------------------- LDS-DMA convolution (csrc/conv8.hip)
-CONV_CELLS_MIN_ROWS = 32768  # below this the grid is a latency case: the split-k path of the streaming kernel serves it
+CONV_CELLS_MIN_ROWS = 49152  # 192 row tiles of 256: below that the 128-row tiles of the streaming kernel fill the chip better (tools/conv8_sweep.py: 0.86-0.97x at 128 tiles, 1.3-1.6x from 256)
 
 
 def conv_cells_applies(Cin: int, O: int, rows: int, taps: int = 27) -> bool:

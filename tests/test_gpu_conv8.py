@@ -130,18 +130,18 @@ def test_cells_convolution_split_format(B, grid, k, hip_device):
 
 
 def test_dispatch_takes_the_cells_kernel_at_c5_widths(hip_device, monkeypatch):
-    """ops.conv_project routes the wide shapes (O = 256, >= 32768 rows) to the LDS-DMA kernel and HAET_CONV_V1=1 back to the
+    """ops.conv_project routes the wide shapes (O = 256, >= 49152 rows) to the LDS-DMA kernel and HAET_CONV_V1=1 back to the
     streaming one; both agree."""
     from haet_amd import ops
 
     torch.manual_seed(9)
-    grid = (32, 32, 32)
-    x = torch.randn(1, 32768, 64, device=hip_device)
+    grid = (40, 40, 40)
+    x = torch.randn(1, 64000, 64, device=hip_device)
     W = torch.randn(256, 64, 3, 3, 3, device=hip_device) * 0.05
     w = ops.SplitConv(W, torch.randn(256, device=hip_device))
-    assert ops.conv_cells_applies(64, 256, 32768)
+    assert ops.conv_cells_applies(64, 256, 64000)
     a = ops.conv_project(x, w, grid)
     monkeypatch.setenv("HAET_CONV_V1", "1")
-    assert not ops.conv_cells_applies(64, 256, 32768)
+    assert not ops.conv_cells_applies(64, 256, 64000)
     b = ops.conv_project(x, w, grid)
     assert _rel(a.cpu(), b.cpu()) < 1e-5

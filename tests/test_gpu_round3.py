@@ -188,7 +188,8 @@ def test_split_k_convolution_deterministic_switch(hip_device):
     """The convolution projection of a small grid (config C1's regime) splits its k-tiles over workgroups that add
     with float atomics; deterministic mode (HAET_DETERMINISTIC=1 / torch.use_deterministic_algorithms) takes the
     one-workgroup-per-tile path: two runs bit-identical, and both variants equal to rounding.  2 500 rows: a partial
-    last 128-row tile."""
+    last 128-row tile.  The Python host passes torch's setting PER CALL (haet_conv_project_det_fwd) and never writes the
+    library's process-wide flag; an explicit C-side haet_set_deterministic(1) is honoured and left alone."""
     from haet_amd import _lib, ops
 
     torch.manual_seed(4)
@@ -203,11 +204,18 @@ def test_split_k_convolution_deterministic_switch(hip_device):
     torch.use_deterministic_algorithms(True, warn_only=True)
     try:
         d1 = ops.conv_project(x, w, grid)
-        assert lib.haet_get_deterministic() == 1
+        assert lib.haet_get_deterministic() == 0  # (the process-wide flag is not the host's to write)
         d2 = ops.conv_project(x, w, grid)
     finally:
         torch.use_deterministic_algorithms(old)
     assert torch.equal(d1, d2)
+    lib.haet_set_deterministic(1)  # a C caller's explicit, process-wide choice
+    try:
+        d3 = ops.conv_project(x, w, grid)
+        assert lib.haet_get_deterministic() == 1
+    finally:
+        lib.haet_set_deterministic(0)
+    assert torch.equal(d1, d3)
     assert O.rel_l2(fast.cpu(), d1.cpu()) < 2e-6
     ref = torch.nn.functional.conv2d(x.double().reshape(1, *grid, Cin).permute(0, 3, 1, 2), W.double(), b.double(), padding=1)
     assert O.rel_l2(d1.cpu(), ref.permute(0, 2, 3, 1).reshape(1, -1, Oc).cpu()) < FP32_TOL
