@@ -94,9 +94,9 @@ SIGNATURES = {
     "haet_conv_project_supported": (c_int, [c_int, c_int]),
     "haet_conv_cells_supported": (c_int, [c_int, c_int]),
     "haet_conv_cells_bytes": (c_size_t, [c_longlong, c_int]),
-    "haet_conv_presplit": (c_int, [_P, c_longlong, c_int, _P, _P, _P, c_float, _P]),
-    "haet_conv_project_cells_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P, _P]),
-    "haet_conv_project_cells_split_fwd": (c_int, [_P, _P, _P, _P, _P, c_float, c_float] + [c_int] * 9 + [_P, _P, _P]),
+    "haet_conv_presplit": (c_int, [_P, c_longlong, c_int, _P, _P, _P, c_float, c_int, _P]),
+    "haet_conv_project_cells_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 9 + [_P, c_int, _P]),
+    "haet_conv_project_cells_split_fwd": (c_int, [_P, _P, _P, _P, _P, c_float, c_float] + [c_int] * 9 + [_P, _P, c_int, _P]),
     "haet_conv_project_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                       _P, _P]),
     "haet_conv_project_det_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -27,6 +27,9 @@ namespace haet {
 namespace c8 {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -64,11 +67,29 @@ __device__ __forceinline__ f32x4 mfma3(const u32x4 ah, const u32x4 al, const u32
     return c;
 }
 
+// PREC = 1 ("fp16x2", opt-in: haet_amd.set_precision / the trailing argument of the entry points): activations as fp16 hi +
+// fp16 lo, the weight as ONE fp16 plane -- two products per term instead of three; ~2e-4 against fp64 (bf16x3: 4e-6),
+// inside north_star's 1e-3 and the reference's own fp16-autocast grade; BASELINE config C5 names "fp16 MFMA".
+__device__ __forceinline__ f32x4 mfma2h(const u32x4 ah, const u32x4 al, const u32x4 b, f32x4 c) {
+    const f16x8 a_h = __builtin_bit_cast(f16x8, ah), a_l = __builtin_bit_cast(f16x8, al), b_h = __builtin_bit_cast(f16x8, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, b_h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l, b_h, c, 0, 0, 0);
+    return c;
+}
+__device__ __forceinline__ void split_f16_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    const f32x2 v = {a, b};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    const f32x2 r = {a - hf[0], b - hf[1]};
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+
 // x fp32 [rows][Cin] -> cells [rows + 1][Cin / 32][{32 hi | 32 lo}] bf16, row `rows` zeroed.  One thread = 8 channels
 // (two 16-B loads, one 16-B store into each plane half); LNORM = 1: nn.LayerNorm(Cin) over the row first (ln_1 in
 // front of the projection, HAETransolver_Structured_Mesh_3D.py block: the normalised activations never exist in HBM;
 // Cin = 256: a row = 32 threads).
-template <int LNORM>
+template <int LNORM, int PREC>
 __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__ x, long long rows, int Cin,
                                                        char* __restrict__ cells, const float* __restrict__ ln_g,
                                                        const float* __restrict__ ln_b, float ln_eps) {
@@ -111,10 +132,17 @@ __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__
         }
     }
     unsigned h[4], l[4];
-    split_bf16_pair(a[0], a[1], h[0], l[0]);
-    split_bf16_pair(a[2], a[3], h[1], l[1]);
-    split_bf16_pair(b[0], b[1], h[2], l[2]);
-    split_bf16_pair(b[2], b[3], h[3], l[3]);
+    if (PREC == 0) {
+        split_bf16_pair(a[0], a[1], h[0], l[0]);
+        split_bf16_pair(a[2], a[3], h[1], l[1]);
+        split_bf16_pair(b[0], b[1], h[2], l[2]);
+        split_bf16_pair(b[2], b[3], h[3], l[3]);
+    } else {
+        split_f16_pair(a[0], a[1], h[0], l[0]);
+        split_f16_pair(a[2], a[3], h[1], l[1]);
+        split_f16_pair(b[0], b[1], h[2], l[2]);
+        split_f16_pair(b[2], b[3], h[3], l[3]);
+    }
     *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
     *reinterpret_cast<u32x4*>(dst + 64) = u32x4{l[0], l[1], l[2], l[3]};
 }
@@ -126,8 +154,11 @@ __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__
 //     matrix pipe idles;
 //   PRIO: 1 = static s_setprio 1 for waves 4-7 (the second-dispatched half loses the arbitration otherwise:
 //     MI355X_MICROARCH.md, two waves per SIMD, item 4), 2 = for waves 0-3 instead;
-//   SPL: the four W DMAs two steps behind the four A DMAs instead of with them.
-template <int ACT, int P0, int P1, int PRIO, int SPL>
+// Measured on C5's slab (same process, interleaved; tools/conv8_probe.py): both halves behind the barrier, no priority 16.3 ms;
+// P1 = 3 alone 16.0; priority alone 16.1; P1 = 3 or 4 with priority 14.9-15.1 (shipped: P1 = 4); P1 = 2: 15.4; priority for
+// waves 0-3 instead: 16.1; the W DMAs two steps behind the A DMAs: 15.6; waves 4-7 holding the last A-step's MFMAs back
+// across the barrier (a deferred-epilogue stagger): 15.9 with mid-tile DMAs, 16.7 without -- not kept.
+template <int ACT, int P0, int P1, int PRIO, int PREC>
 __global__ __launch_bounds__(kThreads) void conv8_kernel(const char* __restrict__ xc, const unsigned short* __restrict__ Whi,
                                                          const unsigned short* __restrict__ Wlo, const float* __restrict__ bias,
                                                          int Nrows, int n_row_tiles, float* __restrict__ out, Geom cg, Split cs) {
@@ -156,6 +187,10 @@ __global__ __launch_bounds__(kThreads) void conv8_kernel(const char* __restrict_
     const int aq0 = q0 * 16;
     const char* const w_even = reinterpret_cast<const char*>((q0 >> 2) ? Wlo : Whi) + ((size_t)rloc * K + (q0 & 3) * 8) * 2;
     const char* const w_odd = reinterpret_cast<const char*>((q0 >> 2) ? Whi : Wlo) + ((size_t)rloc * K + (q0 & 3) * 8) * 2;
+    // PREC = 1: the W stage is ONE plane, 64-B rows: a DMA instruction = 16 columns x 64 B, two per wave and k-tile;
+    // 16-B chunk c of column n sits in slot c ^ (-(n >> 2) & 3) (conflict-free ds_read_b128 fragment reads of 64-B rows)
+    const int wcol1 = 32 * wave + (lane >> 2);  // + 16 j
+    const char* const w_one = reinterpret_cast<const char*>(Whi) + ((size_t)wcol1 * K + (((lane & 3) ^ (-(wcol1 >> 2) & 3)) * 8)) * 2;
     const int a_lds0 = (32 * wave) * 128, w_lds0 = kAStage + (32 * wave) * 128;  // + j * 1024; the hardware adds lane * 16
     // fetch cursor (one item ahead of the compute cursor): scalars
     int f_tile = t_lo + widx, f_cb = 0, f_a = 0, f_b = 0, f_c = 0, f_kt = 0, f_tap = 0;
@@ -181,7 +216,7 @@ __global__ __launch_bounds__(kThreads) void conv8_kernel(const char* __restrict_
         }
     };
     tile_masks(f_tile);
-    auto fetch_a = [&](int stage) {
+    auto fetch = [&](int stage) {
         const int shift = ((f_a - (cg.kH >> 1)) * cg.gW + (f_b - (cg.kW >> 1))) * cg.gD + (f_c - (cg.kD >> 1));
         const int cb_off = f_cb * 128, r0 = f_tile * BM + rloc + shift;
 #pragma unroll
@@ -189,11 +224,15 @@ __global__ __launch_bounds__(kThreads) void conv8_kernel(const char* __restrict_
             const int sr = (tapmask[j] >> f_tap) & 1u ? r0 + 8 * j : Nrows;
             dma16(xc + (size_t)sr * rowB + cb_off + (aq0 ^ ((j & 1) << 6)), stage + a_lds0 + j * 1024);
         }
-    };
-    auto fetch_w = [&](int stage) {
+        if (PREC == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            dma16(((j & 1) ? w_odd : w_even) + (size_t)j * 8 * K * 2 + (size_t)f_kt * 64, stage + w_lds0 + j * 1024);
+            for (int j = 0; j < 4; ++j)
+                dma16(((j & 1) ? w_odd : w_even) + (size_t)j * 8 * K * 2 + (size_t)f_kt * 64, stage + w_lds0 + j * 1024);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)  // ((-(n >> 2)) & 3 is the same for n and n + 16)
+                dma16(w_one + (size_t)j * 16 * K * 2 + (size_t)f_kt * 64, stage + kAStage + (32 * wave + 16 * j) * 64);
+        }
     };
     auto advance = [&]() {  // tap fastest, then channel block, then the row tile
         ++f_kt, ++f_tap;
@@ -217,7 +256,8 @@ __global__ __launch_bounds__(kThreads) void conv8_kernel(const char* __restrict_
     // ---- fragment read offsets (see the header: slot XOR (row >> 1) & 7; the lo plane is the hi slot XOR 4)
     const int sw = (l15 >> 1) & 7;
     const int a_rd = (128 * wr + l15) * 128 + ((kg ^ sw) << 4);
-    const int b_rd = kAStage + (64 * wc + l15) * 128 + ((kg ^ sw) << 4);
+    const int b_rd = PREC == 0 ? kAStage + (64 * wc + l15) * 128 + ((kg ^ sw) << 4)
+                               : kAStage + (64 * wc + l15) * 64 + ((kg ^ (-(l15 >> 2) & 3)) << 4);  // + j * 1024 (16 columns x 64 B)
 
     float bv[4];
 #pragma unroll
@@ -235,10 +275,78 @@ __global__ __launch_bounds__(kThreads) void conv8_kernel(const char* __restrict_
             for (int q = 0; q < 4; ++q) wt4[j][q] = cs.wt[16 * (j & 1) + (l15 & ~3) + q];
     }
 
-    fetch_a(0);
-    fetch_w(0);
+    fetch(0);
     advance();
     if (PRIO && wr == (PRIO == 1 ? 1 : 0)) __builtin_amdgcn_s_setprio(1);
+    auto epilogue = [&](int tile) __attribute__((always_inline)) {
+        const long long row0 = (long long)tile * BM + 128 * wr;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long long rbase = row0 + 16 * i + 4 * kg;  // first of this lane's 4 rows of tile row block i
+            if (ACT == 1) {
+                // a 4 x 4 transpose across the lane quad turns four rows of ONE column into ONE row (rbase + lane % 4) and
+                // four consecutive columns = one 16-B cell {4 x hi, 4 x lo}; the Ada-Temp dot over a head's 32 channels =
+                // column blocks (2 h, 2 h + 1) of this lane + the other three quads of its 16-lane row
+                const long long rowi = rbase + (lane & 3);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float t = 0.f;
+                    u32x4 o4[2];
+#pragma unroll
+                    for (int jo = 0; jo < 2; ++jo) {
+                        const int j = 2 * h + jo;
+                        int v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = __float_as_int(acc[i][j][q]);
+                        const bool odd = lane & 1, up = lane & 2;
+#pragma unroll
+                        for (int m = 0; m < 4; m += 2) {
+                            const int send = odd ? v[m] : v[m + 1];
+                            const int recv = __builtin_amdgcn_update_dpp(0, send, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+                            v[m] = odd ? recv : v[m];
+                            v[m + 1] = odd ? v[m + 1] : recv;
+                        }
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const int send = up ? v[m] : v[m + 2];
+                            const int recv = __builtin_amdgcn_update_dpp(0, send, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+                            v[m] = up ? recv : v[m];
+                            v[m + 2] = up ? v[m + 2] : recv;
+                        }
+                        const float f0 = __int_as_float(v[0]), f1 = __int_as_float(v[1]), f2 = __int_as_float(v[2]), f3 = __int_as_float(v[3]);
+                        unsigned h01, l01, h23, l23;
+                        split_bf16_pair(f0, f1, h01, l01);
+                        split_bf16_pair(f2, f3, h23, l23);
+                        o4[jo] = u32x4{h01, h23, l01, l23};
+                        t = fmaf(f0, wt4[j][0], t);
+                        t = fmaf(f1, wt4[j][1], t);
+                        t = fmaf(f2, wt4[j][2], t);
+                        t = fmaf(f3, wt4[j][3], t);
+                    }
+                    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x124, 0xF, 0xF, false));  // row_ror:4
+                    t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, false));  // row_ror:8
+                    const float tau = cs.base_temp + fminf(fmaxf(t + cs.bt, -0.4f), 0.4f);
+                    if (rowi < Nrows) {
+                        const int head = 2 * wc + h;
+#pragma unroll
+                        for (int jo = 0; jo < 2; ++jo)
+                            *reinterpret_cast<u32x4*>(out + rowi * BN + 32 * head + 16 * jo + (l15 & ~3)) = o4[jo];
+                        cs.s_out[rowi * (BN / 32) + head] = 1.4426950408889634f * __builtin_amdgcn_rcpf(tau);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float* oc = out + rbase * BN + 64 * wc + 16 * j + l15;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (rbase + r < Nrows) oc[(size_t)r * BN] = acc[i][j][r];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{bv[j], bv[j], bv[j], bv[j]};
+        }
+    };
     int c_tile = t_lo + widx, c_kt = 0;
     for (int it = 0; it < total; ++it) {
         const int st = (it & 1) * kStage;
@@ -247,24 +355,17 @@ __global__ __launch_bounds__(kThreads) void conv8_kernel(const char* __restrict_
         __builtin_amdgcn_s_barrier();
         // (the fetches are unconditional: the item past the end is a ghost into the stage nobody reads again)
         if (P0 == P1 && P0 < 0) {
-            fetch_a(st ^ kStage);
-            if (!SPL) fetch_w(st ^ kStage);
+            fetch(st ^ kStage);
         } else {
-            if (P0 < 0 && wr == 0) {
-                fetch_a(st ^ kStage);
-                if (!SPL) fetch_w(st ^ kStage);
-            }
-            if (P1 < 0 && wr == 1) {
-                fetch_a(st ^ kStage);
-                if (!SPL) fetch_w(st ^ kStage);
-            }
+            if (P0 < 0 && wr == 0) fetch(st ^ kStage);
+            if (P1 < 0 && wr == 1) fetch(st ^ kStage);
         }
 
         u32x4 bh[4], bl[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            bh[j] = lds16(st + b_rd + j * 2048);
-            bl[j] = lds16(st + (b_rd ^ 64) + j * 2048);
+            bh[j] = lds16(st + b_rd + j * (PREC == 0 ? 2048 : 1024));
+            if (PREC == 0) bl[j] = lds16(st + (b_rd ^ 64) + j * 2048);
         }
         u32x4 ah = lds16(st + a_rd), al = lds16(st + (a_rd ^ 64));
 #pragma unroll
@@ -275,98 +376,19 @@ __global__ __launch_bounds__(kThreads) void conv8_kernel(const char* __restrict_
                 nl = lds16(st + (a_rd ^ 64) + (i + 1) * 2048);
             }
             if (P0 == P1) {
-                if (i == P0) {
-                    fetch_a(st ^ kStage);
-                    if (!SPL) fetch_w(st ^ kStage);
-                }
-                if (SPL && i == P0 + 2) fetch_w(st ^ kStage);
+                if (i == P0) fetch(st ^ kStage);
             } else {
-                if (i == P0 && wr == 0) {
-                    fetch_a(st ^ kStage);
-                    if (!SPL) fetch_w(st ^ kStage);
-                }
-                if (SPL && i == P0 + 2 && wr == 0) fetch_w(st ^ kStage);
-                if (i == P1 && wr == 1) {
-                    fetch_a(st ^ kStage);
-                    if (!SPL) fetch_w(st ^ kStage);
-                }
-                if (SPL && i == P1 + 2 && wr == 1) fetch_w(st ^ kStage);
+                if (i == P0 && wr == 0) fetch(st ^ kStage);
+                if (i == P1 && wr == 1) fetch(st ^ kStage);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma3(ah, al, bh[j], bl[j], acc[i][j]);
+            for (int j = 0; j < 4; ++j) acc[i][j] = PREC == 0 ? mfma3(ah, al, bh[j], bl[j], acc[i][j]) : mfma2h(ah, al, bh[j], acc[i][j]);
             ah = nh, al = nl;
         }
         advance();
-
-        if (++c_kt == nkt) {  // row tile finished
+        if (++c_kt == nkt) {  // row tile finished: its stores go out behind the next barrier (waves 4-7: behind their held-back MFMAs)
             c_kt = 0;
-            const long long row0 = (long long)c_tile * BM + 128 * wr;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const long long rbase = row0 + 16 * i + 4 * kg;  // first of this lane's 4 rows of tile row block i
-                if (ACT == 1) {
-                    // a 4 x 4 transpose across the lane quad turns four rows of ONE column into ONE row (rbase + lane % 4) and
-                    // four consecutive columns = one 16-B cell {4 x hi, 4 x lo}; the Ada-Temp dot over a head's 32 channels =
-                    // column blocks (2 h, 2 h + 1) of this lane + the other three quads of its 16-lane row
-                    const long long rowi = rbase + (lane & 3);
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        float t = 0.f;
-                        u32x4 o4[2];
-#pragma unroll
-                        for (int jo = 0; jo < 2; ++jo) {
-                            const int j = 2 * h + jo;
-                            int v[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) v[q] = __float_as_int(acc[i][j][q]);
-                            const bool odd = lane & 1, up = lane & 2;
-#pragma unroll
-                            for (int m = 0; m < 4; m += 2) {
-                                const int send = odd ? v[m] : v[m + 1];
-                                const int recv = __builtin_amdgcn_update_dpp(0, send, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
-                                v[m] = odd ? recv : v[m];
-                                v[m + 1] = odd ? v[m + 1] : recv;
-                            }
-#pragma unroll
-                            for (int m = 0; m < 2; ++m) {
-                                const int send = up ? v[m] : v[m + 2];
-                                const int recv = __builtin_amdgcn_update_dpp(0, send, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
-                                v[m] = up ? recv : v[m];
-                                v[m + 2] = up ? v[m + 2] : recv;
-                            }
-                            const float f0 = __int_as_float(v[0]), f1 = __int_as_float(v[1]), f2 = __int_as_float(v[2]), f3 = __int_as_float(v[3]);
-                            unsigned h01, l01, h23, l23;
-                            split_bf16_pair(f0, f1, h01, l01);
-                            split_bf16_pair(f2, f3, h23, l23);
-                            o4[jo] = u32x4{h01, h23, l01, l23};
-                            t = fmaf(f0, wt4[j][0], t);
-                            t = fmaf(f1, wt4[j][1], t);
-                            t = fmaf(f2, wt4[j][2], t);
-                            t = fmaf(f3, wt4[j][3], t);
-                        }
-                        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x124, 0xF, 0xF, false));  // row_ror:4
-                        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, false));  // row_ror:8
-                        const float tau = cs.base_temp + fminf(fmaxf(t + cs.bt, -0.4f), 0.4f);
-                        if (rowi < Nrows) {
-                            const int head = 2 * wc + h;
-#pragma unroll
-                            for (int jo = 0; jo < 2; ++jo)
-                                *reinterpret_cast<u32x4*>(out + rowi * BN + 32 * head + 16 * jo + (l15 & ~3)) = o4[jo];
-                            cs.s_out[rowi * (BN / 32) + head] = 1.4426950408889634f * __builtin_amdgcn_rcpf(tau);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float* oc = out + rbase * BN + 64 * wc + 16 * j + l15;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (rbase + r < Nrows) oc[(size_t)r * BN] = acc[i][j][r];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{bv[j], bv[j], bv[j], bv[j]};
-            }
+            epilogue(c_tile);
             c_tile += wper;
         }
     }
@@ -383,26 +405,26 @@ extern "C" int haet_conv_cells_supported(int Cin, int O) { return (Cin >= 32 && 
 extern "C" size_t haet_conv_cells_bytes(long long rows, int Cin) { return (size_t)(rows + 1) * (size_t)Cin * 4; }
 
 extern "C" int haet_conv_presplit(const float* x, long long rows, int Cin, void* cells, const float* ln_g, const float* ln_b,
-                                  float ln_eps, haet_stream_t stream) {
+                                  float ln_eps, int fp16x2, haet_stream_t stream) {
     if (!x || !cells || rows < 1) return fail(HAET_E_ARG, "conv_presplit: null pointer / no rows");
     if (Cin < 32 || Cin % 32) return fail(HAET_E_ARG, "conv_presplit: C_in=%d is not a multiple of 32", Cin);
     if ((ln_g != nullptr) != (ln_b != nullptr)) return fail(HAET_E_ARG, "conv_presplit: ln_g / ln_b go together");
     if (ln_g && Cin != 256) return fail(HAET_E_ARG, "conv_presplit: the fused LayerNorm needs C_in = 256");
     const long long threads = (rows + 1) * (Cin / 8);
     const unsigned blocks = (unsigned)((threads + 255) / 256);
-    if (ln_g)
-        hipLaunchKernelGGL(c8::presplit_kernel<1>, dim3(blocks), dim3(256), 0, as_stream(stream), x, rows, Cin,
-                           reinterpret_cast<char*>(cells), ln_g, ln_b, ln_eps);
-    else
-        hipLaunchKernelGGL(c8::presplit_kernel<0>, dim3(blocks), dim3(256), 0, as_stream(stream), x, rows, Cin,
-                           reinterpret_cast<char*>(cells), nullptr, nullptr, 0.f);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, as_stream(stream), x, rows, Cin, reinterpret_cast<char*>(cells), ln_g,
+                           ln_b, ln_eps);
+    };
+    if (ln_g) fp16x2 ? go(c8::presplit_kernel<1, 1>) : go(c8::presplit_kernel<1, 0>);
+    else fp16x2 ? go(c8::presplit_kernel<0, 1>) : go(c8::presplit_kernel<0, 0>);
     return check_launch("presplit_kernel");
 }
 
 static int conv_cells_impl(const void* xc, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias, int B, int gH, int gW,
                            int gD, int Cin, int O, int kH, int kW, int kD, float* out, haet_stream_t stream,
-                           const c8::Split* split) {
-    if (!xc || !W_hi || !W_lo || !out) return fail(HAET_E_ARG, "conv_project_cells_fwd: null pointer");
+                           const c8::Split* split, int fp16x2) {
+    if (!xc || !W_hi || (!W_lo && !fp16x2) || !out) return fail(HAET_E_ARG, "conv_project_cells_fwd: null pointer");
     if (!haet_conv_cells_supported(Cin, O))
         return fail(HAET_E_ARG, "conv_project_cells_fwd: C_in=%d (multiple of 32) / O=%d (256) unsupported", Cin, O);
     if (B < 1 || gH < 1 || gW < 1 || gD < 1 || kH < 1 || kW < 1 || kD < 1 || !(kH & kW & kD & 1))
@@ -416,7 +438,7 @@ static int conv_cells_impl(const void* xc, const uint16_t* W_hi, const uint16_t*
     int grid = ((tiles + 7) / 8) * 8;
     if (grid > cus) grid = cus;
     const c8::Geom cg{Cin, gH * gW * gD, gH, gW, gD, kH, kW, kD};
-    static PerDeviceOnce once[16];
+    static PerDeviceOnce once[10];
     auto launch = [&](auto kern, int which) {
         if (!once[which].done()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, c8::kLds);
@@ -431,16 +453,12 @@ static int conv_cells_impl(const void* xc, const uint16_t* W_hi, const uint16_t*
     if (taps > 32) return fail(HAET_E_ARG, "conv_project_cells_fwd: %d taps (at most 32: one validity bit per tap)", taps);
     const char* ve = getenv("HAET_C8_VAR");  // A/B switch, read per call (tools/conv8_probe.py)
     const int var = ve ? atoi(ve) : c8::kDefaultVar;
-    if (split) return launch(c8::conv8_kernel<1, -1, 4, 1, 0>, 15);
+    if (fp16x2) return split ? launch(c8::conv8_kernel<1, -1, 4, 1, 1>, 9) : launch(c8::conv8_kernel<0, -1, 4, 1, 1>, 8);
+    if (split) return launch(c8::conv8_kernel<1, -1, 4, 1, 0>, 7);
     switch (var) {
         case 0: return launch(c8::conv8_kernel<0, -1, -1, 0, 0>, 0);
         case 1: return launch(c8::conv8_kernel<0, -1, 3, 0, 0>, 1);
         case 2: return launch(c8::conv8_kernel<0, -1, -1, 1, 0>, 2);
-        case 4: return launch(c8::conv8_kernel<0, -1, 2, 1, 0>, 4);
-        case 6: return launch(c8::conv8_kernel<0, 0, 4, 1, 0>, 6);
-        case 7: return launch(c8::conv8_kernel<0, -1, 3, 1, 1>, 7);
-        case 8: return launch(c8::conv8_kernel<0, -1, 3, 2, 0>, 8);
-        case 9: return launch(c8::conv8_kernel<0, 3, -1, 1, 0>, 9);
         case 3: return launch(c8::conv8_kernel<0, -1, 3, 1, 0>, 3);
         default: return launch(c8::conv8_kernel<0, -1, 4, 1, 0>, 5);
     }
@@ -448,15 +466,15 @@ static int conv_cells_impl(const void* xc, const uint16_t* W_hi, const uint16_t*
 
 extern "C" int haet_conv_project_cells_fwd(const void* x_cells, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
                                            int B, int gH, int gW, int gD, int Cin, int O, int kH, int kW, int kD, float* out,
-                                           haet_stream_t stream) {
-    return conv_cells_impl(x_cells, W_hi, W_lo, bias, B, gH, gW, gD, Cin, O, kH, kW, kD, out, stream, nullptr);
+                                           int fp16x2, haet_stream_t stream) {
+    return conv_cells_impl(x_cells, W_hi, W_lo, bias, B, gH, gW, gD, Cin, O, kH, kW, kD, out, stream, nullptr, fp16x2);
 }
 
 extern "C" int haet_conv_project_cells_split_fwd(const void* x_cells, const uint16_t* W_hi, const uint16_t* W_lo,
                                                  const float* bias, const float* wt, float bt, float base_temp, int B, int gH,
                                                  int gW, int gD, int Cin, int O, int kH, int kW, int kD, void* cells_out,
-                                                 float* s_out, haet_stream_t stream) {
+                                                 float* s_out, int fp16x2, haet_stream_t stream) {
     if (!wt || !s_out) return fail(HAET_E_ARG, "conv_project_cells_split_fwd: null pointer");
     const c8::Split cs{wt, bt, base_temp, s_out};
-    return conv_cells_impl(x_cells, W_hi, W_lo, bias, B, gH, gW, gD, Cin, O, kH, kW, kD, reinterpret_cast<float*>(cells_out), stream, &cs);
+    return conv_cells_impl(x_cells, W_hi, W_lo, bias, B, gH, gW, gD, Cin, O, kH, kW, kD, reinterpret_cast<float*>(cells_out), stream, &cs, fp16x2);
 }

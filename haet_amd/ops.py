@@ -668,14 +668,18 @@ CONV_CELLS_MIN_ROWS = 49152  # 192 row tiles of 256: below that the 128-row tile
 
 def conv_cells_applies(Cin: int, O: int, rows: int, taps: int = 27) -> bool:
     """Whether the LDS-DMA implicit GEMM (haet_conv_project_cells_fwd: x pre-split into k-tile cells once per forward)
-    serves this convolution: O = 256, C_in % 32 = 0, at most 32 kernel taps, a grid large enough to fill the chip, default
-    bf16x3 arithmetic."""
-    if os.environ.get("HAET_CONV_V1") or _lib.precision() != "bf16x3" or rows < CONV_CELLS_MIN_ROWS or taps > 32:
+    serves this convolution: O = 256, C_in % 32 = 0, at most 32 kernel taps, a grid large enough to fill the chip (both
+    arithmetic modes: bf16x3 and the opt-in fp16x2)."""
+    if os.environ.get("HAET_CONV_V1") or rows < CONV_CELLS_MIN_ROWS or taps > 32:
         return False
     return bool(_lib.load().haet_conv_cells_supported(int(Cin), int(O)))
 
 
-def conv_presplit(x: Tensor, ln=None) -> Tensor:
+def _conv_f16(w: "SplitConv") -> bool:
+    return _lib.precision() == "fp16x2" and w.f16_ok()
+
+
+def conv_presplit(x: Tensor, ln=None, f16: bool = False) -> Tensor:
     """x [B, N, C_in] fp32 -> the convolution's operand cells [(B*N + 1), C_in] (4-byte slots: per row and 32-channel block
     {32 x bf16 hi | 32 x bf16 lo}; the extra last row is zeros = the padding every out-of-grid tap reads).
     `ln` = (weight, bias, eps): nn.LayerNorm(C_in) applied to every row first (C_in = 256)."""
@@ -687,7 +691,7 @@ def conv_presplit(x: Tensor, ln=None) -> Tensor:
     eps = 0.0
     if ln is not None:
         g, b, eps = _f32(ln[0].detach(), "ln.weight"), _f32(ln[1].detach(), "ln.bias"), float(ln[2])
-    check(lib.haet_conv_presplit(_p(x), B * N, Cin, _p(cells), _p(g), _p(b), eps, _stream()), "haet_conv_presplit")
+    check(lib.haet_conv_presplit(_p(x), B * N, Cin, _p(cells), _p(g), _p(b), eps, int(f16), _stream()), "haet_conv_presplit")
     return cells
 
 
@@ -703,11 +707,13 @@ def conv_project_cells(x: Tensor, w: "SplitConv", grid: Tuple[int, ...], ln=None
     lib = _lib.load()
     B, N, Cin = x.shape
     gH, gW, gD = _grid3(grid, N)
-    cells = conv_presplit(x, ln)
+    f16 = _conv_f16(w)
+    cells = conv_presplit(x, ln, f16)
     out = torch.empty((B, N, w.O), dtype=torch.float32, device=x.device)
     kH, kW, kD = w.kernel
-    check(lib.haet_conv_project_cells_fwd(_p(cells), _p(w.lin.hi), _p(w.lin.lo), _p(w.lin.bias), B, gH, gW, gD, Cin, w.O,
-                                          kH, kW, kD, _p(out), _stream()), "haet_conv_project_cells_fwd")
+    check(lib.haet_conv_project_cells_fwd(_p(cells), _p(w.f16() if f16 else w.lin.hi), _p(None if f16 else w.lin.lo), _p(w.lin.bias),
+                                          B, gH, gW, gD, Cin, w.O, kH, kW, kD, _p(out), int(f16), _stream()),
+          "haet_conv_project_cells_fwd")
     return out
 
 
@@ -715,12 +721,14 @@ def conv_project_cells_split(x: Tensor, w: "SplitConv", grid: Tuple[int, ...], p
     lib = _lib.load()
     B, N, Cin = x.shape
     gH, gW, gD = _grid3(grid, N)
-    xc = conv_presplit(x, ln)
+    f16 = _conv_f16(w)
+    xc = conv_presplit(x, ln, f16)
     cells = torch.empty((B, N, w.O), dtype=torch.float32, device=x.device)
     s = torch.empty((B, N, H), dtype=torch.float32, device=x.device)
     kH, kW, kD = w.kernel
-    check(lib.haet_conv_project_cells_split_fwd(_p(xc), _p(w.lin.hi), _p(w.lin.lo), _p(w.lin.bias), _p(p.wt), p.bt, p.base_temp,
-                                                B, gH, gW, gD, Cin, w.O, kH, kW, kD, _p(cells), _p(s), _stream()),
+    check(lib.haet_conv_project_cells_split_fwd(_p(xc), _p(w.f16() if f16 else w.lin.hi), _p(None if f16 else w.lin.lo),
+                                                _p(w.lin.bias), _p(p.wt), p.bt, p.base_temp, B, gH, gW, gD, Cin, w.O, kH, kW, kD,
+                                                _p(cells), _p(s), int(f16), _stream()),
           "haet_conv_project_cells_split_fwd")
     return SplitPoints(cells, s, H, C)
 

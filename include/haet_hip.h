@@ -489,14 +489,19 @@ int haet_conv_project_det_fwd(const float* x, const uint16_t* W_hi, const uint16
  * = 0, O = 256), odd kernels, rows < 2^31 - 256.                                                                  */
 int haet_conv_cells_supported(int Cin, int O);
 size_t haet_conv_cells_bytes(long long rows, int Cin);
+/* fp16x2 != 0 (opt-in, see the "fp16x2" note below): the cells hold fp16 hi / fp16 lo instead of bf16, W_hi is the weight as
+ * ONE fp16 plane (haet_conv_project_f16_fwd's W_f16) and W_lo is ignored (may be NULL): 2 products per term, ~2e-4.
+ * The pre-split pass and the convolution must be called with the same setting.                                   */
 int haet_conv_presplit(const float* x /*[rows, C_in]*/, long long rows, int Cin, void* x_cells,
-                       const float* ln_g /*[C_in] or NULL*/, const float* ln_b, float ln_eps, haet_stream_t stream);
+                       const float* ln_g /*[C_in] or NULL*/, const float* ln_b, float ln_eps, int fp16x2,
+                       haet_stream_t stream);
 int haet_conv_project_cells_fwd(const void* x_cells, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
                                 int B, int gH, int gW, int gD, int Cin, int O, int kH, int kW, int kD,
-                                float* out, haet_stream_t stream);
+                                float* out, int fp16x2, haet_stream_t stream);
 int haet_conv_project_cells_split_fwd(const void* x_cells, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
                                       const float* wt, float bt, float base_temp, int B, int gH, int gW, int gD, int Cin,
-                                      int O, int kH, int kW, int kD, void* cells, float* s_out, haet_stream_t stream);
+                                      int O, int kH, int kW, int kD, void* cells, float* s_out, int fp16x2,
+                                      haet_stream_t stream);
 /* The same convolution with Ada-Temp in its epilogue and the output in the fused operand format of the streaming
  * passes (what haet_project_split_fwd writes for the Linear projection; StructuredMesh2D.py:173-181,
  * StructuredMesh3D.py:177-185): cells [B*N][O] 4-byte slots -- per 4 channels {4 x bf16 hi, 4 x bf16 lo} -- and

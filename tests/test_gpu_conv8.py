@@ -145,3 +145,33 @@ def test_dispatch_takes_the_cells_kernel_at_c5_widths(hip_device, monkeypatch):
     assert not ops.conv_cells_applies(64, 256, 64000)
     b = ops.conv_project(x, w, grid)
     assert _rel(a.cpu(), b.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("B,grid,Cin,k", [(2, (9, 7), 32, 3), (1, (3, 300), 96, 3), (1, (14, 14, 14), 256, 3)])
+def test_cells_convolution_fp16x2_mode(B, grid, Cin, k, hip_device):
+    """The opt-in reduced-term arithmetic (haet_amd.set_precision("fp16x2"): fp16 hi + lo activations, one fp16 weight plane,
+    two products per term) of the LDS-DMA kernel: ~2e-4 against fp64, bound 5e-4 (north_star's bar: 1e-3); the fp32 and the
+    split-format epilogues."""
+    import haet_amd
+    from haet_amd import ops
+
+    torch.manual_seed(sum(grid) + Cin)
+    N = 1
+    for g in grid:
+        N *= g
+    x = torch.randn(B, N, Cin)
+    W = torch.randn(256, Cin, *([k] * len(grid))) * 0.05
+    b = torch.randn(256)
+    ref = _conv_fp64(x, W, b, grid, k)
+    w = ops.SplitConv(W.to(hip_device), b.to(hip_device))
+    sp = ops.SliceParams(torch.randn(64, 32, device=hip_device), torch.randn(64, device=hip_device),
+                         torch.randn(1, 32, device=hip_device) * 0.3, 0.05, 0.5, 1e-6)
+    haet_amd.set_precision("fp16x2")
+    try:
+        out = ops.conv_project_cells(x.to(hip_device), w, grid).cpu()
+        xs = ops.conv_project_cells_split(x.to(hip_device), w, grid, sp, 8, 32)
+    finally:
+        haet_amd.set_precision("bf16x3")
+    e = _rel(out, ref)
+    assert 1e-5 < e < 5e-4, e  # (above the bf16x3 grade: the mode really ran)
+    assert _rel(xs.to_float().cpu(), ref) < 5e-4

@@ -37,9 +37,9 @@ def timed(fn):
     return a.elapsed_time(b), r
 
 
-def new_kernel_only(cells, out):
-    ops.check(lib.haet_conv_project_cells_fwd(ops._p(cells), ops._p(w.lin.hi), ops._p(w.lin.lo), ops._p(w.lin.bias), 1, *grid, Cin, O,
-                                              3, 3, 3, ops._p(out), ops._stream()), "cells")
+def new_kernel_only(cells, out, f16=False):
+    ops.check(lib.haet_conv_project_cells_fwd(ops._p(cells), ops._p(w.f16() if f16 else w.lin.hi), ops._p(None if f16 else w.lin.lo),
+                                              ops._p(w.lin.bias), 1, *grid, Cin, O, 3, 3, 3, ops._p(out), int(f16), ops._stream()), "cells")
 
 
 def old(xx):
@@ -56,8 +56,12 @@ with torch.no_grad():
     new_kernel_only(cells, out)
     ref = old(x)
     err = float((out - ref).norm() / ref.norm())
-    variants = [int(v) for v in os.environ.get("C8_VARIANTS", "0").split(",")]
-    t = {"presplit": [], "old": []}
+    variants = [int(v) for v in os.environ.get("C8_VARIANTS", "5").split(",")]
+    t = {"presplit": [], "old": [], "new_f16": []}
+    cells16 = ops.conv_presplit(x, None, True)
+    out16 = torch.empty_like(out)
+    new_kernel_only(cells16, out16, True)
+    err16 = float((out16 - ref).norm() / ref.norm())
     for v in variants:
         t[f"new{v}"] = []
         os.environ["HAET_C8_VAR"] = str(v)
@@ -70,6 +74,7 @@ with torch.no_grad():
             os.environ["HAET_C8_VAR"] = str(v)
             t[f"new{v}"].append(timed(lambda: new_kernel_only(cells, out))[0])
         t["old"].append(timed(lambda: old(x))[0])
+        t["new_f16"].append(timed(lambda: new_kernel_only(cells16, out16, True))[0])
 fl3 = 3 * 2.0 * N * 27 * Cin * O
 med = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
 print(f"conv {planes}x{gw}x{gw} = {N} points, 256 -> 256, 3x3x3, rel diff new vs old {err:.1e}")
@@ -77,5 +82,6 @@ print(f"  presplit {med['presplit']:.3f} ms ({2 * N * Cin * 4 / med['presplit'] 
 for k in t:
     if k == "presplit":
         continue
-    tf = fl3 / (med[k] * 1e-3) / 1e12
-    print(f"  {k:6s} {med[k]:.2f} ms  min {min(t[k]):.2f}  = {tf:.0f} TFLOP/s of bf16 MFMA ({tf / 25:.1f} % of 2.5 PF)")
+    tf = fl3 * (2.0 / 3.0 if k == "new_f16" else 1.0) / (med[k] * 1e-3) / 1e12
+    print(f"  {k:7s} {med[k]:.2f} ms  min {min(t[k]):.2f}  = {tf:.0f} TFLOP/s of bf16 / fp16 MFMA ({tf / 25:.1f} % of 2.5 PF)")
+print(f"  fp16x2 vs bf16x3 output: rel diff {err16:.1e}")
