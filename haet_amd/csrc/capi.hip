@@ -41,7 +41,7 @@ int deslice_valu_fwd(const float*, const float*, const float*, const float*, flo
 
 // slice_mfma.hip
 struct MfmaPlan {
-    int li, ipw, mb, hpw, tiles_per_chunk, parts;
+    int li, ipw, mb, hpw, tiles_per_chunk, parts, cb;
     int s_nw, s_li;
     size_t lds_slice, lds_deslice;
 };
@@ -144,7 +144,7 @@ extern "C" int haet_deslice_fwd(const float* x_lin, const float* Ws, const float
 // ---- the same two passes on the split-format projection (haet_project_split_fwd) ----------------
 extern "C" int haet_slice_split_supported(int B, int N, int H, int C, int M) {
     MfmaPlan p;
-    return (slice_shape_ok(B, N, H, C, M) == HAET_OK && (H == 8 || H == 16) && use_mfma(B, N, H, C, M, &p)) ? 1 : 0;
+    return (slice_shape_ok(B, N, H, C, M) == HAET_OK && C == 32 && (H == 8 || H == 16) && use_mfma(B, N, H, C, M, &p)) ? 1 : 0;
 }
 
 extern "C" int haet_slice_fwd_split(const void* x_split, const float* s, const float* Ws, const float* bs,

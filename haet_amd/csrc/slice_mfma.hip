@@ -44,7 +44,9 @@ namespace haet {
 // instead of overlapping (two waves per SIMD at ~230 VGPRs).  Tried without gain: 16 waves with
 // one item each (128 VGPRs only with spills; 25 % slower), running the two waves of a SIMD in
 // opposite stage/compute order.
-template <int LI, int IPW, int MB, int NWV = NW, bool SPLIT = false, bool PRIV = false>
+// CB = dim_head / 32 (round 4; BASELINE config C2 is H = 4, dim_head 64, M = 32): the tile is staged as H * CB virtual
+// heads of 32 channels; an item's logits contract over both channel blocks, its P feeds CB accumulators Z.
+template <int LI, int IPW, int MB, int NWV = NW, bool SPLIT = false, bool PRIV = false, int CB = 1>
 __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ Ws, const float* __restrict__ bs,
     const float* __restrict__ wt, float bt, float base_temp, float c0, int N, int H,
@@ -62,22 +64,25 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
     const int n_tiles = (N + TN - 1) / TN, G = gridDim.x;
     const int t_begin = blockIdx.x, t_end = n_tiles;
     // LDS (byte offsets): tile buffers [2][H][hi|lo] | s_n [2][H][32] | rescale scratch [NW][32] | Ws images
-    const int buf_bytes = H * 2 * IMG;
-    const int sarr0 = 2 * buf_bytes, sarr_bytes = H * TN * 4;
+    constexpr int C = kC * CB;
+    const int Hv = H * CB;  // virtual heads of 32 channels
+    const int buf_bytes = Hv * 2 * IMG;
+    const int sarr0 = 2 * buf_bytes, sarr_bytes = Hv * TN * 4;
     const int scratch = sarr0 + 2 * sarr_bytes + wave * 32 * 4;
-    const int wimg = sarr0 + 2 * sarr_bytes + NWV * 32 * 4;  // [MB][hi|lo] images of Ws
-    const float* xb = x + (size_t)b * N * H * kC;
+    const int wimg = sarr0 + 2 * sarr_bytes + NWV * 32 * 4;  // [MB][CB][hi|lo] images of Ws
+    const float* xb = x + (size_t)b * N * H * C;
 
     static_assert(!PRIV || (SPLIT && LI == 4), "wave-private loading: split input, H = 8 (one head per wave)");
-    Loader<LI, NWV * 64, SPLIT, PRIV> ld;
-    ld.init(wt, xb, H, t_begin * TN, SPLIT ? s_in + (size_t)b * N * H : nullptr);
+    static_assert(CB == 1 || (!SPLIT && !PRIV), "dim_head 64: fp32 input (Ada-Temp in the loader)");
+    Loader<LI, NWV * 64, SPLIT, PRIV, CB> ld;
+    ld.init(wt, xb, Hv, t_begin * TN, SPLIT ? s_in + (size_t)b * N * H : nullptr);
     ld.tile_stride *= G;
     if (SPLIT) ld.s_stride *= G;
-    stage_ws(wimg, Ws, M);
+    stage_ws<CB>(wimg, Ws, M);
 
     // per-item state (the Ws fragments -- B operand: col g = lane&31, k = c -- come from LDS)
     float bias[IPW], m2[IPW], lsum[IPW];
-    f32x16 Z[IPW];
+    f32x16 Z[IPW][CB];
     const int item0 = wave * IPW;
 #pragma unroll
     for (int k = 0; k < IPW; ++k) {
@@ -87,7 +92,9 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
         m2[k] = -INFINITY;
         lsum[k] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Z[k][r] = 0.f;
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Z[k][cb][r] = 0.f;
     }
     const bool active = item0 < H * MB;
 
@@ -103,14 +110,14 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
 #pragma unroll
             for (int hh = 0; hh < HPW; ++hh) {
                 const int h = (item0 + hh * IPH) / MB;
-                const int img = cur * buf_bytes + h * (2 * IMG);
-                const int sp = sarr0 + cur * sarr_bytes + 4 * (h * TN);
+                const int img = cur * buf_bytes + h * CB * (2 * IMG);  // (+ cb * 2 IMG: the head's channel blocks)
+                const int sp = sarr0 + cur * sarr_bytes + 4 * (h * CB * TN);
                 // rows of this lane's accumulator registers: n = (r&3) + 8(r>>2) + 4hf
                 const int sq = sp + 16 * hf;  // s_n of those rows: four 16-B pieces, 32 B apart
 #pragma unroll
                 for (int kk = 0; kk < IPH; ++kk) {
                     const int k = hh * IPH + kk;
-                    const int wi = wimg + ((item0 + k) % MB) * (2 * IMG);
+                    const int wi = wimg + ((item0 + k) % MB) * CB * (2 * IMG);
                     // Live ranges are kept short on purpose (fragments read where they are used, the
                     // logits not kept for the rare rescale): the one-item-per-wave variant has to fit
                     // 128 VGPRs to run four waves per SIMD.
@@ -118,8 +125,11 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
                         f32x16 Y;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) Y[r] = bias[k];
-                        Y = mfma3(read_rows(img, l31, hf), read_rows(wi, l31, hf), Y);
-                        Y = mfma3(read_rows(img, l31, 2 + hf), read_rows(wi, l31, 2 + hf), Y);
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb) {
+                            Y = mfma3(read_rows(img + cb * (2 * IMG), l31, hf), read_rows(wi + cb * (2 * IMG), l31, hf), Y);
+                            Y = mfma3(read_rows(img + cb * (2 * IMG), l31, 2 + hf), read_rows(wi + cb * (2 * IMG), l31, 2 + hf), Y);
+                        }
                         return Y;
                     };
                     // p = exp2(Y s_n - m2): one fma + one v_exp per element.  The running maximum is a
@@ -172,7 +182,9 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
                         for (int i = 0; i < 4; ++i) {
                             const f32x4 a4 = *reinterpret_cast<const f32x4*>(smem + scratch + 4 * (8 * i + 4 * hf));
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) Z[k][4 * i + q] *= a4[q];
+                            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) Z[k][cb][4 * i + q] *= a4[q];
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         m2[k] = mn;
@@ -197,7 +209,9 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
                         float ph[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) ph[j] = p[8 * s + j];
-                        Z[k] = mfma3(split8(ph), read_cols(img, s, lane), Z[k]);
+                        const Frag pf = split8(ph);
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb) Z[k][cb] = mfma3(pf, read_cols(img + cb * (2 * IMG), s, lane), Z[k][cb]);
                     }
                 }
             }
@@ -212,24 +226,26 @@ __global__ __launch_bounds__(NWV * 64) void slice_mfma_kernel(
 #pragma unroll
         for (int k = 0; k < IPW; ++k) {
             const int id = item0 + k, h = id / MB, gb = id % MB;
-            float* rec = parts + ((size_t)blockIdx.x * BH + b * H + h) * (size_t)M_rec * (kC + 2);
+            float* rec = parts + ((size_t)blockIdx.x * BH + b * H + h) * (size_t)M_rec * (C + 2);
             const float l = lsum[k] + __shfl_xor(lsum[k], 32);
             if (hf == 0) {
                 rec[g_off + 32 * gb + l31] = m2[k] * kLn2;
                 rec[M_rec + g_off + 32 * gb + l31] = l;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int g = g_off + 32 * gb + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                rec[2 * M_rec + g * kC + l31] = Z[k][r];
-            }
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int g = g_off + 32 * gb + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                    rec[2 * M_rec + g * C + 32 * cb + l31] = Z[k][cb][r];
+                }
         }
     }
 }
 
 // ----------------------------------------------------------------------------- de-slice
 // HPW heads per wave; all MB column blocks of a head are summed into one output tile.
-template <int LI, int HPW, int MB, bool SPLIT = false>
+template <int LI, int HPW, int MB, bool SPLIT = false, int CB = 1>
 __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ Ws, const float* __restrict__ bs,
     const float* __restrict__ wt, float bt, float base_temp, float c0,
@@ -241,45 +257,51 @@ __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
     const int b = blockIdx.y;
     const int n_tiles = (N + TN - 1) / TN, G = gridDim.x;  // tiles dealt round-robin, see the slice kernel
     const int t_begin = blockIdx.x, t_end = n_tiles;
-    // LDS (byte offsets): tile buffers | s_n [2][H][32] | bias [H][M] | m2 [H][M] | Ws images
-    const int buf_bytes = H * 2 * IMG;
-    const int sarr0 = 2 * buf_bytes, sarr_bytes = H * TN * 4;
+    // LDS (byte offsets): tile buffers | s_n [2][H CB][32] | bias [H][M] | m2 [H][M] | Ws images
+    constexpr int C = kC * CB;
+    const int Hv = H * CB;
+    const int buf_bytes = Hv * 2 * IMG;
+    const int sarr0 = 2 * buf_bytes, sarr_bytes = Hv * TN * 4;
     const int biasL = sarr0 + 2 * sarr_bytes;  // [H][M]  bs - c0
     const int m2L = biasL + H * M * 4;         // [H][M]  col_max * log2e
-    const int wimg = m2L + H * M * 4;          // [MB][hi|lo] images of Ws
-    const float* xb = x + (size_t)b * N * H * kC;
-    float* ob = out + (size_t)b * N * H * kC;
+    const int wimg = m2L + H * M * 4;          // [MB][CB][hi|lo] images of Ws
+    const float* xb = x + (size_t)b * N * H * C;
+    float* ob = out + (size_t)b * N * H * C;
+    static_assert(CB == 1 || !SPLIT, "dim_head 64: fp32 input (Ada-Temp in the loader)");
 
     for (int i = threadIdx.x; i < H * M; i += NTHR) {
         *reinterpret_cast<float*>(smem + biasL + 4 * i) = bs[i % M] - c0;
         *reinterpret_cast<float*>(smem + m2L + 4 * i) = col_max[(size_t)b * H * M + i] * kLog2e;
     }
-    Loader<LI, NTHR, SPLIT> ld;
-    ld.init(wt, xb, H, t_begin * TN, SPLIT ? s_in + (size_t)b * N * H : nullptr);
+    Loader<LI, NTHR, SPLIT, false, CB> ld;
+    ld.init(wt, xb, Hv, t_begin * TN, SPLIT ? s_in + (size_t)b * N * H : nullptr);
     ld.tile_stride *= G;
     if (SPLIT) ld.s_stride *= G;
-    stage_ws(wimg, Ws, M);
+    stage_ws<CB>(wimg, Ws, M);
 
-    // per-head constants: the S'/l fragments (A operand: row c = lane&31, k = g in accumulator
+    // per-head constants: the S'/l fragments (A operand: row c = lane&31 of channel block cb, k = g in accumulator
     // order); the Ws fragments (A operand: row g = lane&31, k = c) come from LDS
-    Frag sf[HPW][MB][2];
+    Frag sf[HPW][MB][2][CB];
     const int head0 = wave * HPW;
 #pragma unroll
     for (int hh = 0; hh < HPW; ++hh) {
         const int h = min(head0 + hh, H - 1);
-        const float* s2h = S2 + ((size_t)b * H + h) * M * kC;
+        const float* s2h = S2 + ((size_t)b * H + h) * M * C;
         const float* csh = col_sum + ((size_t)b * H + h) * M;
 #pragma unroll
         for (int gb = 0; gb < MB; ++gb) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int g = 32 * gb + 16 * s + 8 * (j >> 2) + 4 * hf + (j & 3);
-                    v[j] = s2h[g * kC + l31] / csh[g];
+                for (int cb = 0; cb < CB; ++cb) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int g = 32 * gb + 16 * s + 8 * (j >> 2) + 4 * hf + (j & 3);
+                        v[j] = s2h[g * C + 32 * cb + l31] / csh[g];
+                    }
+                    sf[hh][gb][s][cb] = split8(v);
                 }
-                sf[hh][gb][s] = split8(v);
             }
         }
     }
@@ -296,12 +318,17 @@ __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
         for (int hh = 0; hh < HPW; ++hh) {
             const int h = head0 + hh;
             if (h < H) {
-                const int img = cur * buf_bytes + h * (2 * IMG);
-                const float sn = *reinterpret_cast<const float*>(smem + sarr0 + cur * sarr_bytes + 4 * (h * TN + l31));
-                const Frag x0 = read_rows(img, l31, hf), x1 = read_rows(img, l31, 2 + hf);
-                f32x16 O;
+                const int img = cur * buf_bytes + h * CB * (2 * IMG);
+                const float sn = *reinterpret_cast<const float*>(smem + sarr0 + cur * sarr_bytes + 4 * (h * CB * TN + l31));
+                Frag x0[CB], x1[CB];
+                f32x16 O[CB];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) O[r] = 0.f;
+                for (int cb = 0; cb < CB; ++cb) {
+                    x0[cb] = read_rows(img + cb * (2 * IMG), l31, hf);
+                    x1[cb] = read_rows(img + cb * (2 * IMG), l31, 2 + hf);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) O[cb][r] = 0.f;
+                }
 #pragma unroll
                 for (int gb = 0; gb < MB; ++gb) {
                     const int bp = biasL + 4 * (h * M + 32 * gb + 4 * hf);
@@ -315,25 +342,34 @@ __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
 #pragma unroll
                         for (int q = 0; q < 4; ++q) Y[4 * i + q] = b4[q];
                     }
-                    const int wi = wimg + gb * (2 * IMG);
-                    Y = mfma3(read_rows(wi, l31, hf), x0, Y);  // Yt[g,n]: rows g in regs, point on the lane
-                    Y = mfma3(read_rows(wi, l31, 2 + hf), x1, Y);
+                    const int wi = wimg + gb * CB * (2 * IMG);
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) {
+                        Y = mfma3(read_rows(wi + cb * (2 * IMG), l31, hf), x0[cb], Y);  // Yt[g,n]: rows g in regs, point on the lane
+                        Y = mfma3(read_rows(wi + cb * (2 * IMG), l31, 2 + hf), x1[cb], Y);
+                    }
                     float p0[8], p1[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         p0[j] = __builtin_amdgcn_exp2f(fmaf(Y[j], sn, -m4[j >> 2][j & 3]));
                         p1[j] = __builtin_amdgcn_exp2f(fmaf(Y[8 + j], sn, -m4[2 + (j >> 2)][j & 3]));
                     }
-                    O = mfma3(sf[hh][gb][0], split8(p0), O);  // Ot[c,n] += (S'/l)^T P
-                    O = mfma3(sf[hh][gb][1], split8(p1), O);
+                    const Frag pf0 = split8(p0), pf1 = split8(p1);
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) {
+                        O[cb] = mfma3(sf[hh][gb][0][cb], pf0, O[cb]);  // Ot[c,n] += (S'/l)^T P
+                        O[cb] = mfma3(sf[hh][gb][1][cb], pf1, O[cb]);
+                    }
                 }
                 if (l31 < nvalid) {
-                    float* orow = ob + ((size_t)(t * TN + l31) * H + h) * kC + 4 * hf;
+                    float* orow = ob + ((size_t)(t * TN + l31) * H + h) * C + 4 * hf;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const f32x4 v = {O[4 * i], O[4 * i + 1], O[4 * i + 2], O[4 * i + 3]};
-                        *reinterpret_cast<f32x4*>(orow + 8 * i) = v;
-                    }
+                    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 v = {O[cb][4 * i], O[cb][4 * i + 1], O[cb][4 * i + 2], O[cb][4 * i + 3]};
+                            *reinterpret_cast<f32x4*>(orow + 32 * cb + 8 * i) = v;
+                        }
                 }
             }
         }
@@ -345,15 +381,19 @@ __global__ __launch_bounds__(NTHR) void deslice_mfma_kernel(
 
 // ----------------------------------------------------------------------------- host side
 struct MfmaPlan {
-    int li, ipw, mb, hpw, tiles_per_chunk, parts;
+    int li, ipw, mb, hpw, tiles_per_chunk, parts, cb;
     int s_nw, s_li;  // slice pass: waves per workgroup and loader chunks per thread
     size_t lds_slice, lds_deslice;
 };
 
-// shapes the MFMA path covers: C = 32, M in {32, 64, 128}, even H <= 16
+// shapes the MFMA path covers: C = 32, M in {32, 64, 128}, even H <= 16; round 4: C = 64 (two 32-channel blocks per head)
+// where every (head, slice block) item has its own wave and the de-slice's S'/l fragments fit the registers:
+// H * M / 32 <= 8, M <= 64, H in {2, 4, 8} -- BASELINE config C2 (H = 4, M = 32) is inside
 bool mfma_plan(int B, int N, int H, int C, int M, MfmaPlan* p) {
-    if (C != kC || (M != 32 && M != 64 && M != 128)) return false;
-    if (H < 2 || H > 16 || (H & 1)) return false;
+    if ((C != kC && C != 2 * kC) || (M != 32 && M != 64 && M != 128)) return false;
+    const int cbk = C / kC;
+    if (cbk == 2 && !((H == 2 || H == 4 || H == 8) && M <= 64 && H * (M / 32) <= 8)) return false;
+    if (cbk == 1 && (H < 2 || H > 16 || (H & 1))) return false;
     const int mb = M / 32, items = H * mb;
     const int ipw = (items + NW - 1) / NW;
     if (ipw != 1 && ipw != 2 && ipw != 4) return false;
@@ -362,7 +402,8 @@ bool mfma_plan(int B, int N, int H, int C, int M, MfmaPlan* p) {
     const int hpw = (H + NW - 1) / NW;
     if (hpw != 1 && hpw != 2) return false;
     if (p) {
-        p->li = (H + 1) / 2;
+        p->li = (H * cbk + 1) / 2;
+        p->cb = cbk;
         p->ipw = ipw;
         p->mb = mb;
         p->hpw = hpw;
@@ -373,8 +414,8 @@ bool mfma_plan(int B, int N, int H, int C, int M, MfmaPlan* p) {
         if (target < 1) target = 1;
         p->parts = n_tiles < target ? n_tiles : target;
         p->tiles_per_chunk = (n_tiles + p->parts - 1) / p->parts;  // (informational: tiles per workgroup)
-        const size_t bufs = (size_t)2 * H * 2 * IMG + (size_t)2 * H * TN * 4;
-        const size_t wimg = (size_t)mb * 2 * IMG;
+        const size_t bufs = (size_t)2 * H * cbk * 2 * IMG + (size_t)2 * H * cbk * TN * 4;
+        const size_t wimg = (size_t)mb * cbk * 2 * IMG;
         p->s_nw = NW;  // (16 waves with one item each fit 128 VGPRs only with spills and ran 25 % slower)
         p->s_li = p->li;
         p->lds_slice = bufs + p->s_nw * 32 * 4 + wimg;
@@ -449,6 +490,24 @@ static int slice_mfma_launch(const float* x, const float* Ws, const float* bs, c
     if (!mfma_plan(B, N, H, C, M, &p)) return fail(HAET_E_ARG, "slice_mfma: unsupported shape");
     dim3 grid(p.parts, B);
     static const bool shared_load = getenv("HAET_SLICE_SHARED_LOAD") != nullptr;  // A/B: cooperative loader
+    if (p.cb == 2) {  // dim_head 64: fp32 input only, one item per wave
+        if (s_in) return fail(HAET_E_ARG, "slice_mfma: the split operand format needs dim_head 32");
+#define SLICE_CASE64(LI_, MB_)                                                                                  \
+    if (p.s_li == LI_ && p.ipw == 1 && p.mb == MB_) {                                                           \
+        auto kern = slice_mfma_kernel<LI_, 1, MB_, NW, false, false, 2>;                                        \
+        if (int rc = set_lds(kern, p.lds_slice)) return rc;                                                     \
+        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), p.lds_slice, st, x, Ws, bs, wt, bt, base_temp, c0, N, H,  \
+                           p.tiles_per_chunk, parts, s_in, M_rec, g_off);                                      \
+        return check_launch("slice_mfma_kernel<dim_head 64>");                                                  \
+    }
+        SLICE_CASE64(4, 1)  // H = 4, M = 32 (C2)
+        SLICE_CASE64(4, 2)  // H = 4, M = 64
+        SLICE_CASE64(8, 1)  // H = 8, M = 32
+        SLICE_CASE64(2, 1)  // H = 2
+        SLICE_CASE64(2, 2)
+#undef SLICE_CASE64
+        return fail(HAET_E_ARG, "slice_mfma: no dim_head-64 instantiation for H=%d M=%d", H, M);
+    }
     SLICE_CASE(4, 2, 2, 8)   // H=8,  M=64  (C3/C4)
     SLICE_CASE(4, 1, 1, 8)   // H=8,  M=32
     SLICE_CASE(4, 4, 4, 8)   // H=8,  M=128 (C5)
@@ -486,6 +545,24 @@ int deslice_mfma_fwd(const float* x, const float* Ws, const float* bs, const flo
     MfmaPlan p;
     if (!mfma_plan(B, N, H, C, M, &p)) return fail(HAET_E_ARG, "deslice_mfma: unsupported shape");
     dim3 grid(p.parts, B);
+    if (p.cb == 2) {
+        if (s_in) return fail(HAET_E_ARG, "deslice_mfma: the split operand format needs dim_head 32");
+#define DESLICE_CASE64(LI_, MB_)                                                                                     \
+    if (p.li == LI_ && p.mb == MB_) {                                                                                \
+        auto kern = deslice_mfma_kernel<LI_, 1, MB_, false, 2>;                                                      \
+        if (int rc = set_lds(kern, p.lds_deslice)) return rc;                                                        \
+        hipLaunchKernelGGL(kern, grid, dim3(NTHR), p.lds_deslice, st, x, Ws, bs, wt, bt, base_temp, c0, cm, cs, S2,  \
+                           N, H, p.tiles_per_chunk, out, s_in);                                                     \
+        return check_launch("deslice_mfma_kernel<dim_head 64>");                                                     \
+    }
+        DESLICE_CASE64(4, 1)
+        DESLICE_CASE64(4, 2)
+        DESLICE_CASE64(8, 1)
+        DESLICE_CASE64(2, 1)
+        DESLICE_CASE64(2, 2)
+#undef DESLICE_CASE64
+        return fail(HAET_E_ARG, "deslice_mfma: no dim_head-64 instantiation for H=%d M=%d", H, M);
+    }
     DESLICE_CASE(4, 1, 2)
     DESLICE_CASE(4, 1, 1)
     DESLICE_CASE(4, 1, 4)

@@ -78,7 +78,9 @@ __device__ __forceinline__ float dpp(float v) {
 // LI = 16-B chunks per thread per tile (32 rows x H*8 chunks / NT threads): ceil(H/2) at 512 threads.
 // Everything that does not change from tile to tile is computed once in init(): the row / head of
 // each chunk, its LDS offsets, its global pointer (advanced by one tile per fetch).
-template <int LI, int NT = NTHR, bool SPLIT = false, bool PRIV = false>
+// CB = dim_head / 32 (round 4: dim_head 64 = two 32-channel "virtual heads" per head; H below is then the number of
+// VIRTUAL heads, H_real * CB, and Ada-Temp -- a dot over all 64 channels -- sums the two 8-lane groups of a 16-lane row).
+template <int LI, int NT = NTHR, bool SPLIT = false, bool PRIV = false, int CB = 1>
 struct Loader {
     f32x4 xr[LI];
     float wt4[4];
@@ -130,8 +132,10 @@ struct Loader {
         }
         const int cpr = H * 8;  // chunks per row
         tile_stride = (size_t)TN * cpr * 4;
+        // (cpr divides NT: a thread's chunks all sit in the same column q of their rows, i.e. in the same virtual head)
+        const int vh0 = ((int)threadIdx.x % cpr) >> 3;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wt4[i] = SPLIT ? 0.f : wt[4 * q8 + i];
+        for (int i = 0; i < 4; ++i) wt4[i] = SPLIT ? 0.f : wt[32 * (vh0 % CB) + 4 * q8 + i];
 #pragma unroll
         for (int i = 0; i < LI; ++i) {
             const int e = threadIdx.x + NT * i;
@@ -184,6 +188,7 @@ struct Loader {
                 t += dpp<0xB1>(t);   // quad_perm [1,0,3,2]
                 t += dpp<0x4E>(t);   // quad_perm [2,3,0,1]
                 t += dpp<0x141>(t);  // row_half_mirror: the other quad of the 8-lane group
+                if (CB == 2) t += dpp<0x128>(t);  // row_ror:8: the head's other 32 channels (the neighbouring virtual head)
                 unsigned h01, l01, h23, l23;
                 split_bf16_pair(v[0], v[1], h01, l01);
                 split_bf16_pair(v[2], v[3], h23, l23);
@@ -230,16 +235,17 @@ __device__ __forceinline__ Frag read_cols(int img, int s, int lane) {
     return f;
 }
 
-// Ws as MB swizzled [32][32] split-bf16 image pairs in LDS (same for every head): both passes
-// re-read their Ws fragments per tile instead of pinning 16 VGPRs per column block.
+// Ws as MB x CB swizzled [32][32] split-bf16 image pairs in LDS (same for every head; image (gb, cb) = slice columns
+// 32 gb .., channels 32 cb ..): both passes re-read their Ws fragments per tile instead of pinning 16 VGPRs per column block.
+template <int CB = 1>
 __device__ __forceinline__ void stage_ws(int wimg, const float* __restrict__ Ws, int M) {
-    for (int e = threadIdx.x; e < M * 4; e += blockDim.x) {
-        const int g = e >> 2, chunk = e & 3;
+    for (int e = threadIdx.x; e < M * 4 * CB; e += blockDim.x) {
+        const int g = e / (4 * CB), rest = e - g * (4 * CB), cb = rest >> 2, chunk = rest & 3;
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = Ws[g * kC + 8 * chunk + j];
+        for (int j = 0; j < 8; ++j) v[j] = Ws[g * (kC * CB) + 32 * cb + 8 * chunk + j];
         const Frag f = split8(v);
-        const int off = wimg + (g >> 5) * (2 * IMG) + img_off(g & 31, chunk);
+        const int off = wimg + ((g >> 5) * CB + cb) * (2 * IMG) + img_off(g & 31, chunk);
         *reinterpret_cast<u32x4*>(smem + off) = f.hi;
         *reinterpret_cast<u32x4*>(smem + off + IMG) = f.lo;
     }

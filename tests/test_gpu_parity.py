@@ -40,7 +40,8 @@ def _slice_params(sd, cfg, dev):
 
 @pytest.fixture(params=["auto", "valu", "f32"])
 def kernel_path(request):
-    """'auto' = the fastest kernels the shape allows (split-bf16 MFMA at C = 32, f32 MFMA at C = 64),
+    """'auto' = the fastest kernels the shape allows (split-bf16 MFMA at C = 32 and, round 4, at C = 64 with H * M / 32 <= 8;
+    f32 MFMA at the other C = 64 shapes),
     'valu' = generic fp32 vector-ALU kernels everywhere, 'f32' = the f32-MFMA kernels wherever they apply."""
     import os
 
@@ -433,10 +434,11 @@ def test_full_size_properties_1m_points(hip_device, kernel_path):
 
 @pytest.mark.parametrize("N", [1, 31, 33, 1057])
 @pytest.mark.parametrize("H,M,C", [(4, 64, 32), (8, 32, 32), (2, 128, 32), (8, 128, 32), (16, 32, 32), (16, 64, 32),
-                                   (4, 128, 32), (2, 32, 32), (4, 32, 64), (2, 64, 64), (3, 128, 64)])
+                                   (4, 128, 32), (2, 32, 32), (4, 32, 64), (2, 64, 64), (3, 128, 64), (8, 32, 64), (4, 64, 64),
+                                   (2, 32, 64)])
 def test_ragged_point_counts_mfma_shapes(N, H, M, C, hip_device, kernel_path):
-    """Shapes the MFMA kernels take (C = 32: split-bf16 or f32; C = 64: f32), partial last tile, B = 2,
-    chunk boundaries."""
+    """Shapes the MFMA kernels take (C = 32: split-bf16 or f32; C = 64: split-bf16 -- round 4, H * M / 32 <= 8 -- or f32),
+    partial last tile, B = 2, chunk boundaries."""
     from haet_amd import ops
 
     if kernel_path == "valu":
