@@ -268,8 +268,8 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
             fn.restype, fn.argtypes = res, args
-        if lib.haet_abi_version() != 6:
-            raise HaetError(f"libhaet_hip.so ABI {lib.haet_abi_version()} != 6")
+        if lib.haet_abi_version() != 7:
+            raise HaetError(f"libhaet_hip.so ABI {lib.haet_abi_version()} != 7")
         _lib = lib
     return _lib
 

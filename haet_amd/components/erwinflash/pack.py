@@ -5,7 +5,8 @@ Blob = [ copy of the descriptor | tensors ], offsets in floats from the blob sta
 * Linear weights: PyTorch [out][in] layout, rows zero-padded to Kp = roundup(in, 32), stored
   pre-split as two bf16 planes -- hi = RNE(w) at the offset, lo = RNE(w - hi) O*Kp bf16 later --
   so the kernel feeds them to the MFMA without conversion (3 products hi*hi + hi*lo + lo*hi
-  give fp32-class accuracy).
+  give fp32-class accuracy); behind the two planes (2*O*Kp bf16 from the offset) a tile-ordered copy of both
+  (roundup(O, 16)*Kp*2 bf16: `_Blob.planes`), which is what erwin.hip's Linear loads.
 * pe_proj (2/3 inputs) stays fp32, transposed [d][c]; biases / norm weights fp32.
 * eval-mode BatchNorm1d is folded to y*scale + shift (scale = gamma / sqrt(running_var + eps),
   shift = beta - running_mean * scale; models/components/erwinflash/components/pooling.py:23,38,56,68);
@@ -42,14 +43,24 @@ class _Blob:
         return off
 
     def planes(self, linear):
-        """[out][in~32] bf16 hi plane followed by the lo plane (see module docstring)."""
+        """[out][in~32] bf16 hi plane followed by the lo plane (see module docstring), followed by the TILE-ORDERED copy
+        erwin.hip's Linear streams (round 4): per (16-row tile ot, 32-wide k-step ks, plane) one 1-KB piece in which lane
+        l = 16 kq + r of a wave holds W[16 ot + r][32 ks + 8 kq .. + 8] -- a wave-wide 16-B load is then 1 KB of consecutive
+        bytes instead of 16 rows x 64 B (which the vector cache serves lane by lane: ~11 B/cycle per CU, stamped at config C2).
+        Rows past `out` are zero."""
         w = linear.weight.detach().float()
         pad = (-w.shape[1]) % 32
         if pad:
             w = torch.nn.functional.pad(w, (0, pad))
         hi = w.to(torch.bfloat16)
         lo = (w - hi.float()).to(torch.bfloat16)
-        planes = torch.cat([hi.reshape(-1), lo.reshape(-1)]).contiguous()
+        O, Kp = w.shape
+        nto, nks = (O + 15) // 16, Kp // 32
+        both = torch.stack([hi, lo])                                            # [plane][O][Kp]
+        if nto * 16 != O:
+            both = torch.nn.functional.pad(both, (0, 0, 0, nto * 16 - O))
+        tiled = both.reshape(2, nto, 16, nks, 4, 8).permute(1, 3, 0, 4, 2, 5)    # [ot][ks][plane][kq][r][8]
+        planes = torch.cat([hi.reshape(-1), lo.reshape(-1), tiled.reshape(-1)]).contiguous()
         return self.add(planes.view(torch.float32))
 
     def end_group(self, start):

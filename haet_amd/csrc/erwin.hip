@@ -169,15 +169,18 @@ __device__ __forceinline__ WPre linear_prefetch(int K, const unsigned short* __r
     const size_t plane = (size_t)O * Kp;
     int ot = wave % nto, ks = 0;  // item 0 of this wave (the token tile does not enter the address)
     WPre p;
+    // the tile-ordered copy behind the two row-major planes (pack.py, _Blob.planes): piece (ot, ks, plane) = 1 KB, lane * 16 B
+    const unsigned short* Ta = Wa + 2 * plane + lane * 8;
+    const unsigned short* Tb = DUAL ? Wb + 2 * plane + lane * 8 : Ta;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const size_t off = (size_t)min(ot * 16 + l15, O - 1) * Kp + 32 * ks + 8 * kq;
+        const size_t off = (size_t)(ot * nks + ks) * 1024;
         u32x4(&wv)[4] = i ? p.b : p.a;
-        wv[0] = *(gv4)(Wa + off);
-        wv[1] = *(gv4)(Wa + plane + off);
+        wv[0] = *(gv4)(Ta + off);
+        wv[1] = *(gv4)(Ta + off + 512);
         if (DUAL) {
-            wv[2] = *(gv4)(Wb + off);
-            wv[3] = *(gv4)(Wb + plane + off);
+            wv[2] = *(gv4)(Tb + off);
+            wv[3] = *(gv4)(Tb + off + 512);
         }
         if (++ks == nks) {  // same walk as Cur::advance in linear_core_t
             ks = 0;
@@ -247,13 +250,19 @@ __device__ ERWIN_PHASE void linear_core_t(
     };
     u32x4 w0[4], w1[4];
     typedef const __attribute__((address_space(1))) u32x4* gv4;  // explicit global loads (not flat)
+    // Weights come from the TILE-ORDERED copy behind the two row-major planes (pack.py, _Blob.planes; round 4): piece
+    // (ot, ks, plane) = 1 KB, this lane's 16 B at lane * 16 -- one wave load = 1 KB of consecutive bytes.  From the row-major
+    // planes the same fragment was 16 rows x 64 B with NEIGHBOURING lanes in different rows, which the vector cache serves
+    // lane by lane: ~2.8k cycles per item, 11 B/cycle per CU, whatever the prefetch depth (stamps at config C2).
+    const unsigned short* Ta = Wa + 2 * plane + lane * 8;
+    const unsigned short* Tb = dual ? Wb + 2 * plane + lane * 8 : Ta;
     auto fetch = [&](const Cur& c, u32x4 (&wv)[4]) {
-        const size_t off = (size_t)min(c.ot * 16 + l15, O - 1) * Kp + 32 * c.ks + 8 * kq;
-        wv[0] = *(gv4)(Wa + off);
-        wv[1] = *(gv4)(Wa + plane + off);
+        const size_t off = (size_t)(c.ot * nks + c.ks) * 1024;  // bf16 elements: two 1-KB pieces per (ot, ks)
+        wv[0] = *(gv4)(Ta + off);
+        wv[1] = *(gv4)(Ta + off + 512);
         if (dual) {
-            wv[2] = *(gv4)(Wb + off);
-            wv[3] = *(gv4)(Wb + plane + off);
+            wv[2] = *(gv4)(Tb + off);
+            wv[3] = *(gv4)(Tb + off + 512);
         }
     };
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -334,7 +343,10 @@ __device__ ERWIN_PHASE void linear_core_t(
             acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    // The fetch cursor runs two items ahead of the compute cursor.  Fetches are UNCONDITIONAL
+    // The fetch cursor runs two items ahead of the compute cursor.  (Round 4, measured at BASELINE config C2 with stamps: a ring
+    // of four items made every Linear SLOWER -- level-0 block 60k -> 80k cycles, the first item's wait 1.35k -> 4.3k: the
+    // weight stream is throughput-bound at ~11 B/cycle per CU, the rate of one CU reading BEYOND its XCD's L2, not
+    // latency-bound; what helps is the clouds' workgroups sharing one L2: xcd_pack below.)  Fetches are UNCONDITIONAL
     // (addresses clamped) and the loop runs whole 2-step rounds (a ghost step past the end multiplies
     // garbage into an accumulator that is never written): with a conditional load between a fetch and
     // its use, hipcc's waitcnt pass cannot count the younger loads in flight and waits vmcnt(0),
@@ -565,10 +577,14 @@ __device__ ERWIN_PHASE void ball_attention_mfma(int qkv, int ldq, int n, int c, 
     qkv = U(qkv), ldq = U(ldq), n = U(n), c = U(c), heads = U(heads), ball = U(ball), perm = U(perm);
     const int lane = threadIdx.x & 63, wave = U(threadIdx.x >> 6), hf = lane >> 5, l31 = lane & 31;
     const float qscale = 1.4426950408889634f / sqrtf((float)HD);  // softmax in base 2
-    const int items = (n >> 5) * heads, bmask = 31 & ~(ball - 1);  // ball: a power of two <= 32
+    // (round 4: n need not be a multiple of 32 -- the 16-token coarse level of M = 32 clouds, BASELINE config C2 and the
+    // reference's velocity-mem-checker shape, ran on the generic vector-ALU attention: 46.7k cycles per block against 9.2k
+    // here: the lanes past the end mirror the last token, take no part as keys and store nothing)
+    const int items = ((n + 31) >> 5) * heads, bmask = 31 & ~(ball - 1);  // ball: a power of two <= 32
     for (int item = wave; item < items; item += kErwinThreads / 64) {
         const int tile = item / heads, h = item - tile * heads;
-        const int t = I(perm + 4 * (tile * 32 + l31));  // my token: key row of St, query column of St
+        const int nv = n - tile * 32;  // valid tokens of this tile (>= 32 except on a partial last tile)
+        const int t = I(perm + 4 * min(tile * 32 + l31, n - 1));  // my token: key row of St, query column of St
         const int row = qkv + 4 * (t * ldq + h * HD);
         f32x16 S;
 #pragma unroll
@@ -599,7 +615,7 @@ __device__ ERWIN_PHASE void ball_attention_mfma(int qkv, int ldq, int n, int c, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = (r & 3) + 8 * (r >> 2) + 4 * hf;
-            if ((key ^ l31) & bmask) S[r] = -INFINITY;  // another ball of the same tile
+            if (((key ^ l31) & bmask) || key >= nv) S[r] = -INFINITY;  // another ball of the same tile / past the end
             m = fmaxf(m, S[r]);
         }
         m = fmaxf(m, __shfl_xor(m, 32));
@@ -631,14 +647,16 @@ __device__ ERWIN_PHASE void ball_attention_mfma(int qkv, int ldq, int n, int c, 
         }
         // lane (q, hf) holds O[q][d] for d = (r & 3) + 8 (r >> 2) + 4 hf, r < HD / 2 (rows d >= HD are zero)
         const float inv = 1.0f / l;
+        if (l31 < nv) {
 #pragma unroll
-        for (int r = 0; r < HD / 2; ++r) out.put(t, h * HD + (r & 3) + 8 * (r >> 2) + 4 * hf, O[r] * inv);
+            for (int r = 0; r < HD / 2; ++r) out.put(t, h * HD + (r & 3) + 8 * (r >> 2) + 4 * hf, O[r] * inv);
+        }
     }
 }
 
 __device__ ERWIN_PHASE void attention_dispatch(int hd, int qkv, int ldq, int n, int c,
                                                              int heads, int ball, int perm, const Img out) {
-    if (n % 32 == 0 && ball <= 32 && (ball & (ball - 1)) == 0) {
+    if (ball <= 32 && (ball & (ball - 1)) == 0 && n % ball == 0) {
         if (hd == 8) return ball_attention_mfma<8>(qkv, ldq, n, c, heads, ball, perm, out);
         if (hd == 16) return ball_attention_mfma<16>(qkv, ldq, n, c, heads, ball, perm, out);
         if (hd == 32) return ball_attention_mfma<32>(qkv, ldq, n, c, heads, ball, perm, out);
@@ -1013,10 +1031,14 @@ __global__ __launch_bounds__(512) void erwin_kernel(
     int32_t* __restrict__ tree_idx, uint8_t* __restrict__ tree_mask,
     int32_t* __restrict__ rot, const float* __restrict__ W, int M, int Mp,
     float* __restrict__ out, ErwinDir dir, ErwinTrain tr, WTreeCfg tcfg, float* __restrict__ pos_out,
-    unsigned blob_pieces) {
+    unsigned blob_pieces, int xcd_pack) {
+    // xcd_pack = the number of clouds (else 0): the grid is 8x as large and only every eighth workgroup works, so that all
+    // clouds run on ONE XCD (workgroups are dealt round-robin over the 8 XCDs: a speed assumption only) and share its L2 --
+    // every cloud streams the same weight blob, and a CU reads beyond its L2 at a third of the rate it reads from it
+    if (xcd_pack && (blockIdx.x & 7)) return;
     STAMP(0);
     const haet_erwin_desc& D = *reinterpret_cast<const haet_erwin_desc*>(W);
-    const int cloud = blockIdx.x, n_clouds = gridDim.x, d = D.d, nl = D.n_levels;
+    const int cloud = xcd_pack ? blockIdx.x >> 3 : blockIdx.x, n_clouds = xcd_pack ? xcd_pack : gridDim.x, d = D.d, nl = D.n_levels;
     // LDS directory: computed on the host (one thread walking the layout cost ~9k cycles per launch)
     if (threadIdx.x < T_WORDS) I(4 * threadIdx.x) = dir.t[threadIdx.x];
     __syncthreads();
@@ -1258,8 +1280,12 @@ static int erwin_launch(const float* tokens, const float* pos, int32_t* tree_idx
     if (int rc = erwin_train_args(desc, train, n_clouds, stream, &tr)) return rc;
     ErwinDir dir;
     erwin_directory(*desc, Mp, &dir);
-    hipLaunchKernelGGL(erwin_kernel<FUSED>, dim3(n_clouds), dim3(kErwinThreads), bytes, stream, tokens, pos, tree_idx,
-                       tree_mask, rot, weights, M, Mp, out, dir, tr, tcfg, pos_out, (unsigned)(weight_floats / 4));
+    // eval mode, few clouds (one per CU of an XCD at most): pack them onto one XCD; HAET_ERWIN_XCD_PACK=0 switches it off (A/B)
+    const char* pe = getenv("HAET_ERWIN_XCD_PACK");
+    const bool pack = !tr.on && !tr.tape && n_clouds <= 32 && !(pe && pe[0] == '0');
+    hipLaunchKernelGGL(erwin_kernel<FUSED>, dim3(pack ? 8 * n_clouds : n_clouds), dim3(kErwinThreads), bytes, stream, tokens, pos,
+                       tree_idx, tree_mask, rot, weights, M, Mp, out, dir, tr, tcfg, pos_out, (unsigned)(weight_floats / 4),
+                       pack ? n_clouds : 0);
     return check_launch(FUSED ? "erwin_kernel<fused token stage>" : "erwin_kernel");
 }
 

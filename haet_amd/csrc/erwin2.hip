@@ -580,18 +580,22 @@ __global__ __launch_bounds__(kThreads) void erwin2_kernel(const float* __restric
                                                          uint8_t* __restrict__ tree_mask, int32_t* __restrict__ rot,
                                                          const float* __restrict__ W, const char* __restrict__ FR,
                                                          float* __restrict__ out, WTreeCfg tcfg, float* __restrict__ pos_out,
-                                                         Head PL, int warm) {
+                                                         Head PL, int warm, int xcd_pack) {
+    // xcd_pack = the number of clouds (else 0): an 8x grid of which every eighth workgroup works -- all clouds on ONE XCD,
+    // sharing its L2 for the fragment blob they all stream (erwin.hip, erwin_kernel)
+    if (xcd_pack && (blockIdx.x & 7)) return;
+    const int cloud_ = xcd_pack ? blockIdx.x >> 3 : blockIdx.x, n_clouds_ = xcd_pack ? xcd_pack : gridDim.x;
     STAMP2(0);
     // The directory and the op table are read from the blob's own copy of the Plan: refuse a blob that was packed for
     // another descriptor or M (uniform exit before any barrier; the output goes out as NaN so that the caller SEES it --
     // with foreign offsets the kernel would address LDS and weights out of bounds instead)
     if (*reinterpret_cast<const unsigned*>(FR + offsetof(Plan, h) + offsetof(Head, stamp)) != PL.stamp) {
-        for (int i = threadIdx.x; i < PL.M * PL.c0; i += kThreads) out[(size_t)blockIdx.x * PL.M * PL.c0 + i] = __int_as_float(0x7fc00000);
+        for (int i = threadIdx.x; i < PL.M * PL.c0; i += kThreads) out[(size_t)cloud_ * PL.M * PL.c0 + i] = __int_as_float(0x7fc00000);
         return;
     }
     const int dirf_all = reinterpret_cast<const int*>(FR + offsetof(Plan, h) + offsetof(Head, dir))[min((int)(threadIdx.x & 63), (int)(sizeof(Dir) / 4) - 1)];
     const int dirf = dirf_all;
-    const int cloud = blockIdx.x, n_clouds = gridDim.x, d = PL.d, nl = PL.n_levels, M = PL.M, c0 = PL.c0;
+    const int cloud = cloud_, n_clouds = n_clouds_, d = PL.d, nl = PL.n_levels, M = PL.M, c0 = PL.c0;
     for (int i = threadIdx.x; i < PL.n_ops * kOpInts; i += kThreads)  // the op table (visible after the builder's barriers)
         I(DF(ops) + 4 * i) = reinterpret_cast<const int*>(FR + offsetof(Plan, ops))[i];
     {
@@ -1024,7 +1028,10 @@ extern "C" int haet_token_stage_fwd_frag(const float* S, int n_clouds, int M, fl
         if (e != hipSuccess) return fail(HAET_E_LAUNCH, "token_stage_frag: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_dev.store(bytes, std::memory_order_release);
     }
-    hipLaunchKernelGGL(e2::erwin2_kernel, dim3(n_clouds), dim3(e2::kThreads), bytes, as_stream(stream), S, tree_idx, tree_mask,
-                       rot, weights, reinterpret_cast<const char*>(frags), out, cfg, pos_out, P.h, warm);
+    const char* pe = getenv("HAET_ERWIN_XCD_PACK");  // A/B switch ("0": one workgroup per cloud on consecutive XCDs, as before round 4)
+    const bool pack = n_clouds <= 32 && !(pe && pe[0] == '0');
+    hipLaunchKernelGGL(e2::erwin2_kernel, dim3(pack ? 8 * n_clouds : n_clouds), dim3(e2::kThreads), bytes, as_stream(stream), S,
+                       tree_idx, tree_mask, rot, weights, reinterpret_cast<const char*>(frags), out, cfg, pos_out, P.h, warm,
+                       pack ? n_clouds : 0);
     return check_launch("erwin2_kernel");
 }

@@ -34,9 +34,10 @@
 extern "C" {
 #endif
 
-#define HAET_ABI_VERSION 6  /* 2: + haet_tokens_tree_build, haet_project_split_fwd, haet_*_fwd_split; 4: train-mode
+#define HAET_ABI_VERSION 7  /* 2: + haet_tokens_tree_build, haet_project_split_fwd, haet_*_fwd_split; 4: train-mode
                              BatchNorm (haet_erwin_train), haet_token_stage_fwd; 6: haet_token_stage_fwd_frag (the
-                             fragment kernel), haet_erwin_barrier_status, haet_set_deterministic */
+                             fragment kernel), haet_erwin_barrier_status, haet_set_deterministic; 7: tile-ordered weight copies in the
+                             Erwin blob, haet_conv_presplit / haet_conv_project_cells_*, haet_conv_project_det_fwd */
 
 #define HAET_OK 0
 #define HAET_E_ARG (-1)      /* bad argument / unsupported shape */
@@ -171,7 +172,12 @@ typedef struct {
     /* offsets (in floats) from the start of the blob.  Linear weights keep PyTorch's [out][in]
      * layout, rows zero-padded to in~ = roundup(in, 32), pre-split into two bf16 planes: hi =
      * RNE(w) at the offset, lo = RNE(w - hi) out*in~ bf16 later (one lane of the MFMA B operand
-     * reads 8 consecutive k of one output row).  pe_w is fp32, transposed [d][c].              */
+     * reads 8 consecutive k of one output row) -- what haet_erwin_frag_pack and the fragment kernel's
+     * resampling read -- FOLLOWED (2*out*in~ bf16 from the offset) by a tile-ordered copy of both planes,
+     * which is what haet_erwin_fwd / haet_token_stage_fwd stream (ABI 7): for every (16-row tile ot,
+     * 32-wide k-step ks, plane) one 1-KB piece, order [ot][ks][plane], in which the 16 bytes at 16*(16*kq + r)
+     * are W[16 ot + r][32 ks + 8 kq .. + 8]; rows past `out` are zero: roundup(out,16)*in~*2 bf16.
+     * pe_w is fp32, transposed [d][c].                                                          */
     int32_t norm1, norm2;            /* [c] */
     int32_t pe_w, pe_b;              /* [d][c], [c] */
     int32_t qkv_w, qkv_b;            /* [3c][c~], [3c] */

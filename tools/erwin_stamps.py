@@ -15,7 +15,9 @@ from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-mod = Physics_Attention_Irregular_Mesh(256, heads=8, dim_head=32, slice_num=64, rotate=45).eval().to(dev)
+# shape: STAMP_SHAPE="heads,dim_head,slice_num" (default: config C3; C2 = "4,64,32")
+_h, _c, _m = (int(v) for v in os.environ.get("STAMP_SHAPE", "8,32,64").split(","))
+mod = Physics_Attention_Irregular_Mesh(256, heads=_h, dim_head=_c, slice_num=_m, rotate=45).eval().to(dev)
 x = torch.randn(1, 200_000, 256, device=dev)
 big = torch.empty(256 * 1024 * 1024, device=dev)  # flush caches between forwards like the 1M-point run
 with torch.no_grad():
