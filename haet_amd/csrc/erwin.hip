@@ -345,8 +345,10 @@ __device__ ERWIN_PHASE void linear_core_t(
     };
     // The fetch cursor runs two items ahead of the compute cursor.  (Round 4, measured at BASELINE config C2 with stamps: a ring
     // of four items made every Linear SLOWER -- level-0 block 60k -> 80k cycles, the first item's wait 1.35k -> 4.3k: the
-    // weight stream is throughput-bound at ~11 B/cycle per CU, the rate of one CU reading BEYOND its XCD's L2, not
-    // latency-bound; what helps is the clouds' workgroups sharing one L2: xcd_pack below.)  Fetches are UNCONDITIONAL
+    // weight stream was throughput-bound at ~11 B/cycle per CU, not
+    // latency-bound.  The cause was the ACCESS SHAPE, not the depth: see `fetch` above.  With the tile-ordered copy a ring of
+    // three or four items was measured again: C2 token stage 0.177 / 0.178 / 0.188 ms for 2 / 3 / 4 -- two it stays.)
+    // Fetches are UNCONDITIONAL
     // (addresses clamped) and the loop runs whole 2-step rounds (a ghost step past the end multiplies
     // garbage into an accumulator that is never written): with a conditional load between a fetch and
     // its use, hipcc's waitcnt pass cannot count the younger loads in flight and waits vmcnt(0),
