@@ -20,7 +20,8 @@
 // traffic and was the largest part of a phase), and a second barrier: 4 per block against ~10 in erwin.hip, with none
 // of its ~50 LDS round trips per block.
 //
-// Envelope (haet_erwin_frag_bytes != 0): eval-mode BatchNorm, head dim 8, channels 32 or 64, 32 | tokens per level,
+// Envelope (haet_erwin_frag_bytes != 0): eval-mode BatchNorm, head dim 8, channels 32 or 64, 32 | tokens per level (round 4: a
+// 16-token level below level 0 runs as one tile padded with phantom tokens: M = 32, the velocity-mem-checker shape),
 // (tokens / 32) * heads <= 8 and (tokens / 32) * hidden / 32 <= 8 (every item of a phase on its own wave), power-of-two
 // balls <= 32, stride 2, power-of-two clouds <= 64 tokens (the wave tree builder).  BASELINE config C3 (M = 64: 64 x 32
 // and 32 x 64 tokens x channels) is inside; everything else, training (tape, batch statistics) included, stays on
@@ -83,8 +84,10 @@ struct Op {
 constexpr int kOpInts = sizeof(Op) / 4;
 static_assert(kOpInts <= 64, "an Op is fetched from LDS with one dword per lane");
 
-struct Dir {  // LDS byte offsets
-    int X[HAET_ERWIN_MAX_LEVELS], ld[HAET_ERWIN_MAX_LEVELS], n[HAET_ERWIN_MAX_LEVELS], P[HAET_ERWIN_MAX_LEVELS];
+struct Dir {  // LDS byte offsets; n = tokens of the level PADDED to whole 32-token tiles, nr = the real count (round 4: the
+              // 16-token coarse level of M = 32 clouds -- the reference's velocity-mem-checker shape -- runs as one tile
+              // whose places 16..31 are phantom tokens: finite, a ball of their own, never read back)
+    int X[HAET_ERWIN_MAX_LEVELS], ld[HAET_ERWIN_MAX_LEVELS], n[HAET_ERWIN_MAX_LEVELS], nr[HAET_ERWIN_MAX_LEVELS], P[HAET_ERWIN_MAX_LEVELS];
     int rel[HAET_ERWIN_MAX_LEVELS][2], rotm[HAET_ERWIN_MAX_LEVELS];
     int ident, tmap, par[2], slab, ops, total;
 };
@@ -470,7 +473,7 @@ __device__ __forceinline__ void resample(const int tid, const int opf, const int
     const int lane = tid & 63, p = lane & 31, hf = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l = OF(lvl), st = OF(stride), c = OF(c), c2 = OF(c2);
-    const int n2 = DFI(n, l + 1);
+    const int n2 = DFI(n, l + 1), nr2 = DFI(nr, l + 1);  // (padded / real coarse tokens)
     const int K = UNPOOL ? c2 + st * d : st * c + st * d, Kp = round32(K), Oc = UNPOOL ? st * c : c2;
     const int X0 = DFI(X, l), ld0 = DFI(ld, l), X1 = DFI(X, l + 1), ld1 = DFI(ld, l + 1), P0 = DFI(P, l), P1 = DFI(P, l + 1);
     const int otiles = Oc >> 5, nitems = (n2 >> 5) * otiles;
@@ -483,7 +486,8 @@ __device__ __forceinline__ void resample(const int tid, const int opf, const int
     const int feat = UNPOOL ? c2 : st * c, kf = feat >> 4;
     for (int item = wave; item < nitems; item += kThreads / 64) {
         const int Tt = item / otiles, ot = item - Tt * otiles;
-        const int pt = 32 * Tt + p;  // coarse token of this lane
+        const int pt_place = 32 * Tt + p;              // coarse token of this lane; a phantom one (>= nr2) mirrors the last real
+        const int pt = min(pt_place, nr2 - 1);         // token: pooling gives it that token's (finite) value, unpooling stores nothing
         const unsigned short* wrow = Wh + (size_t)(32 * ot + p) * Kp + 8 * hf;
         u32x4 ah[KF], al[KF];
 #pragma unroll
@@ -548,12 +552,12 @@ __device__ __forceinline__ void resample(const int tid, const int opf, const int
                 f32x4 yv;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) yv[i] = (old[i] + acc[4 * q + i] + b[i]) * sc[i] + sh[i];
-                F4(dst) = yv;
+                if (pt_place < nr2) F4(dst) = yv;
             } else {
                 f32x4 yv;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) yv[i] = (acc[4 * q + i] + b[i]) * sc[i] + sh[i];
-                F4(X1 + 4 * (pt * ld1 + o4)) = yv;
+                F4(X1 + 4 * (pt_place * ld1 + o4)) = yv;
             }
         }
     }
@@ -650,13 +654,16 @@ __global__ __launch_bounds__(kThreads) void erwin2_kernel(const float* __restric
     parv = *(gf4)(W + first_off + min((int)threadIdx.x * 4, first_len - 4));
     for (int i = threadIdx.x; i < M; i += kThreads) I(DF(ident) + 4 * i) = i;
     for (int l = 0; l + 1 < nl; ++l) {  // pooled positions (pooling.py:29-33): mean of the children, sequential sum
-        const int st = PL.stride[l], n2 = DFI(n, l + 1);
+        const int st = PL.stride[l], n2 = DFI(n, l + 1), nr2 = DFI(nr, l + 1);
         for (int i = threadIdx.x; i < n2 * d; i += kThreads) {
             const int pt = i / d, j = i - pt * d;
             float sum = 0.f;
-            for (int q = 0; q < st; ++q) sum += F(DFI(P, l) + 4 * ((pt * st + q) * d + j));
-            F(DFI(P, l + 1) + 4 * i) = sum / (float)st;
+            if (pt < nr2)
+                for (int q = 0; q < st; ++q) sum += F(DFI(P, l) + 4 * ((pt * st + q) * d + j));
+            F(DFI(P, l + 1) + 4 * i) = sum / (float)st;  // (phantom places of a padded level: 0)
         }
+        if (PL.rotate)  // the builder wrote the rotated partition of the REAL tokens; phantom places keep themselves
+            for (int i = nr2 + (int)threadIdx.x; i < n2; i += kThreads) I(DFI(rotm, l + 1) + 4 * i) = i;
         lds_barrier();
     }
     if (nl == 1) lds_barrier();  // (the identity map)
@@ -808,9 +815,11 @@ static bool make_plan(const haet_erwin_desc& D, int M, Plan* out) {
     if (nl < 1 || nl > HAET_ERWIN_MAX_LEVELS || !D.decode || D.bn_train || (D.d != 2 && D.d != 3)) return false;
     if (M < 32 || M > 64 || (M & (M - 1))) return false;
     P.n_levels = nl, P.d = D.d, P.M = M, P.c0 = D.enc[0].c, P.rotate = D.rotate ? 1 : 0;
-    int n = M, nlv[HAET_ERWIN_MAX_LEVELS];
+    int n = M, nlv[HAET_ERWIN_MAX_LEVELS], nreal[HAET_ERWIN_MAX_LEVELS];
     for (int l = 0; l < nl; ++l) {
-        nlv[l] = n;
+        nreal[l] = n;
+        nlv[l] = (n + 31) & ~31;  // whole tiles: a 16-token level (below level 0) is padded with phantom tokens
+        if (n % 32 && (l == 0 || n != 16)) return false;
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && l == nl - 1) break;
             const haet_erwin_layer& L = pass ? D.dec[l] : D.enc[l];
@@ -821,7 +830,7 @@ static bool make_plan(const haet_erwin_desc& D, int M, Plan* out) {
             if (L.ball < 2 || L.ball > 32 || (L.ball & (L.ball - 1)) || n % L.ball) return false;
             if (pass && L.ball != D.enc[l].ball) return false;
             if (L.hidden < 32 || L.hidden % 32) return false;
-            if (n % 32 || (n / 32) * L.heads > 8 || (n / 32) * (L.hidden / 32) > 8) return false;
+            if ((nlv[l] / 32) * L.heads > 8 || (nlv[l] / 32) * (L.hidden / 32) > 8) return false;
         }
         P.ball[l] = D.enc[l].ball;
         if (l < nl - 1) {
@@ -915,6 +924,7 @@ static bool make_plan(const haet_erwin_desc& D, int M, Plan* out) {
     };
     for (int l = 0; l < nl; ++l) {
         T.n[l] = nlv[l];
+        T.nr[l] = nreal[l];
         T.ld[l] = D.enc[l].c + kPad;
         T.X[l] = take(4 * nlv[l] * T.ld[l]);
         const int s = 8 * (D.enc[l].c / 32) * 4096;

@@ -224,6 +224,11 @@ ATTN_CASES = [
                                                 c_hidden=[16, 16], ball_sizes=[16, 8]), 450, "amp", True),
     ("irr_b2_amp_train", "irregular", dict(dim=64, heads=4, dim_head=16, slice_num=16, rotate=45), 350, "amp", True),
     ("irr_c3like_amp_train", "irregular", dict(dim=256, heads=8, dim_head=32, slice_num=64, rotate=45), 900, "amp", True),
+    # round 4 -- the reference's own velocity-mem-checker shape (benchmarks/00-VelocityMemMocker/velocity-mem-checker.py:34-44:
+    # n_hidden 256, n_head 8, slice_num 32): 32-token clouds whose coarse level has 16 tokens per cloud (the fragment kernel's
+    # padded tile, the MFMA ball attention on a partial tile)
+    ("irr_memchk_amp", "irregular", dict(dim=256, heads=8, dim_head=32, slice_num=32, rotate=45), 800, "amp", False),
+    ("irr_memchk_b2_amp", "irregular", dict(dim=256, heads=8, dim_head=32, slice_num=32, rotate=45), 300, "amp", False),
 ]
 
 # BASELINE configs C1 and C5 at their REAL widths (dim 256 -> 8 heads x 32: inside the HIP convolution's envelope),

@@ -164,6 +164,36 @@ def test_pre_norm_in_the_projection_matches_separate_layernorm(hip_device):
     assert O.rel_l2(fused.cpu(), ref.cpu()) < 2e-5
 
 
+@pytest.mark.parametrize("kind", ["2d", "3d"])
+def test_pre_norm_in_the_convolution_presplit_matches_separate_layernorm(kind, hip_device, monkeypatch):
+    """Structured variants (round 4): Attn(x, pre_norm=ln) with the LayerNorm inside the pre-split pass of the LDS-DMA
+    convolution (haet_conv_presplit) against Attn(ln(x)), on grids large enough for that kernel (>= 192 row tiles); and the
+    same module on the streaming convolution (HAET_CONV_V1=1)."""
+    from haet_amd.PhysicsAttention import Physics_Attention_Structured_Mesh_2D, Physics_Attention_Structured_Mesh_3D
+
+    torch.manual_seed(5)
+    if kind == "2d":
+        mod = Physics_Attention_Structured_Mesh_2D(dim=256, heads=8, dim_head=32, slice_num=32, H=240, W=230, rotate=45)
+        N = 240 * 230
+    else:
+        mod = Physics_Attention_Structured_Mesh_3D(dim=256, heads=8, dim_head=32, slice_num=64, H=40, W=38, D=36, rotate=45)
+        N = 40 * 38 * 36
+    mod = mod.eval().to(hip_device)
+    ln = torch.nn.LayerNorm(256).to(hip_device)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.normal_(0, 0.3)
+        x = torch.randn(1, N, 256, device=hip_device) * 1.7 + 0.2
+        assert mod.fuses_pre_norm(x, ln)
+        fused = mod(x, pre_norm=ln)
+        ref = mod(ln(x))
+        monkeypatch.setenv("HAET_CONV_V1", "1")
+        assert not mod.fuses_pre_norm(x, ln)
+        old = mod(x, pre_norm=ln)
+    assert O.rel_l2(fused.cpu(), ref.cpu()) < 2e-5
+    assert O.rel_l2(fused.cpu(), old.cpu()) < 2e-5
+
+
 @pytest.mark.parametrize("mode", ["reduce-overhead", "max-autotune-no-cudagraphs"])
 def test_model_under_torch_compile(mode, hip_device):
     """The reference's scripts wrap the model in torch.compile (exp_airfoil.py:137 "max-autotune", exp_plas.py:177
