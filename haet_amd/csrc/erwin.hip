@@ -1282,9 +1282,9 @@ static int erwin_launch(const float* tokens, const float* pos, int32_t* tree_idx
     if (int rc = erwin_train_args(desc, train, n_clouds, stream, &tr)) return rc;
     ErwinDir dir;
     erwin_directory(*desc, Mp, &dir);
-    // eval mode, few clouds (one per CU of an XCD at most): pack them onto one XCD; HAET_ERWIN_XCD_PACK=0 switches it off (A/B)
+    // HAET_ERWIN_XCD_PACK=1 (A/B switch, off by default: measured without effect): eval mode, few clouds -- pack them onto one XCD
     const char* pe = getenv("HAET_ERWIN_XCD_PACK");
-    const bool pack = !tr.on && !tr.tape && n_clouds <= 32 && !(pe && pe[0] == '0');
+    const bool pack = !tr.on && !tr.tape && n_clouds <= 32 && pe && pe[0] == '1';
     hipLaunchKernelGGL(erwin_kernel<FUSED>, dim3(pack ? 8 * n_clouds : n_clouds), dim3(kErwinThreads), bytes, stream, tokens, pos,
                        tree_idx, tree_mask, rot, weights, M, Mp, out, dir, tr, tcfg, pos_out, (unsigned)(weight_floats / 4),
                        pack ? n_clouds : 0);

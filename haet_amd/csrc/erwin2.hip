@@ -1038,8 +1038,8 @@ extern "C" int haet_token_stage_fwd_frag(const float* S, int n_clouds, int M, fl
         if (e != hipSuccess) return fail(HAET_E_LAUNCH, "token_stage_frag: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_dev.store(bytes, std::memory_order_release);
     }
-    const char* pe = getenv("HAET_ERWIN_XCD_PACK");  // A/B switch ("0": one workgroup per cloud on consecutive XCDs, as before round 4)
-    const bool pack = n_clouds <= 32 && !(pe && pe[0] == '0');
+    const char* pe = getenv("HAET_ERWIN_XCD_PACK");  // A/B switch, off by default ("1": all clouds on one XCD; measured without effect)
+    const bool pack = n_clouds <= 32 && pe && pe[0] == '1';
     hipLaunchKernelGGL(e2::erwin2_kernel, dim3(pack ? 8 * n_clouds : n_clouds), dim3(e2::kThreads), bytes, as_stream(stream), S,
                        tree_idx, tree_mask, rot, weights, reinterpret_cast<const char*>(frags), out, cfg, pos_out, P.h, warm,
                        pack ? n_clouds : 0);

@@ -8,6 +8,7 @@
 #include "common.h"
 
 #include <cfloat>
+#include <cstdlib>
 
 namespace haet {
 
@@ -237,6 +238,126 @@ __global__ __launch_bounds__(kAttThreads) void ball_attention_kernel(const float
         for (int e = 0; e < HD; e += 4) {
             const f32x4 o = {acc[e] * inv, acc[e + 1] * inv, acc[e + 2] * inv, acc[e + 3] * inv};
             *reinterpret_cast<f32x4*>(out + (r0 + i) * ldo + h * HD + e) = o;
+        }
+    }
+}
+
+// The same attention on the matrix cores (round 4; power-of-two balls of 32 .. 128 tokens, head dims 8 / 16 / 32 -- the
+// ShapeNetCar configuration: c = 128, 8 heads x 16, balls 64 / 32).  One workgroup per ball, K and V of all heads in LDS as
+// above; an item = (32-query tile, head), dealt to the 8 waves:
+//   St[k][q] = sum_d K[k][d] Q[q][d]   per 32-key tile: A = K rows from LDS, B = the lane's own query row from global memory
+//                                      (scaled to log2 units), split bf16 x 3 on v_mfma_f32_32x32x16_bf16 (head dim 8: the
+//                                      upper half of the 16-wide k-step is zero)
+//   the softmax of a query is over ONE lane's registers (16 per key tile) + its partner lane (xor 32): no LDS, no atomics
+//   Ot[d][q] = sum_k Vt[d][k] P[k][q]  A = V gathered from LDS in the accumulator's key order, B = P as it stands
+// against ~2 ball^2 head_dim fused multiply-adds per (query, head) THREAD in the kernel above.
+typedef __attribute__((ext_vector_type(16))) float pc_f16v;
+typedef __attribute__((ext_vector_type(8))) __bf16 pc_bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned pc_u4;
+__device__ __forceinline__ void pc_split8(const float (&v)[8], pc_u4& hi, pc_u4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned h, l;
+        split_bf16_pair(v[2 * i], v[2 * i + 1], h, l);
+        hi[i] = h, lo[i] = l;
+    }
+}
+__device__ __forceinline__ pc_f16v pc_mfma3(pc_u4 ah, pc_u4 al, pc_u4 bh, pc_u4 bl, pc_f16v c) {
+    const pc_bf16x8 a0 = __builtin_bit_cast(pc_bf16x8, ah), a1 = __builtin_bit_cast(pc_bf16x8, al);
+    const pc_bf16x8 b0 = __builtin_bit_cast(pc_bf16x8, bh), b1 = __builtin_bit_cast(pc_bf16x8, bl);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
+    return c;
+}
+template <int HD, int KT>  // KT = ball / 32 key tiles
+__global__ __launch_bounds__(kAttThreads) void ball_attention_mfma_kernel(const float* __restrict__ qkv, int ldq, int c, int heads,
+                                                                         float scale, float* __restrict__ out, int ldo) {
+    constexpr int ball = 32 * KT, NS = HD > 16 ? HD / 16 : 1;  // 16-wide k-steps of the score product
+    float* const Ks = pc_lds;
+    float* const Vs = pc_lds + (size_t)ball * c;
+    const size_t r0 = (size_t)blockIdx.x * ball;
+    for (int i = threadIdx.x; i < ball * (c / 4); i += kAttThreads) {
+        const int j = i / (c / 4), ch = 4 * (i % (c / 4));
+        *reinterpret_cast<f32x4*>(Ks + (size_t)j * c + ch) = *reinterpret_cast<const f32x4*>(qkv + (r0 + j) * ldq + c + ch);
+        *reinterpret_cast<f32x4*>(Vs + (size_t)j * c + ch) = *reinterpret_cast<const f32x4*>(qkv + (r0 + j) * ldq + 2 * c + ch);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, l31 = lane & 31;
+    const float qs = scale * 1.4426950408889634f;  // scores in log2 units
+    for (int item = wave; item < KT * heads; item += kAttThreads / 64) {
+        const int qt = item / heads, h = item - qt * heads;
+        const float* qrow = qkv + (r0 + 32 * qt + l31) * ldq + h * HD;
+        // B operand: this lane's query, elements d = 16 s + 8 hf .. + 7 of k-step s (head dim 8: the hf = 1 half is zero)
+        pc_u4 qh[NS], ql[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int d0 = HD == 8 ? 0 : 16 * s + 8 * hf;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(qrow + d0), b = *reinterpret_cast<const f32x4*>(qrow + d0 + 4);
+            const bool pad = HD == 8 && hf;
+            const float v[8] = {pad ? 0.f : a[0] * qs, pad ? 0.f : a[1] * qs, pad ? 0.f : a[2] * qs, pad ? 0.f : a[3] * qs,
+                                pad ? 0.f : b[0] * qs, pad ? 0.f : b[1] * qs, pad ? 0.f : b[2] * qs, pad ? 0.f : b[3] * qs};
+            pc_split8(v, qh[s], ql[s]);
+        }
+        pc_f16v S[KT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
+            const float* krow = Ks + (size_t)(32 * kt + l31) * c + h * HD;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int d0 = HD == 8 ? 0 : 16 * s + 8 * hf;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(krow + d0), b = *reinterpret_cast<const f32x4*>(krow + d0 + 4);
+                const bool pad = HD == 8 && hf;
+                const float v[8] = {pad ? 0.f : a[0], pad ? 0.f : a[1], pad ? 0.f : a[2], pad ? 0.f : a[3],
+                                    pad ? 0.f : b[0], pad ? 0.f : b[1], pad ? 0.f : b[2], pad ? 0.f : b[3]};
+                pc_u4 kh, kl;
+                pc_split8(v, kh, kl);
+                S[kt] = pc_mfma3(kh, kl, qh[s], ql[s], S[kt]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, S[kt][r]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                S[kt][r] = __builtin_amdgcn_exp2f(S[kt][r] - m);
+                l += S[kt][r];
+            }
+        l += __shfl_xor(l, 32);
+        pc_f16v O;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[r] = 0.f;
+        const int dcol = h * HD + (l31 & (HD - 1));
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float vv[8], pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int key = 32 * kt + 16 * s + 8 * (j >> 2) + 4 * hf + (j & 3);  // the accumulator's key order
+                    const float v1 = Vs[(size_t)key * c + dcol];  // (unconditional read; rows d >= HD of Vt are zero)
+                    vv[j] = l31 < HD ? v1 : 0.f;
+                    pv[j] = S[kt][8 * s + j];
+                }
+                pc_u4 vh, vl, ph, pl;
+                pc_split8(vv, vh, vl);
+                pc_split8(pv, ph, pl);
+                O = pc_mfma3(vh, vl, ph, pl, O);
+            }
+        // lane (q, hf) holds O[q][d] for d = (r & 3) + 8 (r >> 2) + 4 hf, r < HD / 2: four consecutive d per register quad
+        const float inv = 1.0f / l;
+        float* orow = out + (r0 + 32 * qt + l31) * ldo + h * HD + 4 * hf;
+#pragma unroll
+        for (int g = 0; g < HD / 8; ++g) {
+            const f32x4 o = {O[4 * g] * inv, O[4 * g + 1] * inv, O[4 * g + 2] * inv, O[4 * g + 3] * inv};
+            *reinterpret_cast<f32x4*>(orow + 8 * g) = o;
         }
     }
 }
@@ -982,6 +1103,25 @@ extern "C" int haet_pc_ball_attention(const float* qkv, int ldq, long long rows,
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)(rows / ball)), dim3(kAttThreads), lds, as_stream(stream), qkv, ldq, c, heads, ball, scale, out, ldo);
     };
+    // matrix-core kernel: balls of 32 / 64 / 128 tokens, head dims 8 / 16 / 32 (HAET_PC_ATT_VALU=1: the vector-ALU kernel, A/B)
+    static const bool valu = getenv("HAET_PC_ATT_VALU") != nullptr;
+    if (!valu && (ball == 32 || ball == 64 || (ball == 128 && hd != 16)) && (hd == 8 || hd == 16 || hd == 32) && ldq % 4 == 0 &&
+        ldo % 4 == 0) {  // (ball 128 at head dim 16 spills 28 registers: it keeps the vector-ALU kernel)
+        auto gom = [&](auto kern) {
+            if (lds > 64 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(rows / ball)), dim3(kAttThreads), lds, as_stream(stream), qkv, ldq, c, heads, scale, out, ldo);
+        };
+#define HAET_PC_ATT(HD_)                                            \
+    if (hd == HD_) {                                                \
+        if (ball == 32) gom(ball_attention_mfma_kernel<HD_, 1>);    \
+        else if (ball == 64) gom(ball_attention_mfma_kernel<HD_, 2>); \
+        else gom(ball_attention_mfma_kernel<HD_, 4>);               \
+    }
+        HAET_PC_ATT(8) HAET_PC_ATT(16) HAET_PC_ATT(32)
+#undef HAET_PC_ATT
+        return check_launch("ball_attention_mfma_kernel");
+    }
     switch (hd) {
         case 8: go(ball_attention_kernel<8>); break;
         case 16: go(ball_attention_kernel<16>); break;

@@ -12,7 +12,7 @@ import os
 import statistics
 import sys
 
-SHORT = (("gemm_ws_kernel<8, 4, true", "gemm_ws_split"), ("gemm_ws_kernel", "gemm_ws"), ("deslice_out_kernel", "deslice_out"),
+SHORT = (("conv8_kernel", "conv8"), ("presplit_kernel", "conv_presplit"), ("gemm_ws_kernel<8, 4, true", "gemm_ws_split"), ("gemm_ws_kernel", "gemm_ws"), ("deslice_out_kernel", "deslice_out"),
          ("deslice_mfma_kernel", "deslice"), ("slice_mfma_kernel", "slice"), ("slice_merge_kernel", "merge"),
          ("erwin2_kernel", "token_stage"), ("erwin_kernel<true>", "token_stage_v1"), ("erwin_kernel", "erwin"),
          ("slice_bwd_x3_kernel", "slice_bwd_x3"), ("balltree_wave_kernel", "balltree_wave"),
