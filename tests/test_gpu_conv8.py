@@ -175,3 +175,30 @@ def test_cells_convolution_fp16x2_mode(B, grid, Cin, k, hip_device):
     e = _rel(out, ref)
     assert 1e-5 < e < 5e-4, e  # (above the bf16x3 grade: the mode really ran)
     assert _rel(xs.to_float().cpu(), ref) < 5e-4
+
+
+def test_slab_with_halo_planes_equals_the_unsharded_convolution(hip_device):
+    """What the slab-sharded structured path does around the LDS-DMA kernel (haet_amd/PhysicsAttention/_base.py
+    `_conv_project`): a rank convolves its planes extended by one halo plane per side and drops the halo rows.
+    Two virtual ranks of a 44 x 40 x 36 grid (the cells kernel called directly, pre-norm fused in the pre-split pass) against the unsharded convolution: the interior rows must agree to rounding, the global faces keep zero padding."""
+    from haet_amd import ops
+
+    torch.manual_seed(21)
+    gH, gW, gD, Cin = 44, 40, 36, 256
+    plane = gW * gD
+    x = torch.randn(1, gH * plane, Cin, device=hip_device)
+    W = torch.randn(256, Cin, 3, 3, 3, device=hip_device) * 0.03
+    w = ops.SplitConv(W, torch.randn(256, device=hip_device))
+    ln = torch.nn.LayerNorm(Cin).to(hip_device)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.normal_(0, 0.2)
+    lnp = (ln.weight, ln.bias, ln.eps)
+    full = ops.conv_project_cells(x, w, (gH, gW, gD), lnp)
+    half = gH // 2
+    for r, (lo, hi) in enumerate([(0, half), (half, gH)]):
+        elo, ehi = max(lo - 1, 0), min(hi + 1, gH)  # one halo plane per side where a neighbour exists
+        x_ext = x[:, elo * plane:ehi * plane].contiguous()
+        y = ops.conv_project_cells(x_ext, w, (ehi - elo, gW, gD), lnp)
+        mine = y[:, (lo - elo) * plane:(lo - elo) * plane + (hi - lo) * plane]
+        assert _rel(mine.cpu(), full[:, lo * plane:hi * plane].cpu()) < 1e-6, r
