@@ -147,7 +147,8 @@ def pack_erwin(erwin):
 # --------------------------------------------------------------------------- fp32 blob of the backward kernel
 def pack_erwin_f32(erwin):
     """(blob, layout, param_map) for haet_erwin_bwd: every tensor in fp32, Linear weights in PyTorch's [out][in]
-    layout AND transposed (the kernel reads whichever makes its loads coalesced); the blob BEGINS WITH the layout
+    layout AND transposed (the kernel reads whichever makes its loads coalesced), each of the block Linears' two tensors
+    followed by a tile-ordered copy of itself (round 4: what the matrix-core phases load); the blob BEGINS WITH the layout
     (include/haet_hip.h haet_erwin_f32_layout).  `param_map`: [(parameter, offset)] -- where each parameter's gradient
     sits in a cloud's slice of the kernel's `grads` output."""
     from ..._lib import ErwinF32Layout
@@ -172,13 +173,26 @@ def pack_erwin_f32(erwin):
             pmap.append((param, off))
         return off
 
+    def tiled(w):
+        """[R][K] -> per (32-row tile, 16-wide k-step) two 1-KB pieces in which lane (r, hf) of a wave holds
+        W[32 ot + r][16 s + 8 hf + 4 which .. + 4] (erwin_bwd.hip eb_phase, wfetch); same number of floats; zeros where the
+        shape is not a multiple of (32, 16) -- such shapes never take the matrix-core phases."""
+        w = w.detach().float()
+        R, K = w.shape
+        if R % 32 or K % 16:
+            return torch.zeros(R * K, device=w.device)
+        # [ot][r][s][hf][which][4] -> [ot][s][which][hf][r][4]
+        return w.reshape(R // 32, 32, K // 16, 2, 2, 4).permute(0, 2, 4, 3, 1, 5).contiguous().reshape(-1)
+
     def fill_block(dst, blk):
         a = blk.BMSA
         dst.norm1, dst.norm2 = add(blk.norm1.weight, blk.norm1.weight), add(blk.norm2.weight, blk.norm2.weight)
         dst.pe_w, dst.pe_b = add(a.pe_proj.weight, a.pe_proj.weight), add(a.pe_proj.bias, a.pe_proj.bias)
         for name, lin in (("qkv", a.qkv), ("proj", a.proj), ("w1", blk.swiglu.w1), ("w2", blk.swiglu.w2), ("w3", blk.swiglu.w3)):
             setattr(dst, name + "_w", add(lin.weight, lin.weight))
+            add(tiled(lin.weight))      # (round 4) the tile-ordered copy the matrix-core phases stream: right behind the tensor
             setattr(dst, name + "_wT", add(lin.weight.detach().t().contiguous()))
+            add(tiled(lin.weight.detach().t()))
             setattr(dst, name + "_b", add(lin.bias, lin.bias))
 
     def fill_resample(dst, mod):

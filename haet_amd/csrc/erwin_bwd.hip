@@ -288,7 +288,8 @@ __device__ __forceinline__ eb_f16v eb_mfma3(const EbFrag& a, const EbFrag& b, eb
 // read by everybody behind the phase's opening barrier): inlined at its seven call sites the routine was 38k lines of ISA
 // with 161 spill operations, and as a by-value argument the descriptor went through scratch memory.
 struct EbJob {
-    int g_on, Y, Ystep, ldy, X, ldx, X2, n, K, K2, O, nmat, acc, ldk, ldk2;
+    int g_on, Y, Ystep, ldy, X, ldx, X2, n, K, K2, O, nmat, acc;
+    int tnks, tot0, ts0, tnks2, ts02;  // W / Wb / W2 are TILED copies: k-steps per full row, row-tile and k-step offsets of the sub-block
     const float *W, *Wb, *W2, *bias, *biasb;
     int w_on, ldw, A, Astep, lda, B, B2, ldb, wO, wK, wmat, gmode;
     float *dW, *dWb, *db, *dbb;
@@ -312,16 +313,18 @@ __device__ __attribute__((noinline)) void eb_phase(int JOB) {
     eb_lds_barrier();  // the job descriptor is in LDS; the producers of the phase's inputs (and the last readers of its outputs) are done
     const EbJob j = *reinterpret_cast<const EbJob*>(sm + EU(JOB));
 #ifdef HAET_STAMPS
-    const bool st_on = EU(j.stamp) != 0;
-#define ESTAMP(i) do { if (st_on && blockIdx.x == 0 && threadIdx.x == 0 && haet_bwd_stamp_on) haet_bwd_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
-    if (st_on && blockIdx.x == 0 && threadIdx.x == 0 && haet_bwd_stamp_on) haet_bwd_stamps[52] = st_in;
+    // (the flag is read ONCE: as a global read inside every stamp it cost ~2k cycles per stamp and distorted the picture)
+    const bool st_on = EU(j.stamp) != 0 && blockIdx.x == 0 && threadIdx.x == 0 && haet_bwd_stamp_on;
+#define ESTAMP(i) do { if (st_on) haet_bwd_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    if (st_on) haet_bwd_stamps[52] = st_in;
     ESTAMP(53);
 #else
 #define ESTAMP(i) do { } while (0)
 #endif
     // uniform copies
     const int g_on = EU(j.g_on), Y0 = EU(j.Y), Ystep = EU(j.Ystep), ldy = EU(j.ldy), X = EU(j.X), ldx = EU(j.ldx), X2 = EU(j.X2);
-    const int n = EU(j.n), K = EU(j.K), K2 = EU(j.K2), O = EU(j.O), nmat = EU(j.nmat), accm = EU(j.acc), ldk = EU(j.ldk), ldk2 = EU(j.ldk2);
+    const int n = EU(j.n), K = EU(j.K), K2 = EU(j.K2), O = EU(j.O), nmat = EU(j.nmat), accm = EU(j.acc);
+    const int tnks = EU(j.tnks), tot0 = EU(j.tot0), ts0 = EU(j.ts0), tnks2 = EU(j.tnks2), ts02 = EU(j.ts02);
     const float *Wa = EUP(j.W), *Wb = EUP(j.Wb), *W2 = EUP(j.W2), *ba = EUP(j.bias), *bb = EUP(j.biasb);
     const int w_on = EU(j.w_on), ldw = EU(j.ldw), A0 = EU(j.A), Astep = EU(j.Astep), lda = EU(j.lda), B = EU(j.B), B2 = EU(j.B2), ldb = EU(j.ldb);
     const int wO = EU(j.wO), wK = EU(j.wK), wmat = EU(j.wmat), gmode = EU(j.gmode);
@@ -346,14 +349,19 @@ __device__ __attribute__((noinline)) void eb_phase(int JOB) {
         return g;
     };
     auto wfetch = [&](const GT& g, int s0, eb_f4 (&w0)[KG], eb_f4 (&w1)[KG]) {
-        const float* r1 = (g.m ? Wb : Wa) + (size_t)(32 * g.ot + l31) * ldk + 8 * hf;
-        const float* r2 = (W2 ? W2 : Wa) + (size_t)(32 * g.ot + l31) * (W2 ? ldk2 : ldk) + 8 * hf;
+        // Weights come from the TILE-ORDERED copies behind the row-major tensors of the fp32 blob (pack.py, pack_erwin_f32;
+        // round 4): per (32-row tile ot, 16-wide k-step s) two 1-KB pieces -- lane (r, hf) holds W[32 ot + r][16 s + 8 hf
+        // + 4 which ..] -- so that a wave load is 1 KB of consecutive bytes.  From the row-major tensor the same load was 32
+        // rows x 2 x 16 B with neighbouring lanes in different rows (the shape that held erwin.hip's Linears at 11 B/cycle
+        // per CU): bwd_erwin 0.91 -> 0.81 ms in a same-box A/B of the access shape alone.
+        const float* r1 = (g.m ? Wb : Wa) + ((size_t)(tot0 + g.ot) * tnks + ts0) * 512 + lane * 4;
+        const float* r2 = W2 ? W2 + ((size_t)(tot0 + g.ot) * tnks2 + ts02) * 512 + lane * 4 : r1;
 #pragma unroll
         for (int u = 0; u < KG; ++u) {  // (clamped: unconditional loads, an address select instead of a branch)
             const int s = min(s0 + u, ks_n - 1);
-            const float* wr = s < ks1 ? r1 + 16 * s : r2 + 16 * (s - ks1);
+            const float* wr = s < ks1 ? r1 + 512 * s : r2 + 512 * (s - ks1);
             w0[u] = *(gf4)wr;
-            w1[u] = *(gf4)(wr + 4);
+            w1[u] = *(gf4)(wr + 256);
         }
     };
     eb_f4 w0[KG], w1[KG];
@@ -391,6 +399,7 @@ __device__ __attribute__((noinline)) void eb_phase(int JOB) {
             const int Yb = Y0 + g.m * Ystep, t = 32 * g.tt + l31;
             const float* bias = g.m ? bb : ba;
             wfetch(g, 0, w0, w1);  // (ahead of the accumulator's initial values: both are memory round trips)
+            ESTAMP(59);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int o4 = 32 * g.ot + 8 * q + 4 * hf;
@@ -415,6 +424,7 @@ __device__ __attribute__((noinline)) void eb_phase(int JOB) {
                     }
                 }
             }
+            ESTAMP(60);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const eb_f4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -470,14 +480,35 @@ struct BwdDir {
     int IDENT, XIN, N1, AO, XMID, N2, TMP, QKV, HREG, R1, R2, ST, REL, WST, WSTG, total;
 };
 
+// whether the per-token reductions can run with c / 4 lanes per token (a power of two of lanes inside one wave, 16-B aligned rows)
+__device__ __forceinline__ bool lanes_per_token(int c) {
+    const int G = c >> 2;
+    return (c & 3) == 0 && G >= 1 && G <= 64 && (G & (G - 1)) == 0;
+}
+
 // ---- RMSNorm forward: out[t][k] = x[t][k] r[t] g[k] (+ pe_b[k] + sum_j rel[t][j] pe_w[k][j]),  r -> R[t]
 __device__ __forceinline__ void rms_fwd(int OUT, int X, int R, const float* __restrict__ g, int n, int c, int REL, int d,
                                         const float* __restrict__ pe_w, const float* __restrict__ pe_b) {
     float* sm = SM();
-    for (int t = threadIdx.x; t < n; t += kBT) {
-        float ss = 0.f;
-        for (int k = 0; k < c; ++k) ss = fmaf(sm[X + t * c + k], sm[X + t * c + k], ss);
-        sm[R + t] = rsqrtf(ss / (float)c + kRmsEps);
+    if (lanes_per_token(c)) {
+        // c / 4 lanes per token, one 16-B read each, the token's sum by xor-shuffles (round 4: one thread per token walking
+        // its c channels read the SAME LDS bank as every other thread of its wave -- 64-way conflicts, 2-4k cycles per norm)
+        const int G = c >> 2;
+        for (int base = 0; base < n * G; base += kBT) {
+            const int i = base + (int)threadIdx.x;
+            const bool ok = i < n * G;
+            const int t = ok ? i / G : 0, k4 = ok ? i - t * G : 0;
+            const eb_f4 v = *reinterpret_cast<const eb_f4*>(sm + X + t * c + 4 * k4);
+            float ss = ok ? (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]) : 0.f;
+            for (int off = 1; off < G; off <<= 1) ss += __shfl_xor(ss, off);
+            if (ok && k4 == 0) sm[R + t] = rsqrtf(ss / (float)c + kRmsEps);
+        }
+    } else {
+        for (int t = threadIdx.x; t < n; t += kBT) {
+            float ss = 0.f;
+            for (int k = 0; k < c; ++k) ss = fmaf(sm[X + t * c + k], sm[X + t * c + k], ss);
+            sm[R + t] = rsqrtf(ss / (float)c + kRmsEps);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n * c; i += kBT) {
@@ -494,17 +525,48 @@ __device__ __forceinline__ void rms_fwd(int OUT, int X, int R, const float* __re
 
 // ---- RMSNorm backward: DX[t][k] += r (dn g) - x r^3 mean_k(dn g x);  dg[k] = sum_t dn[t][k] x[t][k] r[t]
 __device__ __forceinline__ void rms_bwd(int DX, int DN, int X, int R, const float* __restrict__ g, float* __restrict__ dg,
-                                        int n, int c, int SCR) {
+                                        int n, int c, int SCR, int SCR2 /* kBT floats of scratch, or -1 */) {
     float* sm = SM();
-    for (int t = threadIdx.x; t < n; t += kBT) {
-        float s = 0.f;
-        for (int k = 0; k < c; ++k) s = fmaf(sm[DN + t * c + k] * g[k], sm[X + t * c + k], s);
-        sm[SCR + t] = s / (float)c;
-    }
-    for (int k = threadIdx.x; k < c; k += kBT) {
-        float s = 0.f;
-        for (int t = 0; t < n; ++t) s = fmaf(sm[DN + t * c + k] * sm[X + t * c + k], sm[R + t], s);
-        dg[k] = s;
+    const int P = kBT / c;  // token groups of the dg sums
+    if (lanes_per_token(c) && ((X | DN) & 3) == 0 && P >= 1 && SCR2 >= 0) {
+        // (round 4) per-token sums with c / 4 lanes per token; dg with kBT / c token groups per channel: partial sums to LDS,
+        // then one thread per channel adds them in a fixed order.  The serial forms below took 12-14k cycles per call.
+        const int G = c >> 2;
+        for (int base = 0; base < n * G; base += kBT) {
+            const int i = base + (int)threadIdx.x;
+            const bool ok = i < n * G;
+            const int t = ok ? i / G : 0, k4 = ok ? i - t * G : 0;
+            const eb_f4 dn = *reinterpret_cast<const eb_f4*>(sm + DN + t * c + 4 * k4);
+            const eb_f4 xv = *reinterpret_cast<const eb_f4*>(sm + X + t * c + 4 * k4);
+            const eb_f4 gv = *reinterpret_cast<const eb_f4*>(g + 4 * k4);
+            float sv = ok ? (dn[0] * gv[0] * xv[0] + dn[1] * gv[1] * xv[1]) + (dn[2] * gv[2] * xv[2] + dn[3] * gv[3] * xv[3]) : 0.f;
+            for (int off = 1; off < G; off <<= 1) sv += __shfl_xor(sv, off);
+            if (ok && k4 == 0) sm[SCR + t] = sv / (float)c;
+        }
+        const int per = (n + P - 1) / P;
+        for (int i = threadIdx.x; i < P * c; i += kBT) {
+            const int part = i / c, k = i - part * c;
+            float sv = 0.f;
+            for (int t = part * per; t < min(n, (part + 1) * per); ++t) sv = fmaf(sm[DN + t * c + k] * sm[X + t * c + k], sm[R + t], sv);
+            sm[SCR2 + i] = sv;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < c; k += kBT) {
+            float sv = 0.f;
+            for (int part = 0; part < P; ++part) sv += sm[SCR2 + part * c + k];
+            dg[k] = sv;
+        }
+    } else {
+        for (int t = threadIdx.x; t < n; t += kBT) {
+            float sv = 0.f;
+            for (int k = 0; k < c; ++k) sv = fmaf(sm[DN + t * c + k] * g[k], sm[X + t * c + k], sv);
+            sm[SCR + t] = sv / (float)c;
+        }
+        for (int k = threadIdx.x; k < c; k += kBT) {
+            float sv = 0.f;
+            for (int t = 0; t < n; ++t) sv = fmaf(sm[DN + t * c + k] * sm[X + t * c + k], sm[R + t], sv);
+            dg[k] = sv;
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n * c; i += kBT) {
@@ -520,6 +582,22 @@ __device__ __forceinline__ void rel_pos(int REL, int P, int PERM, int n, int d, 
     float* sm = SM();
     const int* pm = reinterpret_cast<const int*>(smem) + PERM;
     const int nb = n / ball;
+    if (ball <= 64 && (ball & (ball - 1)) == 0 && n % ball == 0 && (n & 63) % ball == 0) {
+        // (round 4) one thread per (dimension, place): the places of a ball are neighbouring lanes, its mean a xor-shuffle sum
+        // (the serial form below had n / ball * d threads -- six at C3 -- walking a ball twice: 6k cycles per block)
+        const int total = (n * d + 63) & ~63;  // whole waves: every lane takes part in the shuffles
+        for (int i = threadIdx.x; i < total; i += kBT) {
+            const int j = i / n, pl = i - j * n;
+            const bool ok = j < d;
+            const int tok = ok ? pm[pl] : 0;
+            const float v = ok ? sm[P + tok * d + j] : 0.f;
+            float sum = v;
+            for (int off = 1; off < ball; off <<= 1) sum += __shfl_xor(sum, off);
+            if (ok) sm[REL + tok * d + j] = v - sum / (float)ball;
+        }
+        __syncthreads();
+        return;
+    }
     for (int i = threadIdx.x; i < nb * d; i += kBT) {
         const int b = i / d, j = i - b * d;
         float s = 0.f;
@@ -707,7 +785,7 @@ __device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdD
     if (fast) {
         EbJob j = {};
         j.g_on = 1, j.Y = QKV, j.ldy = 3 * c, j.X = N1, j.ldx = c, j.n = n, j.K = c, j.O = 3 * c, j.nmat = 1;
-        j.W = Wf + w.qkv_w, j.ldk = c, j.bias = Wf + w.qkv_b;
+        j.W = Wf + w.qkv_w + 3 * c * c, j.tnks = c >> 4, j.bias = Wf + w.qkv_b;  // (tiled copy: right behind the [3c][c] tensor)
         EB_RUN(j);
     } else {
         gemm(T.WSTG, QKV, 3 * c, N1, c, Wf + w.qkv_wT, 3 * c, Wf + w.qkv_b, n, c, 3 * c, false);
@@ -722,7 +800,7 @@ __device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdD
     if (fast) {
         EbJob j = {};
         j.g_on = 1, j.Y = XMID, j.ldy = c, j.X = AO, j.ldx = c, j.n = n, j.K = c, j.O = c, j.nmat = 1, j.acc = 1;
-        j.W = Wf + w.proj_w, j.ldk = c;
+        j.W = Wf + w.proj_w + c * c, j.tnks = c >> 4;
         EB_RUN(j);
     } else {
         gemm(T.WSTG, XMID, c, AO, c, Wf + w.proj_wT, c, nullptr, n, c, c, true);
@@ -751,7 +829,7 @@ __device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdD
             {
                 EbJob j = {};
                 j.g_on = 1, j.Y = H1, j.Ystep = H2 - H1, j.ldy = hw, j.X = N2, j.ldx = c, j.n = n, j.K = c, j.O = hw, j.nmat = 2;
-                j.W = Wf + w.w1_w + (size_t)j0 * c, j.Wb = Wf + w.w2_w + (size_t)j0 * c, j.ldk = c;
+                j.W = Wf + w.w1_w + hid * c, j.Wb = Wf + w.w2_w + hid * c, j.tnks = c >> 4, j.tot0 = j0 >> 5;  // rows j0 .. of [hid][c]
                 j.bias = Wf + w.w1_b + j0, j.biasb = Wf + w.w2_b + j0;
                 j.stamp = j0 == 0;
                 EB_RUN(j);
@@ -763,7 +841,7 @@ __device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdD
                 j.w_on = 1, j.dW = G + w.w3_w + j0, j.ldw = hid, j.A = DX, j.lda = c, j.B = H2, j.B2 = H1, j.ldb = hw;
                 j.wO = c, j.wK = hw, j.wmat = 1, j.gmode = 1;
                 j.g_on = 1, j.Y = GG, j.ldy = hw, j.X = DX, j.ldx = c, j.n = n, j.K = c, j.O = hw, j.nmat = 1;
-                j.W = Wf + w.w3_wT + (size_t)j0 * c, j.ldk = c;
+                j.W = Wf + w.w3_wT + hid * c, j.tnks = c >> 4, j.tot0 = j0 >> 5;  // rows j0 .. of w3^T [hid][c]
                 EB_RUN(j);
             }
             __syncthreads();
@@ -782,7 +860,8 @@ __device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdD
                 j.A = H1, j.Astep = H2 - H1, j.lda = hw, j.B = N2, j.ldb = c, j.wO = hw, j.wK = c, j.wmat = 2;
                 j.db = G + w.w1_b + j0, j.dbb = G + w.w2_b + j0;
                 j.g_on = 1, j.Y = TMP, j.ldy = c, j.X = H1, j.X2 = H2, j.ldx = hw, j.n = n, j.K = hw, j.K2 = hw, j.O = c, j.nmat = 1;
-                j.acc = 1, j.W = Wf + w.w1_wT + j0, j.ldk = hid, j.W2 = Wf + w.w2_wT + j0, j.ldk2 = hid;
+                j.acc = 1, j.W = Wf + w.w1_wT + c * hid, j.tnks = hid >> 4, j.ts0 = j0 >> 4;  // columns j0 .. of w1^T [c][hid]
+                j.W2 = Wf + w.w2_wT + c * hid, j.tnks2 = hid >> 4, j.ts02 = j0 >> 4;
                 EB_RUN(j);
             }
             if (j0 == 0) BSTAMP(26);
@@ -825,14 +904,14 @@ __device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdD
     }
     __syncthreads();
     BSTAMP(5);
-    rms_bwd(DX, TMP, XMID, T.R2, Wf + w.norm2, G + w.norm2, n, c, T.R2 + n);  // DX = dL/dx_mid now
+    rms_bwd(DX, TMP, XMID, T.R2, Wf + w.norm2, G + w.norm2, n, c, T.R2 + n, T.HREG);  // DX = dL/dx_mid now
     BSTAMP(6);
     // ---------------- attention branch: x_mid = x + proj(ao) + b
     if (fast) {  // dWp = dx_mid^T ao, dbp   ||   d ao = dx_mid Wp
         EbJob j = {};
         j.w_on = 1, j.dW = G + w.proj_w, j.ldw = c, j.A = DX, j.lda = c, j.B = AO, j.ldb = c, j.wO = c, j.wK = c, j.wmat = 1;
         j.db = G + w.proj_b;
-        j.g_on = 1, j.Y = TMP, j.ldy = c, j.X = DX, j.ldx = c, j.n = n, j.K = c, j.O = c, j.nmat = 1, j.W = Wf + w.proj_wT, j.ldk = c;
+        j.g_on = 1, j.Y = TMP, j.ldy = c, j.X = DX, j.ldx = c, j.n = n, j.K = c, j.O = c, j.nmat = 1, j.W = Wf + w.proj_wT + c * c, j.tnks = c >> 4;
         EB_RUN(j);
     } else {
         wgrad(G + w.proj_w, c, G + w.proj_b, DX, c, AO, c, n, c, c);
@@ -849,7 +928,7 @@ __device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdD
         j.w_on = 1, j.dW = G + w.qkv_w, j.ldw = c, j.A = DQ, j.lda = 3 * c, j.B = N1, j.ldb = c, j.wO = 3 * c, j.wK = c, j.wmat = 1;
         j.db = G + w.qkv_b;
         j.g_on = 1, j.Y = TMP, j.ldy = c, j.X = DQ, j.ldx = 3 * c, j.n = n, j.K = 3 * c, j.O = c, j.nmat = 1;
-        j.W = Wf + w.qkv_wT, j.ldk = 3 * c;
+        j.W = Wf + w.qkv_wT + 3 * c * c, j.tnks = (3 * c) >> 4;
         EB_RUN(j);
     } else {
         wgrad(G + w.qkv_w, c, G + w.qkv_b, DQ, 3 * c, N1, c, n, 3 * c, c);
@@ -858,7 +937,7 @@ __device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdD
     __syncthreads();
     wgrad(G + w.pe_w, d, G + w.pe_b, TMP, c, T.REL, d, n, c, d);  // d pe_w[k][j] = sum_t dn1[t][k] rel[t][j]
     BSTAMP(9);
-    rms_bwd(DX, TMP, XIN, T.R1, Wf + w.norm1, G + w.norm1, n, c, T.R1 + n);  // DX = dL/dx
+    rms_bwd(DX, TMP, XIN, T.R1, Wf + w.norm1, G + w.norm1, n, c, T.R1 + n, T.HREG);  // DX = dL/dx
     BSTAMP(10);
 }
 

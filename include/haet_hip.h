@@ -295,7 +295,10 @@ int haet_token_stage_fwd_frag(const float* S, int n_clouds, int M, float angle_d
  * reference computes rel_pos / centres under no_grad: attention.py:35, pooling.py:29,59).
  *
  * Weights come as ONE fp32 blob that BEGINS WITH haet_erwin_f32_layout (offsets in floats of every tensor, original
- * [out][in] layout `*_w` and its transpose `*_wT`), laid out by haet_amd/components/erwinflash/pack.py; `grads`
+ * [out][in] layout `*_w` and its transpose `*_wT`; ABI 7: each of a block's ten Linear tensors [R][K] is followed by a
+ * tile-ordered copy of itself of the same size -- per (32-row tile ot, 16-wide k-step s) two 1-KB pieces, order
+ * [ot][s][which], whose 16 bytes at 16 * (r + 32 hf) are W[32 ot + r][16 s + 8 hf + 4 which .. + 4] -- which is what the
+ * matrix-core phases stream), laid out by haet_amd/components/erwinflash/pack.py; `grads`
  * [n_clouds][layout.total] receives every parameter gradient of each cloud at the SAME offsets (the caller sums over
  * the clouds; the `*_wT` / statistics slots stay untouched). */
 typedef struct {

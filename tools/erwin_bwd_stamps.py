@@ -32,4 +32,5 @@ ops = [t[48 - k] for k in range(8)]
 print("per op (reverse order: dec blocks, unpool, bottleneck blocks, pool, enc blocks):", [ops[k + 1] - ops[k] for k in range(7)], "block total", t[10] - t[0])
 
 print("inside eb_phase (phase A of the first chunk, thread 0): entry->barrier+job", t[53] - t[52], "uniform copies", t[54] - t[53],
-      "tile init", t[55] - t[54], "weights requested", t[56] - t[55], "tile done", t[57] - t[56], "db + exit", t[58] - t[57])
+      "decode + weights requested", t[59] - t[54], "bias / accumulator init (waits for the loads)", t[55] - t[59], "first group requested", t[56] - t[55],
+      "k-loop done", t[60] - t[56], "stores + loop end", t[57] - t[60], "db + exit", t[58] - t[57])
