@@ -32,7 +32,6 @@ constexpr int kBT = 512;   // threads
 constexpr float kRmsEps = 1.1920928955078125e-07f;  // nn.RMSNorm(eps=None): finfo(float32).eps
 
 __device__ __forceinline__ float* SM() { return reinterpret_cast<float*>(smem); }
-
 #ifdef HAET_STAMPS
 // Diagnostic build only (make EXTRA=-DHAET_STAMPS; tools/erwin_bwd_stamps.py): s_memtime at phase boundaries of the
 // first block processed by cloud 0, written to a buffer nothing else reads.  Never quote this build's run time.
@@ -389,7 +388,10 @@ __device__ __attribute__((noinline)) void eb_phase(int JOB) {
                 }
                 acc = eb_mfma3(eb_split8(av), eb_split8(bv), acc);
             }
-            float* dW = m ? dWb : dWa;
+            // (explicitly GLOBAL stores: the pointers came through the job descriptor in LDS, i.e. generic, and a flat store
+            // counts in lgkmcnt too -- the next phase's opening barrier then waited for these stores' round trip)
+            typedef __attribute__((address_space(1))) float gfl;
+            gfl* dW = (gfl*)(m ? dWb : dWa);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 dW[(size_t)(32 * ot + (r & 3) + 8 * (r >> 2) + 4 * hf) * ldw + 32 * kt + l31] = acc[r];
@@ -442,7 +444,7 @@ __device__ __attribute__((noinline)) void eb_phase(int JOB) {
             sacc += __shfl_xor(sacc, 1);
             sacc += __shfl_xor(sacc, 2);
             sacc += __shfl_xor(sacc, 4);
-            if (part == 0) (m ? dbb : dba)[o] = sacc;
+            if (part == 0) ((__attribute__((address_space(1))) float*)(m ? dbb : dba))[o] = sacc;
         }
     }
     ESTAMP(58);
@@ -763,7 +765,11 @@ __device__ __forceinline__ void attn_bwd(const BwdDir& T, int QKV, int GO, int D
 }
 
 // one ErwinTransformerBlock, forward recompute + backward; DX (LDS) holds dL/dy on entry, dL/dx on exit
-__device__ __attribute__((noinline)) void block_bwd(const BwdArgs& a, const BwdDir& T, const haet_erwin_layer& Ly,
+// (round 4: INLINED into its one call site.  As a non-inlined function its four by-reference arguments -- the kernel's own
+// argument structs and two descriptors in the weight blobs -- were generic pointers: 172 flat_load instructions re-reading
+// their fields where they are used, each waited for with vmcnt(0) AND lgkmcnt(0); inlined, the fields are scalar loads
+// from the kernel-argument segment / the blob: 312 flat operations in the kernel -> 6.)
+__device__ __forceinline__ void block_bwd(const BwdArgs& a, const BwdDir& T, const haet_erwin_layer& Ly,
                                           const haet_erwin_block_f32& w, float* __restrict__ G, int lvl, int d, int PERM,
                                           const float* __restrict__ tape_in) {
     float* sm = SM();
