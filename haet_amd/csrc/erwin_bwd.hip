@@ -374,6 +374,7 @@ __device__ __attribute__((noinline)) void eb_phase(int JOB) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const int ao = A0 + m * Astep + 32 * ot + l31, bo = B + 32 * kt + l31, bo2 = B2 + 32 * kt + l31;
+            ESTAMP(61);
             for (int s = 0; s < (n >> 4); ++s) {
                 float av[8], bv[8];
 #pragma unroll
@@ -382,14 +383,15 @@ __device__ __attribute__((noinline)) void eb_phase(int JOB) {
                     av[e] = sm[ao + t * lda];
                     bv[e] = sm[bo + t * ldb];
                     if (gmode) {  // g = h2 silu(h1): B holds h2, B2 holds h1
-                        const float h1 = sm[bo2 + t * ldb];
-                        bv[e] *= h1 / (1.0f + __expf(-h1));
+                        const float h1 = sm[bo2 + t * ldb];  // silu via v_exp + v_rcp (the IEEE division was ~10 instructions per element)
+                        bv[e] *= h1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * h1));
                     }
                 }
                 acc = eb_mfma3(eb_split8(av), eb_split8(bv), acc);
             }
             // (explicitly GLOBAL stores: the pointers came through the job descriptor in LDS, i.e. generic, and a flat store
             // counts in lgkmcnt too -- the next phase's opening barrier then waited for these stores' round trip)
+            ESTAMP(62);
             typedef __attribute__((address_space(1))) float gfl;
             gfl* dW = (gfl*)(m ? dWb : dWa);
 #pragma unroll
@@ -837,7 +839,9 @@ __device__ __forceinline__ void block_bwd(const BwdArgs& a, const BwdDir& T, con
                 j.g_on = 1, j.Y = H1, j.Ystep = H2 - H1, j.ldy = hw, j.X = N2, j.ldx = c, j.n = n, j.K = c, j.O = hw, j.nmat = 2;
                 j.W = Wf + w.w1_w + hid * c, j.Wb = Wf + w.w2_w + hid * c, j.tnks = c >> 4, j.tot0 = j0 >> 5;  // rows j0 .. of [hid][c]
                 j.bias = Wf + w.w1_b + j0, j.biasb = Wf + w.w2_b + j0;
+#ifndef HAET_STAMP_PHASE_C
                 j.stamp = j0 == 0;
+#endif
                 EB_RUN(j);
             }
             if (j0 == 0) BSTAMP(21);
@@ -848,6 +852,9 @@ __device__ __forceinline__ void block_bwd(const BwdArgs& a, const BwdDir& T, con
                 j.wO = c, j.wK = hw, j.wmat = 1, j.gmode = 1;
                 j.g_on = 1, j.Y = GG, j.ldy = hw, j.X = DX, j.ldx = c, j.n = n, j.K = c, j.O = hw, j.nmat = 1;
                 j.W = Wf + w.w3_wT + hid * c, j.tnks = c >> 4, j.tot0 = j0 >> 5;  // rows j0 .. of w3^T [hid][c]
+#ifdef HAET_STAMP_PHASE_C
+                j.stamp = j0 == 0;
+#endif
                 EB_RUN(j);
             }
             __syncthreads();
@@ -855,7 +862,7 @@ __device__ __forceinline__ void block_bwd(const BwdArgs& a, const BwdDir& T, con
             if (j0 == 0) BSTAMP(24);
             for (int i = threadIdx.x; i < n * hw; i += kBT) {
                 const float h1 = sm[H1 + i], h2 = sm[H2 + i], dg = sm[GG + i];
-                const float sg = 1.0f / (1.0f + __expf(-h1));
+                const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * h1));
                 sm[H2 + i] = dg * (h1 * sg);                            // dh2
                 sm[H1 + i] = dg * h2 * (sg * (1.0f + h1 * (1.0f - sg)));  // dh1
             }

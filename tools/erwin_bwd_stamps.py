@@ -34,3 +34,6 @@ print("per op (reverse order: dec blocks, unpool, bottleneck blocks, pool, enc b
 print("inside eb_phase (phase A of the first chunk, thread 0): entry->barrier+job", t[53] - t[52], "uniform copies", t[54] - t[53],
       "decode + weights requested", t[59] - t[54], "bias / accumulator init (waits for the loads)", t[55] - t[59], "first group requested", t[56] - t[55],
       "k-loop done", t[60] - t[56], "stores + loop end", t[57] - t[60], "db + exit", t[58] - t[57])
+if os.environ.get("STAMP_PHASE_C"):
+    print("phase C (dW3 tile on wave 0 | dg tiles): wgrad tile: gather + MFMA loop", t[62] - t[61], "; from loop end to the phase's tile loop end (stores)", t[57] - t[62],
+          "; entry -> first tile", t[61] - t[52])
