@@ -33,6 +33,22 @@
 
 namespace haet {
 
+// The x / O images of THIS kernel use the chunk swizzle (-(row >> 2)) & 3 instead of slice_mfma_dev.h's (row >> 2) & 3 (round 4).
+// Both are conflict-free for the 32 x 32 x 16 fragment reads of phase [A] (lane = row, the ds_read_b128 lane groups {0-3, 12-15,
+// 20-27}, {4-11, 16-19, 28-31} see rows with row >> 2 = {0, 3, 5, 6} / {1, 2, 4, 7}: four different xor values either way), but
+// phase [B] has read the O image as 16 x 16 x 32 fragments since round 3 (lane = (row % 16, chunk = lane / 16): a lane group
+// sees rows 0-3 and 12-15 with chunk c and rows 4-11 with chunk c + 1), where (row >> 2) & 3 puts rows r and r + 4 on the same
+// banks: SQ_LDS_BANK_CONFLICT 40 M cycles per launch (15 % of the kernel's cycles, profiles/r04_pmc.json).  Rows 8 apart still
+// differ in bit 1 of the xor, so the loader's two-offset scheme holds.  (The Ws images keep the shared layout: stage_ws.)
+__device__ __forceinline__ int do_img_off(int row, int chunk) { return row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4); }
+__device__ __forceinline__ Frag do_read_rows(int img, int row, int chunk) {
+    Frag f;
+    const int off = img + do_img_off(row, chunk);
+    f.hi = *reinterpret_cast<const u32x4*>(smem + off);
+    f.lo = *reinterpret_cast<const u32x4*>(smem + off + IMG);
+    return f;
+}
+
 constexpr int kDO = 256;  // outputs = H * C = 8 * 32
 
 #ifdef HAET_STAMPS
@@ -127,8 +143,8 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
     //   cell e = lane + 64 i: row r = e >> 3 (= (lane >> 3) + 8 i), 16-B cell q = lane & 7 of the head's row
     const int lr = lane >> 3, lq = lane & 7;
     const int ximg = wave * (2 * IMG);
-    // LDS byte offset of the hi half of cell i: rows 8 apart flip bit 1 of the chunk swizzle ((row >> 2) & 3)
-    const int xoff0 = ximg + img_off(lr, lq >> 1) + ((lq & 1) << 3), xoff1 = ximg + img_off(lr + 8, lq >> 1) + ((lq & 1) << 3) - 512;
+    // LDS byte offset of the hi half of cell i: rows 8 apart flip bit 1 of the chunk swizzle (-(row >> 2) & 3)
+    const int xoff0 = ximg + do_img_off(lr, lq >> 1) + ((lq & 1) << 3), xoff1 = ximg + do_img_off(lr + 8, lq >> 1) + ((lq & 1) << 3) - 512;
     auto xoff = [&](int i) { return ((i & 1) ? xoff1 : xoff0) + 512 * i; };
     f32x4 xr[4];
     float sv = 1.f;
@@ -215,7 +231,7 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
         sfh = *reinterpret_cast<const u32x4*>(smem + sfo);
         sfl = *reinterpret_cast<const u32x4*>(smem + sfo + 1024);
         {
-            const Frag x0 = read_rows(hb, l31, hf), x1 = read_rows(hb, l31, 2 + hf);
+            const Frag x0 = do_read_rows(hb, l31, hf), x1 = do_read_rows(hb, l31, 2 + hf);
             bias_init(0);
             if (!(dbg & 1)) {
                 Y = mfma3(read_rows(wimg, l31, hf), x0, Y);
@@ -287,8 +303,8 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
             }
             if (MB == 2 && s_ == 0) {  // Y(1): Y(0) is dead (one exposed LDS latency per tile; the partner wave fills it)
                 __builtin_amdgcn_sched_barrier(0);
-                const Frag x0b = read_rows(hb, l31, hf), w0b = read_rows(wimg + 2 * IMG, l31, hf);
-                const Frag x1b = read_rows(hb, l31, 2 + hf), w1b = read_rows(wimg + 2 * IMG, l31, 2 + hf);
+                const Frag x0b = do_read_rows(hb, l31, hf), w0b = read_rows(wimg + 2 * IMG, l31, hf);
+                const Frag x1b = do_read_rows(hb, l31, 2 + hf), w1b = read_rows(wimg + 2 * IMG, l31, 2 + hf);
                 bias_init(1);
                 if (!(dbg & 1)) {
                     Y = mfma3(w0b, x0b, Y);
@@ -305,8 +321,8 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
             split2(O[4 * i + 2], O[4 * i + 3], h23, l23);
             const u32x2 hi = {h01, h23};
             const u32x2 lo = {l01, l23};
-            // (= hb + img_off(l31, i) + 8 hf: hb is a multiple of 64, so the swizzle's xor on bits 4-5 commutes with the add)
-            const int off = (hb + img_off(l31, 0) + (hf << 3)) ^ (i << 4);
+            // (= hb + do_img_off(l31, i) + 8 hf: hb is a multiple of 64, so the swizzle's xor on bits 4-5 commutes with the add)
+            const int off = (hb + do_img_off(l31, 0) + (hf << 3)) ^ (i << 4);
             *reinterpret_cast<u32x2*>(smem + off) = hi;
             *reinterpret_cast<u32x2*>(smem + off + IMG) = lo;
         }
@@ -326,13 +342,13 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
         // residual rows of this lane's points (the block's `Attn(ln_1(fx)) + fx`, HAETransolver_Irregular_Mesh.py:125)
         f32x4 res[2][2];
         // B operand of k-step h (= head h): column n = 16 jn + lane % 16, k = 8 kg .. 8 kg + 7 of the head's 32 channels
-        Frag oc0 = read_rows(ob_, l15, kg), oc1 = read_rows(ob_, 16 + l15, kg);
+        Frag oc0 = do_read_rows(ob_, l15, kg), oc1 = do_read_rows(ob_, 16 + l15, kg);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             Frag on0, on1;
             if (h + 1 < H) {
-                on0 = read_rows(ob_ + (h + 1) * (2 * IMG), l15, kg);
-                on1 = read_rows(ob_ + (h + 1) * (2 * IMG), 16 + l15, kg);
+                on0 = do_read_rows(ob_ + (h + 1) * (2 * IMG), l15, kg);
+                on1 = do_read_rows(ob_ + (h + 1) * (2 * IMG), 16 + l15, kg);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!(dbg & 2)) {

@@ -480,6 +480,15 @@ int slice_mfma_fwd(const float* x, const float* Ws, const float* bs, const float
         }
         return HAET_OK;
     }
+    if (M == 64 && H == 16 && C == kC && !one_launch) {
+        // H = 16 at M = 64 is four items per wave too (69-71 spilled registers): two launches of its M = 32 variant
+        for (int half = 0; half < 2; ++half) {
+            int rc = slice_mfma_launch(x, Ws + (size_t)32 * half * kC, bs + 32 * half, wt, bt, base_temp, c0, B, N, H, C, 32, parts, st,
+                                       s_in, 64, 32 * half);
+            if (rc != HAET_OK) return rc;
+        }
+        return HAET_OK;
+    }
     return slice_mfma_launch(x, Ws, bs, wt, bt, base_temp, c0, B, N, H, C, M, parts, st, s_in, M, 0);
 }
 
