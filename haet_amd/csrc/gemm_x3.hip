@@ -32,8 +32,11 @@ __device__ __forceinline__ unsigned g_pack(float a, float b) {
     f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
+// (round 4: the chunk swizzle is -(row >> 2) & 3, not (row >> 2) & 3 -- both are conflict-free for fragment reads of the
+// 32 x 32 x 16 shape, only this one also for the 16 x 16 x 32 shape the streaming kernel's products moved to in round 3,
+// whose ds_read_b128 lane groups see rows r and r + 4 together: deslice_out.hip, do_img_off)
 __device__ __forceinline__ int g_off(int row, int chunk) {
-    return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+    return row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4);
 }
 struct GFrag {
     u32x4 hi, lo;
