@@ -8,7 +8,8 @@
 // (median-of-3 to front, unguarded Hoare partition while range > 3, heap-select when
 // the 2*floor(log2 n) budget is spent, insertion sort of the last <= 3), written from
 // the algorithm description in SURVEY.md appendix A.  All nodes of one tree level are
-// independent and run on different lanes of the wave.
+// independent: the large ones take a wave each (wave_select: the same introselect in ballot rounds),
+// the small ones a lane each.
 //
 // Keys are the fp32 positions; the reference converts them to float64 first
 // (balltree.pyx:542), an exact, order-preserving conversion, so fp32 compares give
@@ -23,47 +24,66 @@ namespace haet {
 constexpr int kMaxPts = 128;  // slots per cloud
 constexpr int kMaxDim = 3;
 
-// split every node of level L (one lane each); stop_small: partition_ball_tree's n<=1 exit
-__device__ void split_level(const float* keys, int kstride, int nd, int* idx, int n, int L,
-                            int lane) {
-    if (lane < (1 << L)) {
+#ifndef HAET_TREE_WAVES
+#define HAET_TREE_WAVES 8
+#endif
+constexpr int kTreeWaves = HAET_TREE_WAVES;  // waves of a cloud's workgroup: the wave-selected nodes of a level are dealt to them
+constexpr int kLaneNode = 4;   // (default; HAET_TREE_LANE_NODE overrides it for sweeps) nodes of more items than this are selected by a whole wave (wave_select), smaller ones by a lane
+
+// split every node of level L.  A node of > kLaneNode items takes a wave (ballot rounds of the same introselect: a
+// one-lane select of the 128-item root is ~10^5 cycles of dependent LDS reads, and it was 2/3 of this kernel), the
+// small ones a lane each; both leave std::nth_element's permutation.  ls / rsl: scratch of n ints each.
+__device__ void split_level(const float* keys, int kstride, int nd, int* idx, int* ls, int* rsl, int n, int L, int tid, int lane_node) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (((n + (1 << L) - 1) >> L) > lane_node) {  // (an upper bound of every node size of this level)
+        for (int node = wave; node < (1 << L); node += kTreeWaves) {
+            int s, e;
+            node_range(n, L, node, s, e);
+            if (e - s > lane_node) {
+                const int dim = wave_split_dim(keys, kstride, nd, idx, s, e, lane);
+                wave_select(idx + s, (s + e) / 2 - s, e - s, keys + dim * kstride, ls + s, rsl + s, lane);
+            }
+        }
+    }
+    if (tid < (1 << L)) {
         int s, e;
-        node_range(n, L, lane, s, e);
-        if (e - s > 1) {
+        node_range(n, L, tid, s, e);
+        if (e - s > 1 && e - s <= lane_node) {
             const int dim = split_dim(keys, kstride, nd, idx, s, e);
             select_nth(idx + s, idx + (s + e) / 2, idx + e, keys + dim * kstride);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
 }
 
 struct Rot3 {
     float r[9];
 };
 
-__global__ __launch_bounds__(64) void balltree_kernel(
+__global__ __launch_bounds__(64 * kTreeWaves) void balltree_kernel(
     const float* __restrict__ pos, int M, int nd, int depth, int n_levels, int s0, int s1, int s2,
     int t0, int t1, int t2, int t3, int rotate, Rot3 R, int32_t* __restrict__ tree_idx,
-    uint8_t* __restrict__ tree_mask, int32_t* __restrict__ rot) {
+    uint8_t* __restrict__ tree_mask, int32_t* __restrict__ rot, int lane_node) {
     __shared__ float kmain[kMaxDim * kMaxPts];
     __shared__ float ka[kMaxDim * kMaxPts];
     __shared__ float kb[kMaxDim * kMaxPts];
     __shared__ int idx[kMaxPts];
     __shared__ int tl[kMaxPts];
-    const int lane = threadIdx.x, cloud = blockIdx.x, n_clouds = gridDim.x;
+    __shared__ int ls[kMaxPts];
+    __shared__ int rsl[kMaxPts];
+    constexpr int kT = 64 * kTreeWaves;
+    const int lane = threadIdx.x, cloud = blockIdx.x, n_clouds = gridDim.x;  // (`lane`: the thread of the workgroup)
     const int Mp = 2 << depth;
     const int strides[3] = {s0, s1, s2};
     const int targets[4] = {t0, t1, t2, t3};
 
-    for (int i = lane; i < M; i += 64) {
+    for (int i = lane; i < M; i += kT) {
         idx[i] = i;
         for (int d = 0; d < nd; ++d) kmain[d * kMaxPts + i] = pos[((size_t)cloud * M + i) * nd + d];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     // main tree: balltree.h:121-186
-    for (int L = 0; L < depth; ++L) split_level(kmain, kMaxPts, nd, idx, M, L, lane);
+    for (int L = 0; L < depth; ++L) split_level(kmain, kMaxPts, nd, idx, ls, rsl, M, L, lane, lane_node);
     if (lane < (1 << depth)) {
         int s, e;
         node_range(M, depth, lane, s, e);
@@ -76,12 +96,11 @@ __global__ __launch_bounds__(64) void balltree_kernel(
         tree_mask[o] = 1;
         tree_mask[o + 1] = (e - s == 1) ? 0 : 1;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     if (!rotate) return;
 
     // rotated leaves (balltree.pyx:639-646): fp32 leaves @ R
-    for (int i = lane; i < Mp; i += 64) {
+    for (int i = lane; i < Mp; i += kT) {
         const int p = tl[i];
         for (int j = 0; j < nd; ++j) {
             float acc = kmain[p] * R.r[j];
@@ -94,19 +113,18 @@ __global__ __launch_bounds__(64) void balltree_kernel(
     int n = Mp;
     size_t rot_off = 0;
     for (int lev = 0; lev < n_levels; ++lev) {
-        for (int i = lane; i < n; i += 64) idx[i] = i;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < n; i += kT) idx[i] = i;
+        __syncthreads();
         // balltree.h:205-259: `target` halvings, nodes of <= 1 point stop early
         for (int L = 0; L < targets[lev] && (n >> L) > 1; ++L)
-            split_level(cur, kMaxPts, nd, idx, n, L, lane);
-        for (int i = lane; i < n; i += 64)
+            split_level(cur, kMaxPts, nd, idx, ls, rsl, n, L, lane, lane_node);
+        for (int i = lane; i < n; i += kT)
             rot[rot_off + (size_t)cloud * n + i] = cloud * n + idx[i];
         rot_off += (size_t)n_clouds * n;
         if (lev < n_levels - 1) {
             // mean-pool consecutive `stride` leaves (balltree.pyx:658-660)
             const int st = strides[lev], n2 = n / st;
-            for (int i = lane; i < n2; i += 64)
+            for (int i = lane; i < n2; i += kT)
                 for (int j = 0; j < nd; ++j) {
                     float sum = cur[j * kMaxPts + i * st];
                     for (int q = 1; q < st; ++q) sum += cur[j * kMaxPts + i * st + q];
@@ -116,8 +134,7 @@ __global__ __launch_bounds__(64) void balltree_kernel(
             cur = nxt;
             nxt = t;
             n = n2;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            __syncthreads();
         }
     }
 }
@@ -188,9 +205,14 @@ static int balltree_build_impl(const float* pos, int n_clouds, int M, int d, int
         const int rc = token_pos_launch(S, n_clouds * M, C, d, const_cast<float*>(pos), as_stream(stream));
         if (rc != HAET_OK) return rc;
     }
-    hipLaunchKernelGGL(balltree_kernel, dim3(n_clouds), dim3(64), 0, as_stream(stream), pos, M, d,
+    static const int lane_node = [] {
+        const char* e = getenv("HAET_TREE_LANE_NODE");
+        const int v = e ? atoi(e) : kLaneNode;
+        return v < 1 ? 1 : v;
+    }();
+    hipLaunchKernelGGL(balltree_kernel, dim3(n_clouds), dim3(64 * kTreeWaves), 0, as_stream(stream), pos, M, d,
                        depth, n_levels, st[0], st[1], st[2], tg[0], tg[1], tg[2], tg[3], rotate, R,
-                       tree_idx, tree_mask, rot);
+                       tree_idx, tree_mask, rot, lane_node);
     return check_launch("balltree_kernel");
 }
 

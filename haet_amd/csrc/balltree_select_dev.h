@@ -145,4 +145,98 @@ __device__ __forceinline__ void node_range(int n, int L, int j, int& s, int& e) 
     }
 }
 
+// ------------------------------------------------------------------------- one wave on one node (LDS arrays)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// std::nth_element(W, W + nth, W + n) by ONE WAVE on LDS arrays: the rounds of big_top_kernel with ballots instead of
+// workgroup scans.  ls / rsl: scratch of n ints each.
+__device__ void wave_select(int* W, int nth, int n, const float* kd, int* ls, int* rsl, int lane) {
+    int first = 0, last = n;
+    int depth = 2 * (31 - __clz(n));
+    while (last - first > 3) {
+        if (depth == 0) {
+            if (lane == 0) {
+                heap_select_(W + first, W + nth + 1, W + last, kd);
+                swp(W + first, W + nth);
+            }
+            wave_sync();
+            return;
+        }
+        --depth;
+        if (lane == 0) {
+            int *a = W + first + 1, *b = W + first + (last - first) / 2, *c = W + last - 1, *f = W + first;
+            if (lt(kd, *a, *b)) {
+                if (lt(kd, *b, *c)) swp(f, b);
+                else if (lt(kd, *a, *c)) swp(f, c);
+                else swp(f, a);
+            } else if (lt(kd, *a, *c)) swp(f, a);
+            else if (lt(kd, *b, *c)) swp(f, c);
+            else swp(f, b);
+        }
+        wave_sync();
+        const float v = kd[W[first]];
+        int nL = 0, nR = 0;  // stoppers inside [first + 1, last), ranked from the left
+        for (int p0 = first + 1; p0 < last; p0 += 64) {
+            const int p = p0 + lane;
+            const float x = p < last ? kd[W[p]] : 0.f;
+            const bool isl = p < last && !(x < v), isr = p < last && !(v < x);
+            const unsigned long long ml = __ballot(isl), mr = __ballot(isr), below = (1ull << lane) - 1ull;
+            if (isl) ls[nL + __popcll(ml & below)] = p;
+            if (isr) rsl[nR + __popcll(mr & below)] = p;
+            nL += __popcll(ml);
+            nR += __popcll(mr);
+        }
+        wave_sync();
+        // k-th right stopper from the right; the pivot's slot is the last one
+        auto Rk = [&](int k) { return k < nR ? rsl[nR - 1 - k] : first; };
+        const int kmax = min(nL, nR + 1);
+        int K = 0;
+        for (int k0 = 0; k0 < kmax; k0 += 64) {
+            const int k = k0 + lane;
+            K += __popcll(__ballot(k < kmax && ls[k] < Rk(k)));
+        }
+        const int bound = K > 0 ? Rk(K - 1) : last;
+        int cut = bound;
+        if (K < nL) {
+            const int Lk = ls[K];
+            cut = Lk < bound ? Lk : bound;
+        }
+        for (int k = lane; k < K; k += 64) {
+            const int a = ls[k], b = Rk(k);
+            const int t = W[a];
+            W[a] = W[b];
+            W[b] = t;
+        }
+        wave_sync();
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    if (lane == 0) insertion_sort_(W + first, W + last, kd);
+    wave_sync();
+}
+
+// balltree.h:32-66 by one wave
+__device__ int wave_split_dim(const float* keys, int kstride, int nd, const int* idx, int s, int e, int lane) {
+    int best = 0;
+    double best_spread = 0.0;
+    for (int k = 0; k < nd; ++k) {
+        const float* kd = keys + k * kstride;
+        float lo = INFINITY, hi = -INFINITY;
+        for (int i = s + lane; i < e; i += 64) {
+            const float v = kd[idx[i]];
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+        const double spread = (double)hi - (double)lo;
+        if (spread > best_spread) best_spread = spread, best = k;
+    }
+    return best;
+}
+
 }  // namespace haet
