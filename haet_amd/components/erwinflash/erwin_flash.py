@@ -199,7 +199,7 @@ class ErwinTransformer(nn.Module):
     def __getstate__(self):
         # weight-derived caches hold ctypes descriptors and device scratch: never pickled, rebuilt at the next forward
         state = dict(self.__dict__)
-        for k in ("_train_cache", "_packed_f32", "_packed_frags", "_fits_memo", "_pack_tensors", "last_positions"):
+        for k in ("_train_cache", "_packed_f32", "_packed_frags", "_fits_memo", "_pack_tensors", "_plan_fwd", "_plan_f32", "last_positions"):
             state.pop(k, None)
         state["_packed"] = None
         state["_pack_stale"] = True
@@ -218,13 +218,25 @@ class ErwinTransformer(nn.Module):
 
     def packed(self):
         """(weights blob, desc) for haet_erwin_fwd, rebuilt only when a parameter changed."""
-        from .pack import pack_erwin
-
         key = (self._pack_key(), self.training)
         if self._packed is None or self._packed[0] != key:
-            blob, desc = pack_erwin(self)
-            self._packed = (key, blob, desc)
+            plan = self._pack_plan("_plan_fwd", self.training)
+            self._packed = (key, plan.run(), plan.desc)
         return self._packed[1], self._packed[2]
+
+    def _pack_plan(self, slot: str, mode):
+        """The blob's layout as a gather plan (pack.py ErwinPackPlan / ErwinF32PackPlan): built once per set of parameter
+        OBJECTS (and mode), so that a repack after an optimizer step is ~8 launches instead of ~400 (call after _pack_key())."""
+        from .pack import ErwinF32PackPlan, ErwinPackPlan
+
+        ts = self.__dict__["_pack_tensors"]  # (a new list object whenever the tensor objects may have changed)
+        hit = self.__dict__.get(slot)
+        if hit is None or hit[0] is not ts:
+            hit = (ts, {})
+            self.__dict__[slot] = hit
+        if mode not in hit[1]:  # (train and eval plans side by side: a validation pass per epoch rebuilds neither)
+            hit[1][mode] = (ErwinPackPlan if slot == "_plan_fwd" else ErwinF32PackPlan)(self)
+        return hit[1][mode]
 
     def packed_frags(self, M: int):
         """The fragment-order weight blob of the fragment kernel (csrc/erwin2.hip) for clouds of M tokens, or None
@@ -318,12 +330,11 @@ class ErwinTransformer(nn.Module):
     # ------------------------------------------------------------------ training: forward with a tape, HIP backward
     def packed_f32(self):
         """(fp32 blob, layout, [(parameter, offset)]) for haet_erwin_bwd, rebuilt only when a parameter changed."""
-        from .pack import pack_erwin_f32
-
         key = self._pack_key()
         hit = self.__dict__.get("_packed_f32")
         if hit is None or hit[0] != key:
-            hit = (key,) + tuple(pack_erwin_f32(self))
+            plan = self._pack_plan("_plan_f32", None)
+            hit = (key, plan.run(), plan.lay, plan.pmap)
             self.__dict__["_packed_f32"] = hit
         return hit[1], hit[2], hit[3]
 

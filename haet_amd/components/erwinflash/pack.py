@@ -215,3 +215,269 @@ def pack_erwin_f32(erwin):
     lay.total = state["n"]
     hdr = torch.frombuffer(bytearray(bytes(lay)) + bytearray(head * 4 - ctypes.sizeof(lay)), dtype=torch.float32).to(device)
     return torch.cat([hdr] + chunks).contiguous(), lay, pmap
+
+
+# --------------------------------------------------------------------------- gather plans (round 4)
+# pack_erwin / pack_erwin_f32 above are ~12 torch ops per Linear: ~400 launches per ErwinTransformer and repack.  At
+# inference the blob is built once; in TRAINING every optimizer step changes the weights, so every step repacks -- at the
+# reference's PDE-benchmark widths (8 layers, n_hidden 128, 1k-17k points: benchmarks/04-.../scripts/*.sh) that was 2/3 of
+# the ~4 000 launches of a step, and the step was host-bound at 66-110 ms.  Both blobs are pure rearrangements of the
+# parameters (plus the bf16 hi / lo split), so the layout is computed ONCE as an index tensor -- by the same sequence of
+# reshape / pad / permute / cat, applied to the elements' source INDICES instead of their values -- and a repack is
+#     flat = cat(parameters);  hi = bf16(flat);  lo = bf16(flat - hi);  blob = cat(flat | hi | lo | header)[plan]
+# i.e. ~8 launches whatever the depth.  tests/test_modules_cpu.py holds the plans to the direct packers bit for bit.
+class _Sources:
+    """The live tensors a blob is made of, in first-use order; `sym(t)` = t's element indices in their concatenation."""
+
+    def __init__(self):
+        self.items, self.base, self.n = [], {}, 0
+
+    def sym(self, t):
+        k = id(t)
+        if k not in self.base:
+            self.base[k] = self.n
+            self.items.append(t)
+            self.n += t.numel()
+        return torch.arange(self.base[k], self.base[k] + t.numel(), dtype=torch.int64).reshape(t.shape)
+
+    def computed(self, fn, numel):
+        """A derived vector (eval-mode BatchNorm folded to scale / shift): `fn()` is evaluated at every repack."""
+        off = self.n
+        self.items.append(fn)
+        self.n += numel
+        return torch.arange(off, off + numel, dtype=torch.int64)
+
+    def flat(self, device):
+        """fp32 concatenation of the sources, plus one trailing 0.0 (what every padding element gathers).  The flattened
+        fp32 views of the live tensors are kept between calls (an optimizer step writes into the same storage); a view is
+        re-made when its tensor's storage moved (`p.data = ...`)."""
+        views = self.__dict__.get("_views")
+        if views is None or views[0] != str(device):
+            views = (str(device), [None] * len(self.items), [0] * len(self.items), torch.zeros(1, device=device))
+            self._views = views
+        _, vs, ptrs, zero = views
+        for i, t in enumerate(self.items):
+            if callable(t):
+                vs[i] = t().reshape(-1).to(device=device, dtype=torch.float32)
+            elif vs[i] is None or ptrs[i] != t.data_ptr():
+                v = t.detach().reshape(-1)
+                direct = v.device == zero.device and v.dtype == torch.float32 and t.is_contiguous()  # (else reshape / to made a copy)
+                vs[i] = v if direct else v.to(device=device, dtype=torch.float32)
+                ptrs[i] = t.data_ptr() if direct else -1  # (a converted copy is re-made every time)
+        return torch.cat(vs + [zero])
+
+
+class _SymBlob:
+    """_Blob on indices: parts are ('f32', idx) = fp32 words or ('b16', enc) = bf16 elements with enc = 2 * source + plane
+    (plane 0 = hi, 1 = lo); index -1 = zero."""
+
+    def __init__(self):
+        self.parts, self.n = [], HEADER_FLOATS
+
+    def _pad(self):
+        pad = (-self.n) % 4
+        if pad:
+            self.parts.append(("f32", torch.full((pad,), -1, dtype=torch.int64)))
+            self.n += pad
+
+    def add(self, sym):
+        sym = sym.reshape(-1)
+        self._pad()
+        off = self.n
+        self.parts.append(("f32", sym))
+        self.n += sym.numel()
+        return off
+
+    def planes(self, w):
+        pad = (-w.shape[1]) % 32
+        if pad:
+            w = torch.nn.functional.pad(w, (0, pad), value=-1)
+        hi = torch.where(w >= 0, 2 * w, w)
+        lo = torch.where(w >= 0, 2 * w + 1, w)
+        O, Kp = w.shape
+        nto, nks = (O + 15) // 16, Kp // 32
+        both = torch.stack([hi, lo])
+        if nto * 16 != O:
+            both = torch.nn.functional.pad(both, (0, 0, 0, nto * 16 - O), value=-1)
+        tiled = both.reshape(2, nto, 16, nks, 4, 8).permute(1, 3, 0, 4, 2, 5)
+        enc = torch.cat([hi.reshape(-1), lo.reshape(-1), tiled.reshape(-1)])
+        self._pad()
+        off = self.n
+        self.parts.append(("b16", enc))
+        self.n += enc.numel() // 2
+        return off
+
+    def end_group(self, start):
+        self._pad()
+        return start, self.n - start
+
+    def index16(self, n_src):
+        """Index of every 16-bit unit of the blob into  [flat as int16 (2 (n+1)) | hi (n+1) | lo (n+1) | header]."""
+        self._pad()
+        n1 = n_src + 1
+        out = [4 * n1 + torch.arange(2 * HEADER_FLOATS, dtype=torch.int64)]
+        for kind, v in self.parts:
+            if kind == "f32":
+                s = torch.where(v >= 0, v, torch.full_like(v, n_src))
+                out.append(torch.stack([2 * s, 2 * s + 1], dim=1).reshape(-1))
+            else:
+                s, plane = v >> 1, v & 1
+                out.append(torch.where(v >= 0, (2 + plane) * n1 + s, torch.full_like(v, 2 * n1 + n_src)))
+        return torch.cat(out)
+
+
+def _sym_layer(dst, layer, blob, src):
+    dst.c, dst.heads, dst.ball = layer.hidden_dim, layer.num_heads, layer.ball_size
+    dst.depth, dst.hidden = len(layer.blocks), layer.hidden_dim * layer.mlp_ratio
+    if dst.depth > MAX_DEPTH:
+        raise HaetError(f"Erwin layer depth {dst.depth} > {MAX_DEPTH}")
+    for j, blk in enumerate(layer.blocks):
+        w = dst.blocks[j]
+        w.norm1 = blob.add(src.sym(blk.norm1.weight))
+        w.norm2 = blob.add(src.sym(blk.norm2.weight))
+        w.pe_w = blob.add(src.sym(blk.BMSA.pe_proj.weight).t())
+        w.pe_b = blob.add(src.sym(blk.BMSA.pe_proj.bias))
+        w.qkv_b = blob.add(src.sym(blk.BMSA.qkv.bias))
+        w.proj_b = blob.add(src.sym(blk.BMSA.proj.bias))
+        w.w1_b = blob.add(src.sym(blk.swiglu.w1.bias))
+        w.w2_b = blob.add(src.sym(blk.swiglu.w2.bias))
+        w.w3_b = blob.add(src.sym(blk.swiglu.w3.bias))
+        w.small_off, w.small_len = blob.end_group(w.norm1)
+        w.qkv_w = blob.planes(src.sym(blk.BMSA.qkv.weight))
+        w.proj_w = blob.planes(src.sym(blk.BMSA.proj.weight))
+        w.w1_w = blob.planes(src.sym(blk.swiglu.w1.weight))
+        w.w2_w = blob.planes(src.sym(blk.swiglu.w2.weight))
+        w.w3_w = blob.planes(src.sym(blk.swiglu.w3.weight))
+
+
+def _sym_resample(dst, mod, blob, src, train):
+    dst.stride = mod.stride
+    bn = mod.norm
+    dst.bn_eps = float(bn.eps)
+    dst.bn_momentum = float(bn.momentum) if bn.momentum is not None else 0.0
+    dst.b = blob.add(src.sym(mod.proj.bias))
+    if train:
+        dst.bn_scale = blob.add(src.sym(bn.weight))
+        dst.bn_shift = blob.add(src.sym(bn.bias))
+    else:  # (the same expressions as _fill_resample, evaluated at every repack)
+        def scale():
+            return bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+
+        def shift():
+            return bn.bias.detach().float() - bn.running_mean.float() * scale()
+
+        dst.bn_scale = blob.add(src.computed(scale, bn.weight.numel()))
+        dst.bn_shift = blob.add(src.computed(shift, bn.weight.numel()))
+    dst.small_off, dst.small_len = blob.end_group(dst.b)
+    dst.w = blob.planes(src.sym(mod.proj.weight))
+
+
+class ErwinPackPlan:
+    """Layout of pack_erwin's blob (for the module's current mode) as a gather; `run()` = the blob of the current weights.
+    The descriptor is part of the plan: it holds offsets and hyper-parameters only, so it is the same object for every repack."""
+
+    def __init__(self, erwin):
+        n_levels = len(erwin.encoder) + 1
+        if n_levels > MAX_LEVELS:
+            raise HaetError(f"Erwin with {n_levels} levels > {MAX_LEVELS}")
+        self.device = next(erwin.parameters()).device
+        desc, blob, src = ErwinDesc(), _SymBlob(), _Sources()
+        desc.n_levels, desc.d = n_levels, erwin.dimensionality
+        desc.rotate, desc.decode = int(erwin.rotate > 0), int(bool(erwin.decode))
+        train = bool(erwin.training)
+        desc.bn_train = int(train)
+        for i, layer in enumerate(erwin.encoder):
+            _sym_layer(desc.enc[i], layer, blob, src)
+            _sym_resample(desc.pool[i], layer.pool, blob, src, train)
+        _sym_layer(desc.enc[n_levels - 1], erwin.bottleneck, blob, src)
+        for k, layer in enumerate(erwin.decoder):
+            lvl = n_levels - 2 - k
+            _sym_layer(desc.dec[lvl], layer, blob, src)
+            _sym_resample(desc.unpool[lvl], layer.unpool, blob, src, train)
+        self.desc, self.src = desc, src
+        self.index = blob.index16(src.n).to(torch.int32).to(self.device)
+        hdr = bytearray(bytes(desc)) + bytearray(HEADER_FLOATS * 4 - ctypes.sizeof(desc))
+        self.hdr16 = torch.frombuffer(hdr, dtype=torch.int16).to(self.device)
+
+    def run(self, flat=None):
+        if flat is None:
+            flat = self.src.flat(self.device)
+        hi = flat.to(torch.bfloat16)
+        lo = (flat - hi.float()).to(torch.bfloat16)
+        pool = torch.cat([flat.view(torch.int16), hi.view(torch.int16), lo.view(torch.int16), self.hdr16])
+        return torch.index_select(pool, 0, self.index).view(torch.float32)
+
+
+class ErwinF32PackPlan:
+    """Layout of pack_erwin_f32's blob as a gather of fp32 words; `.lay`, `.pmap` as pack_erwin_f32 returns them."""
+
+    def __init__(self, erwin):
+        from ..._lib import ErwinF32Layout
+
+        n_levels = len(erwin.encoder) + 1
+        self.device = next(erwin.parameters()).device
+        lay, src = ErwinF32Layout(), _Sources()
+        head = (ctypes.sizeof(ErwinF32Layout) + 15) // 16 * 4
+        parts, pmap = [], []
+        state = {"n": head}
+
+        def add(sym, param=None):
+            sym = sym.reshape(-1)
+            off = state["n"]
+            parts.append(sym)
+            state["n"] += sym.numel()
+            pad = (-state["n"]) % 4
+            if pad:
+                parts.append(torch.full((pad,), -1, dtype=torch.int64))
+                state["n"] += pad
+            if param is not None:
+                pmap.append((param, off))
+            return off
+
+        def tiled(w):
+            R, K = w.shape
+            if R % 32 or K % 16:
+                return torch.full((R * K,), -1, dtype=torch.int64)
+            return w.reshape(R // 32, 32, K // 16, 2, 2, 4).permute(0, 2, 4, 3, 1, 5).reshape(-1)
+
+        def fill_block(dst, blk):
+            a = blk.BMSA
+            dst.norm1, dst.norm2 = add(src.sym(blk.norm1.weight), blk.norm1.weight), add(src.sym(blk.norm2.weight), blk.norm2.weight)
+            dst.pe_w, dst.pe_b = add(src.sym(a.pe_proj.weight), a.pe_proj.weight), add(src.sym(a.pe_proj.bias), a.pe_proj.bias)
+            for name, lin in (("qkv", a.qkv), ("proj", a.proj), ("w1", blk.swiglu.w1), ("w2", blk.swiglu.w2), ("w3", blk.swiglu.w3)):
+                w = src.sym(lin.weight)
+                setattr(dst, name + "_w", add(w, lin.weight))
+                add(tiled(w))
+                setattr(dst, name + "_wT", add(w.t()))
+                add(tiled(w.t()))
+                setattr(dst, name + "_b", add(src.sym(lin.bias), lin.bias))
+
+        def fill_resample(dst, mod):
+            w = src.sym(mod.proj.weight)
+            dst.w, dst.wT = add(w, mod.proj.weight), add(w.t())
+            dst.b = add(src.sym(mod.proj.bias), mod.proj.bias)
+            dst.gamma, dst.beta = add(src.sym(mod.norm.weight), mod.norm.weight), add(src.sym(mod.norm.bias), mod.norm.bias)
+            dst.rmean, dst.rvar = add(src.sym(mod.norm.running_mean)), add(src.sym(mod.norm.running_var))
+
+        for i, layer in enumerate(erwin.encoder):
+            for j, blk in enumerate(layer.blocks):
+                fill_block(lay.enc[i][j], blk)
+            fill_resample(lay.pool[i], layer.pool)
+        for j, blk in enumerate(erwin.bottleneck.blocks):
+            fill_block(lay.enc[n_levels - 1][j], blk)
+        for k, layer in enumerate(erwin.decoder):
+            lvl = n_levels - 2 - k
+            for j, blk in enumerate(layer.blocks):
+                fill_block(lay.dec[lvl][j], blk)
+            fill_resample(lay.unpool[lvl], layer.unpool)
+        lay.total = state["n"]
+        self.lay, self.pmap, self.src = lay, pmap, src
+        hdr = bytearray(bytes(lay)) + bytearray(head * 4 - ctypes.sizeof(lay))
+        self.hdr = torch.frombuffer(hdr, dtype=torch.float32).to(self.device)
+        n1 = src.n + 1
+        idx = torch.cat(parts)
+        idx = torch.where(idx >= 0, idx, torch.full_like(idx, src.n))
+        self.index = torch.cat([n1 + torch.arange(head, dtype=torch.int64), idx]).to(torch.int32).to(self.device)
+
+    def run(self):
+        return torch.index_select(torch.cat([self.src.flat(self.device), self.hdr]), 0, self.index)

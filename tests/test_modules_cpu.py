@@ -86,6 +86,44 @@ def test_pack_erwin_layout():
     assert 0 < _lib.load().haet_erwin_lds_bytes(ctypes.byref(desc), 64) < 160 * 1024
 
 
+@pytest.mark.parametrize("kw", [
+    dict(dim=64, heads=4, dim_head=16, slice_num=16, rotate=45),
+    dict(dim=256, heads=8, dim_head=32, slice_num=64, rotate=45),
+    dict(dim=128, heads=4, dim_head=64, slice_num=32, rotate=0),
+    dict(dim=64, heads=4, dim_head=16, slice_num=12, rotate=45, ball_sizes=[16, 8]),
+    dict(dim=64, heads=4, dim_head=16, slice_num=16, rotate=45, strides=[1], c_hidden=[16, 16], ball_sizes=[16, 8]),
+])
+def test_pack_plans_equal_the_direct_packers_bit_for_bit(kw):
+    """What the modules pack with since round 4 -- the blob layouts as gather plans (pack.py ErwinPackPlan /
+    ErwinF32PackPlan: ~8 launches per repack instead of ~400, the training step of the reference's PDE configurations was
+    host-bound on the repack) -- against the direct packers: same bits, same descriptor / layout / gradient map, in both
+    modes, and again after the weights and the BatchNorm statistics changed (the plan is reused, the blob follows)."""
+    from haet_amd.components.erwinflash import pack
+
+    torch.manual_seed(1)
+    er = Physics_Attention_Irregular_Mesh(**kw).erwin
+    plans = {}
+    for round_ in range(2):
+        with torch.no_grad():
+            for b in er.buffers():
+                if b.dtype.is_floating_point:
+                    b.uniform_(0.5, 1.5)
+            for q in er.parameters():
+                q.add_(torch.randn_like(q) * 0.01)
+        for mode in (True, False):
+            er.train(mode)
+            blob, desc = pack.pack_erwin(er)
+            got, gdesc = er.packed()
+            assert torch.equal(blob.view(torch.int32), got.view(torch.int32))
+            assert bytes(desc) == bytes(gdesc)
+            plan = er.__dict__["_plan_fwd"][1][mode]
+            assert plans.setdefault(mode, plan) is plan  # (same parameter objects: the layout is not recomputed)
+        b32, lay, pmap = pack.pack_erwin_f32(er)
+        g32, glay, gpmap = er.packed_f32()
+        assert torch.equal(b32.view(torch.int32), g32.view(torch.int32))
+        assert bytes(lay) == bytes(glay) and [(id(q), o) for q, o in pmap] == [(id(q), o) for q, o in gpmap]
+
+
 def test_rot_targets_use_total_leaf_count():
     from haet_amd.ops import rot_targets, tree_slots
 
