@@ -501,18 +501,28 @@ def conv_wgrad(g: Tensor, x: Tensor, grid: Tuple[int, ...], kernel: Tuple[int, .
         raise HaetError("conv_wgrad: tensors do not match the grid")
     P = lib.haet_linear_wgrad_num_parts(B * N)
     ob, kb = (O + 255) // 256, (Cin + 255) // 256
-    parts = torch.empty((P, ob * kb, 256 * 256 + 256), dtype=torch.float32, device=g.device)
-    dW = torch.empty((O, Cin) + ks, dtype=torch.float32, device=g.device)
+    taps = [(a, b, c) for a in range(ks[0]) for b in range(ks[1]) for c in range(ks[2])]
+    rec = 256 * 256 + 256
+    # the taps' split-K partials side by side, ONE reduction and one scatter into dW per group of taps (a launch-bound
+    # regime at the PDE benchmarks' grids: 3 launches per tap were 27 of a layer's backward); groups of <= 256 MB
+    group = max(1, min(len(taps), (256 << 20) // (P * ob * kb * rec * 4)))
+    parts = torch.empty((group, P, ob * kb, rec), dtype=torch.float32, device=g.device)
+    dW = torch.empty((O, Cin, len(taps)), dtype=torch.float32, device=g.device)
     db = None
-    for a in range(ks[0]):
-        for b in range(ks[1]):
-            for c in range(ks[2]):
-                check(lib.haet_conv_wgrad_tap(_p(g), _p(x), B, gH, gW, gD, O, Cin, a - ks[0] // 2, b - ks[1] // 2,
-                                              c - ks[2] // 2, _p(parts), _stream()), "haet_conv_wgrad_tap")
-                s = parts.sum(dim=0)
-                dW[:, :, a, b, c] = s[:, :256 * 256].view(ob, kb, 256, 256).permute(0, 2, 1, 3).reshape(ob * 256, kb * 256)[:O, :Cin]
-                if db is None:
-                    db = s[:, 256 * 256:].view(ob, kb, 256)[:, 0].reshape(ob * 256)[:O].clone()
+    ro, rc = min(O, 256), min(Cin, 256)  # (one tile: only its O x Cin corner is summed)
+    for t0 in range(0, len(taps), group):
+        n = min(group, len(taps) - t0)
+        for i, (a, b, c) in enumerate(taps[t0:t0 + n]):
+            check(lib.haet_conv_wgrad_tap(_p(g), _p(x), B, gH, gW, gD, O, Cin, a - ks[0] // 2, b - ks[1] // 2,
+                                          c - ks[2] // 2, _p(parts[i]), _stream()), "haet_conv_wgrad_tap")
+        tiles = parts[:n, :, :, :256 * 256].view(n, P, ob, kb, 256, 256)
+        if ob * kb == 1:
+            s = tiles[:, :, 0, 0, :ro, :rc].sum(dim=1)                                  # [n, O, Cin]
+        else:
+            s = tiles.sum(dim=1).permute(0, 1, 3, 2, 4).reshape(n, ob * 256, kb * 256)[:, :O, :Cin]
+        dW[:, :, t0:t0 + n] = s.permute(1, 2, 0)
+        if db is None:
+            db = parts[0, :, :, 256 * 256:].sum(dim=0).view(ob, kb, 256)[:, 0].reshape(ob * 256)[:O].clone()
     return dW.reshape((O, Cin) + tuple(kernel)), db
 
 
