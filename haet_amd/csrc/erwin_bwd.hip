@@ -1246,6 +1246,11 @@ static bool bwd_directory(const haet_erwin_desc& D, int Mp, BwdDir* T, int* HB_o
     T->R2 = p; p += 2 * nmax;
     T->ST = p; p += st_floats;
     T->REL = p; p += (nmax * d + 3) & ~3;
+    // a cloud that misses 160 KB by less than the staging tile keeps a smaller tile (gemm() takes any size >= one weight
+    // column: fewer output columns per staged tile) -- 128 tokens x 16 channels, the reference's elasticity
+    // configuration (n_hidden 128 / 8 heads, slice_num 128), misses by 1 KB with the full tile
+    const int avail = 160 * 1024 / 4 - p;
+    if (avail < wstage && avail >= 1024) wstage = avail & ~255;
     T->WST = p; p += wstage;
     T->WSTG = T->WST | wstage << 16;
     T->total = p;
