@@ -6,14 +6,16 @@ node, `PhysicsAttentionFunction`, whose N-scaled work is all on the HIP kernels:
     forward   projection GEMM / conv -> slice pass -> merge -> Erwin -> de-slice -> to_out GEMM
     backward  g_out = gy . W_out (GEMM) -> haet_deslice_bwd_tokens (dS2) -> Erwin backward (dS)
               -> haet_slice_bwd_points (dx_lin + the Rep-Slice / Ada-Temp parameter gradients)
-              -> gx = dx_lin . W_in (GEMM); the two weight gradients are plain library GEMMs (rocBLAS)
+              -> gx = dx_lin . W_in (GEMM); the two weight gradients are the split-bf16 G^T.X kernel (csrc/gemm_tn.hip)
 
-The [B,H,N,M] slice-weight tensor is never materialised in either direction.  Only the Erwin stage --
-T = B*H*M tokens (512 at the 1M-point config), independent of N -- still differentiates through this
-file's torch restatement of it (`erwin_forward`, against models/components/erwinflash/*): in eval mode
-the forward uses the Erwin HIP kernel and the backward re-runs the restatement on the saved tokens; in
-train mode (BatchNorm batch statistics over all clouds, running-stat updates) the restatement runs in
-the forward and its graph is kept.  The ball tree comes from the HIP builder either way
+The [B,H,N,M] slice-weight tensor is never materialised in either direction.  The Erwin stage -- T = B*H*M tokens
+(512 at the 1M-point config), independent of N -- runs forward on the HIP kernel with a tape and backward on the
+hand-written `haet_erwin_bwd` (one launch; `ErwinTransformer.forward_taped` / `backward_hip`) wherever one cloud fits that
+kernel's LDS plan (`haet_erwin_bwd_supported`: clouds of <= 64 tokens at 32 channels, 128 tokens at 16 channels).  Outside
+it (C5's 128 tokens x 32 channels) the stage differentiates through this file's torch restatement (`erwin_forward`,
+against models/components/erwinflash/*): in eval mode the forward uses the Erwin HIP kernel and the backward re-runs the
+restatement on the saved tokens; in train mode (BatchNorm batch statistics over all clouds, running-stat updates) the
+restatement runs in the forward and its graph is kept.  The ball tree comes from the HIP builder either way
 (`ops.balltree_build`, bit-identical to the reference's host builder): no CPU round trip, no path
 without libhaet_hip.so.  `attention_forward` is the whole module as stock torch ops on the device --
 the A/B reference of the tests (and `HipForwardTorchBackward`, the previous interim backward).
