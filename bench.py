@@ -17,6 +17,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
                   host cores of this box on the same 1M-point input (rank 0, N = 1 only)
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -107,6 +108,12 @@ def main():
     x = x_full[:, a:b].contiguous().to(dev)
     if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
         del x_full
+
+    # A FULL collection of this process's heap (torch and what it imports lazily: ~10^6 tracked objects) takes ~75 ms
+    # (tools/stall_probe.py) -- 50 steps of the timed region if one lands there.  Everything alive now is moved out of the
+    # collector's reach; the collector stays ON and walks what the loop itself allocates.
+    gc.collect()
+    gc.freeze()
 
     def sync():
         torch.cuda.synchronize()

@@ -26,6 +26,10 @@ CONFIGS = [
     ("plasticity 101x31 M=64, Time_Input (HAETransolver_Plas.sh)", S2, dict(space_dim=2, n_layers=8, n_hidden=128, n_head=8, Time_Input=True, fun_dim=1, out_dim=4, slice_num=64, unified_pos=0, H=101, W=31), 8, 101 * 31, 1, True, 0.1),
 ]
 only = os.environ.get("PDE_ONLY")
+import gc
+
+gc.collect()
+gc.freeze()  # (a full collection of the import-time heap is a ~75 ms stall: tools/stall_probe.py)
 for name, cls, kw, B, N, fd, tin, clip in CONFIGS:
     if only and only not in name:
         continue
