@@ -239,7 +239,7 @@ class PhysicsAttentionFunction(torch.autograd.Function):
                 share = 1.0 / dist.get_world_size(mod.shard_group)
 
         with ev("bwd_erwin"):
-            erwin_params = [p for p in mod.erwin.parameters() if id(p) in wanted]
+            erwin_params = [p for p in mod.erwin.param_list() if id(p) in wanted]
             if ctx.erwin_ctx is not None:  # hand-written backward of the whole stage, one launch
                 dS, by_param = mod.erwin.backward_hip(ctx.erwin_ctx, dS2)
                 ctx.erwin_ctx = None

@@ -185,13 +185,10 @@ class ErwinTransformer(nn.Module):
         # with assign=True (-> post hook, which also fires for an ancestor's load) or a parameter / buffer
         # re-assigned by hand on a submodule (-> torch's global registration hooks bump
         # _lib.cache_generation(), seen here at the very next forward).
-        d = self.__dict__
-        ts = d.get("_pack_tensors")
-        gen = _lib.cache_generation()
-        if ts is None or d.get("_pack_stale", True) or d.get("_pack_gen") != gen:
-            ts = list(self.parameters()) + list(self.buffers())
-            d["_pack_tensors"], d["_pack_stale"], d["_pack_gen"] = ts, False, gen
-        return tuple([(t.data_ptr(), t._version) for t in ts] + [(-1, _lib.invalidate_epoch())])
+        ts = self._tensor_list()
+        # (_stats_epoch: train-mode launches update the BatchNorm running statistics through raw pointers, which bumps no
+        # `_version` -- an eval-mode blob folded from the old statistics must not survive them)
+        return tuple([(t.data_ptr(), t._version) for t in ts] + [(-1, _lib.invalidate_epoch()), (-2, self.__dict__.get("_stats_epoch", 0))])
 
     def _mark_stale(self, *_):
         self.__dict__["_pack_stale"] = True
@@ -199,7 +196,7 @@ class ErwinTransformer(nn.Module):
     def __getstate__(self):
         # weight-derived caches hold ctypes descriptors and device scratch: never pickled, rebuilt at the next forward
         state = dict(self.__dict__)
-        for k in ("_train_cache", "_packed_f32", "_packed_frags", "_fits_memo", "_pack_tensors", "_plan_fwd", "_plan_f32", "last_positions"):
+        for k in ("_train_cache", "_packed_f32", "_packed_frags", "_fits_memo", "_pack_tensors", "_pack_params", "_plans_hit", "_flat_hit", "_stats_epoch", "last_positions"):
             state.pop(k, None)
         state["_packed"] = None
         state["_pack_stale"] = True
@@ -220,23 +217,63 @@ class ErwinTransformer(nn.Module):
         """(weights blob, desc) for haet_erwin_fwd, rebuilt only when a parameter changed."""
         key = (self._pack_key(), self.training)
         if self._packed is None or self._packed[0] != key:
-            plan = self._pack_plan("_plan_fwd", self.training)
-            self._packed = (key, plan.run(), plan.desc)
+            plan = self._pack_plan("fwd", self.training)
+            self._packed = (key, plan.run(self._flat(key[0])), plan.desc)
         return self._packed[1], self._packed[2]
 
-    def _pack_plan(self, slot: str, mode):
-        """The blob's layout as a gather plan (pack.py ErwinPackPlan / ErwinF32PackPlan): built once per set of parameter
-        OBJECTS (and mode), so that a repack after an optimizer step is ~8 launches instead of ~400 (call after _pack_key())."""
+    def _tensor_list(self):
+        """The cached list of parameters + buffers (see _pack_key); a NEW list object whenever the tensor objects may have
+        changed -- what the plans below are keyed on."""
+        d = self.__dict__
+        ts = d.get("_pack_tensors")
+        gen = _lib.cache_generation()
+        if ts is None or d.get("_pack_stale", True) or d.get("_pack_gen") != gen:
+            ps = list(self.parameters())
+            ts = ps + list(self.buffers())
+            d["_pack_tensors"], d["_pack_params"], d["_pack_stale"], d["_pack_gen"] = ts, ps, False, gen
+        return ts
+
+    def _plans(self):
+        ts = self._tensor_list()
+        hit = self.__dict__.get("_plans_hit")
+        if hit is None or hit[0] is not ts:
+            from .pack import _Sources
+
+            hit = (ts, {}, _Sources())
+            self.__dict__["_plans_hit"] = hit
+        return hit
+
+    def _pack_plan(self, which: str, mode):
+        """The blobs' layouts as gather plans (pack.py ErwinPackPlan / ErwinF32PackPlan): built once per set of parameter
+        OBJECTS (and mode) over ONE source registry, so that a repack after an optimizer step is one concatenation of the
+        parameters and one gather per blob (~9 launches) instead of ~400 per blob."""
         from .pack import ErwinF32PackPlan, ErwinPackPlan
 
-        ts = self.__dict__["_pack_tensors"]  # (a new list object whenever the tensor objects may have changed)
-        hit = self.__dict__.get(slot)
-        if hit is None or hit[0] is not ts:
-            hit = (ts, {})
-            self.__dict__[slot] = hit
-        if mode not in hit[1]:  # (train and eval plans side by side: a validation pass per epoch rebuilds neither)
-            hit[1][mode] = (ErwinPackPlan if slot == "_plan_fwd" else ErwinF32PackPlan)(self)
-        return hit[1][mode]
+        _, plans, src = self._plans()
+        if (which, mode) not in plans:  # (train and eval plans side by side: a validation pass per epoch rebuilds neither)
+            plans[(which, mode)] = (ErwinPackPlan if which == "fwd" else ErwinF32PackPlan)(self, src)
+        return plans[(which, mode)]
+
+    def _flat(self, key):
+        """The flat source vector of the plans for the weights `key` describes (shared by the two blobs of a training step)."""
+        src = self._plans()[2]
+        hit = self.__dict__.get("_flat_hit")
+        if hit is None or hit[0] != key or hit[1] != src.n:
+            hit = (key, src.n, src.flat(self._tensor_list()[0].device))
+            self.__dict__["_flat_hit"] = hit
+        return hit[2]
+
+    def _stats_updated(self):
+        self.__dict__["_stats_epoch"] = self.__dict__.get("_stats_epoch", 0) + 1
+
+    def param_list(self):
+        """list(self.parameters()) without the module-tree walk (the cached list of _tensor_list)."""
+        self._tensor_list()
+        return self.__dict__["_pack_params"]
+
+    def plan_desc(self):
+        """The descriptor alone (offsets and hyper-parameters: independent of the weights' values) -- no key walk, no repack."""
+        return self._pack_plan("fwd", self.training).desc
 
     def packed_frags(self, M: int):
         """The fragment-order weight blob of the fragment kernel (csrc/erwin2.hip) for clouds of M tokens, or None
@@ -315,6 +352,8 @@ class ErwinTransformer(nn.Module):
             out, node_positions = ops.token_stage(node_features, blob, desc, n_clouds, M, self.dimensionality,
                                                   self.strides, float(self.rotate), train,
                                                   frags=None if train is not None else self.packed_frags(M))
+            if train is not None:
+                self._stats_updated()
             self.__dict__["last_positions"] = node_positions if self.__dict__.get("keep_positions", True) else None
             return out
         if node_positions is None:
@@ -325,6 +364,8 @@ class ErwinTransformer(nn.Module):
             tree_idx, tree_mask, rot, _ = ops.balltree_build(
                 node_positions, n_clouds, M, self.strides, self.ball_sizes, float(self.rotate))
         self.__dict__["last_positions"] = node_positions if self.__dict__.get("keep_positions", True) else None
+        if train is not None:
+            self._stats_updated()
         return ops.erwin_fwd(node_features, node_positions, tree_idx, tree_mask, rot, blob, desc, n_clouds, M, train)
 
     # ------------------------------------------------------------------ training: forward with a tape, HIP backward
@@ -333,16 +374,15 @@ class ErwinTransformer(nn.Module):
         key = self._pack_key()
         hit = self.__dict__.get("_packed_f32")
         if hit is None or hit[0] != key:
-            plan = self._pack_plan("_plan_f32", None)
-            hit = (key, plan.run(), plan.lay, plan.pmap)
+            plan = self._pack_plan("f32", None)
+            hit = (key, plan.run(self._flat(key)), plan.lay, plan.pmap)
             self.__dict__["_packed_f32"] = hit
         return hit[1], hit[2], hit[3]
 
     def hip_backward_supported(self, n_clouds: int, M: int) -> bool:
         if os.environ.get("HAET_TORCH_ERWIN_BWD") or not self.decode:
             return False
-        _, desc = self.packed()
-        return ops.erwin_bwd_supported(desc, n_clouds, M)
+        return ops.erwin_bwd_supported(self.plan_desc(), n_clouds, M)
 
     def forward_taped(self, tokens: torch.Tensor, n_clouds: int):
         """Forward of the stage (positions from the tokens, tree, Erwin; BatchNorm per self.training) that also records
@@ -350,6 +390,10 @@ class ErwinTransformer(nn.Module):
         T = tokens.shape[0]
         M = T // n_clouds
         blob, desc = self.packed()
+        # the backward's fp32 blob is made NOW: the weights are the forward's (nothing steps between a forward and its
+        # backward), the flat source vector is the one the forward blob was just gathered from, and the backward then
+        # walks no parameter list at all
+        f32 = self.packed_f32()
         st = self._train_state(desc, n_clouds, tokens.device)  # (eval: only its tape slot is used)
         tape, opf = ops.erwin_tape(desc, n_clouds, M, tokens.device)
         st.set_tape(tape, opf)
@@ -364,13 +408,15 @@ class ErwinTransformer(nn.Module):
         finally:
             st.set_tape(None)
         stats = st.batch_stats.clone() if self.training else None
+        if self.training:
+            self._stats_updated()
         ctx = dict(tape=tape, pos=pos, tree_idx=tree_idx, tree_mask=tree_mask, rot=rot, blob=blob, desc=desc,
-                   n_clouds=n_clouds, M=M, stats=stats, workspace=st.workspace)
+                   n_clouds=n_clouds, M=M, stats=stats, workspace=st.workspace, f32=f32)
         return out, ctx
 
     def backward_hip(self, ctx, g_out: torch.Tensor):
         """haet_erwin_bwd on a forward_taped context: (dL/d tokens, {parameter: gradient})."""
-        blob32, lay, pmap = self.packed_f32()
+        blob32, lay, pmap = ctx["f32"] if "f32" in ctx else self.packed_f32()
 
         class _St:  # what ops.erwin_bwd reads of a train state
             batch_stats, workspace = ctx["stats"], ctx["workspace"]
@@ -380,6 +426,11 @@ class ErwinTransformer(nn.Module):
                                         _St if ctx["stats"] is not None else None)
         gsum = per_cloud.sum(dim=0)
         return g_in, {id(p): gsum[off:off + p.numel()].view_as(p) for p, off in pmap}
+
+    def train_state(self):
+        """The ops.ErwinTrainState of the last train-mode / taped launch, or None."""
+        hit = self.__dict__.get("_train_cache")
+        return None if hit is None else hit[1]
 
     def check_grid_barrier(self):
         """Raise HaetError if a grid barrier of a train-mode launch of this module timed out since the last check
@@ -392,7 +443,8 @@ class ErwinTransformer(nn.Module):
     def _train_state(self, desc, n_clouds, device):
         """ops.ErwinTrainState for this (weights object set, cloud count): pointers to the BatchNorm running
         statistics (updated in place by the kernel), batch-statistics output, grid-barrier workspace."""
-        key = (n_clouds, str(device), tuple(b.data_ptr() for b in self.buffers()))
+        ts = self._tensor_list()
+        key = (n_clouds, str(device), tuple(b.data_ptr() for b in ts[len(self.__dict__["_pack_params"]):]))  # (the buffers)
         hit = self.__dict__.get("_train_cache")
         if hit is None or hit[0] != key:
             hit = (key, ops.ErwinTrainState(self, desc, n_clouds, device))

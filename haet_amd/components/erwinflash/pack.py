@@ -227,10 +227,12 @@ def pack_erwin_f32(erwin):
 #     flat = cat(parameters);  hi = bf16(flat);  lo = bf16(flat - hi);  blob = cat(flat | hi | lo | header)[plan]
 # i.e. ~8 launches whatever the depth.  tests/test_modules_cpu.py holds the plans to the direct packers bit for bit.
 class _Sources:
-    """The live tensors a blob is made of, in first-use order; `sym(t)` = t's element indices in their concatenation."""
+    """The live tensors the blobs are made of, in first-use order; `sym(t)` = t's element indices in `flat()` =
+    [0.0 | sources ...]: element 0 is the zero every padding element gathers, so that plans sharing one registry stay valid
+    when another plan registers more sources behind theirs."""
 
     def __init__(self):
-        self.items, self.base, self.n = [], {}, 0
+        self.items, self.base, self.n = [], {}, 1
 
     def sym(self, t):
         k = id(t)
@@ -248,23 +250,22 @@ class _Sources:
         return torch.arange(off, off + numel, dtype=torch.int64)
 
     def flat(self, device):
-        """fp32 concatenation of the sources, plus one trailing 0.0 (what every padding element gathers).  The flattened
-        fp32 views of the live tensors are kept between calls (an optimizer step writes into the same storage); a view is
-        re-made when its tensor's storage moved (`p.data = ...`)."""
+        """[0.0 | fp32 concatenation of the sources].  The flattened fp32 views of the live tensors are kept between calls
+        (an optimizer step writes into the same storage); a view is re-made when its tensor's storage moved (`p.data = ...`)."""
         views = self.__dict__.get("_views")
-        if views is None or views[0] != str(device):
-            views = (str(device), [None] * len(self.items), [0] * len(self.items), torch.zeros(1, device=device))
+        if views is None or views[0] != str(device) or len(views[1]) != len(self.items) + 1:
+            views = (str(device), [torch.zeros(1, device=device)] + [None] * len(self.items), [0] * len(self.items))
             self._views = views
-        _, vs, ptrs, zero = views
+        _, vs, ptrs = views
         for i, t in enumerate(self.items):
             if callable(t):
-                vs[i] = t().reshape(-1).to(device=device, dtype=torch.float32)
-            elif vs[i] is None or ptrs[i] != t.data_ptr():
+                vs[i + 1] = t().reshape(-1).to(device=device, dtype=torch.float32)
+            elif vs[i + 1] is None or ptrs[i] != t.data_ptr():
                 v = t.detach().reshape(-1)
-                direct = v.device == zero.device and v.dtype == torch.float32 and t.is_contiguous()  # (else reshape / to made a copy)
-                vs[i] = v if direct else v.to(device=device, dtype=torch.float32)
+                direct = v.device == vs[0].device and v.dtype == torch.float32 and t.is_contiguous()  # (else reshape / to made a copy)
+                vs[i + 1] = v if direct else v.to(device=device, dtype=torch.float32)
                 ptrs[i] = t.data_ptr() if direct else -1  # (a converted copy is re-made every time)
-        return torch.cat(vs + [zero])
+        return torch.cat(vs)
 
 
 class _SymBlob:
@@ -311,19 +312,21 @@ class _SymBlob:
         self._pad()
         return start, self.n - start
 
-    def index16(self, n_src):
-        """Index of every 16-bit unit of the blob into  [flat as int16 (2 (n+1)) | hi (n+1) | lo (n+1) | header]."""
+    def index16(self):
+        """Per 16-bit unit of the blob (header excluded): (part, element) with part 0 = the fp32 word's low half, 1 = its
+        high half, 2 = bf16 hi, 3 = bf16 lo of flat[element]; element 0 is the zero.  Resolved against the flat vector's
+        length at run time (ErwinPackPlan.run), which may grow when another plan registers sources in the same registry."""
         self._pad()
-        n1 = n_src + 1
-        out = [4 * n1 + torch.arange(2 * HEADER_FLOATS, dtype=torch.int64)]
+        part, elem = [], []
         for kind, v in self.parts:
+            s = torch.where(v >= 0, v if kind == "f32" else v >> 1, torch.zeros_like(v))
             if kind == "f32":
-                s = torch.where(v >= 0, v, torch.full_like(v, n_src))
-                out.append(torch.stack([2 * s, 2 * s + 1], dim=1).reshape(-1))
+                elem.append(torch.stack([s, s], dim=1).reshape(-1))
+                part.append(torch.tensor([0, 1], dtype=torch.int64).repeat(v.numel()))
             else:
-                s, plane = v >> 1, v & 1
-                out.append(torch.where(v >= 0, (2 + plane) * n1 + s, torch.full_like(v, 2 * n1 + n_src)))
-        return torch.cat(out)
+                elem.append(s)
+                part.append(torch.where(v >= 0, 2 + (v & 1), torch.full_like(v, 2)))
+        return torch.cat(part), torch.cat(elem)
 
 
 def _sym_layer(dst, layer, blob, src):
@@ -373,15 +376,16 @@ def _sym_resample(dst, mod, blob, src, train):
 
 
 class ErwinPackPlan:
-    """Layout of pack_erwin's blob (for the module's current mode) as a gather; `run()` = the blob of the current weights.
-    The descriptor is part of the plan: it holds offsets and hyper-parameters only, so it is the same object for every repack."""
+    """Layout of pack_erwin's blob (for the module's current mode) as a gather; `run(flat)` = the blob of the current weights.
+    The descriptor is part of the plan: it holds offsets and hyper-parameters only, so it is the same object for every repack.
+    `src`: the source registry, shared with the module's other plans so that one `flat()` serves them all."""
 
-    def __init__(self, erwin):
+    def __init__(self, erwin, src=None):
         n_levels = len(erwin.encoder) + 1
         if n_levels > MAX_LEVELS:
             raise HaetError(f"Erwin with {n_levels} levels > {MAX_LEVELS}")
         self.device = next(erwin.parameters()).device
-        desc, blob, src = ErwinDesc(), _SymBlob(), _Sources()
+        desc, blob, src = ErwinDesc(), _SymBlob(), (_Sources() if src is None else src)
         desc.n_levels, desc.d = n_levels, erwin.dimensionality
         desc.rotate, desc.decode = int(erwin.rotate > 0), int(bool(erwin.decode))
         train = bool(erwin.training)
@@ -395,9 +399,20 @@ class ErwinPackPlan:
             _sym_layer(desc.dec[lvl], layer, blob, src)
             _sym_resample(desc.unpool[lvl], layer.unpool, blob, src, train)
         self.desc, self.src = desc, src
-        self.index = blob.index16(src.n).to(torch.int32).to(self.device)
+        part, elem = blob.index16()
+        self.part, self.elem = part.to(self.device), elem.to(self.device)
+        self._index = None  # (n, index): resolved for a flat vector of n elements
         hdr = bytearray(bytes(desc)) + bytearray(HEADER_FLOATS * 4 - ctypes.sizeof(desc))
         self.hdr16 = torch.frombuffer(hdr, dtype=torch.int16).to(self.device)
+
+    def index(self, n):
+        """Indices into  [flat as int16 (2 n) | hi (n) | lo (n) | header]  for a flat vector of n elements."""
+        if self._index is None or self._index[0] != n:
+            p, e = self.part, self.elem
+            body = torch.where(p < 2, 2 * e + p, p * n + e)  # (hi at 2 n + e, lo at 3 n + e)
+            hdr = 4 * n + torch.arange(self.hdr16.numel(), dtype=torch.int64, device=self.device)
+            self._index = (n, torch.cat([hdr, body]).to(torch.int32))
+        return self._index[1]
 
     def run(self, flat=None):
         if flat is None:
@@ -405,18 +420,18 @@ class ErwinPackPlan:
         hi = flat.to(torch.bfloat16)
         lo = (flat - hi.float()).to(torch.bfloat16)
         pool = torch.cat([flat.view(torch.int16), hi.view(torch.int16), lo.view(torch.int16), self.hdr16])
-        return torch.index_select(pool, 0, self.index).view(torch.float32)
+        return torch.index_select(pool, 0, self.index(flat.numel())).view(torch.float32)
 
 
 class ErwinF32PackPlan:
     """Layout of pack_erwin_f32's blob as a gather of fp32 words; `.lay`, `.pmap` as pack_erwin_f32 returns them."""
 
-    def __init__(self, erwin):
+    def __init__(self, erwin, src=None):
         from ..._lib import ErwinF32Layout
 
         n_levels = len(erwin.encoder) + 1
         self.device = next(erwin.parameters()).device
-        lay, src = ErwinF32Layout(), _Sources()
+        lay, src = ErwinF32Layout(), (_Sources() if src is None else src)
         head = (ctypes.sizeof(ErwinF32Layout) + 15) // 16 * 4
         parts, pmap = [], []
         state = {"n": head}
@@ -474,10 +489,17 @@ class ErwinF32PackPlan:
         self.lay, self.pmap, self.src = lay, pmap, src
         hdr = bytearray(bytes(lay)) + bytearray(head * 4 - ctypes.sizeof(lay))
         self.hdr = torch.frombuffer(hdr, dtype=torch.float32).to(self.device)
-        n1 = src.n + 1
         idx = torch.cat(parts)
-        idx = torch.where(idx >= 0, idx, torch.full_like(idx, src.n))
-        self.index = torch.cat([n1 + torch.arange(head, dtype=torch.int64), idx]).to(torch.int32).to(self.device)
+        self.body = torch.where(idx >= 0, idx, torch.zeros_like(idx)).to(self.device)  # (element 0 of flat = the zero)
+        self._index = None
 
-    def run(self):
-        return torch.index_select(torch.cat([self.src.flat(self.device), self.hdr]), 0, self.index)
+    def index(self, n):
+        if self._index is None or self._index[0] != n:
+            hdr = n + torch.arange(self.hdr.numel(), dtype=torch.int64, device=self.device)
+            self._index = (n, torch.cat([hdr, self.body]).to(torch.int32))
+        return self._index[1]
+
+    def run(self, flat=None):
+        if flat is None:
+            flat = self.src.flat(self.device)
+        return torch.index_select(torch.cat([flat, self.hdr]), 0, self.index(flat.numel()))

@@ -7,6 +7,7 @@ on a ROCm device; there is no CPU path.
 from __future__ import annotations
 
 import ctypes
+import functools
 import math
 import os
 from typing import List, Optional, Sequence, Tuple
@@ -45,14 +46,19 @@ def tree_slots(M: int) -> int:
     return 2 << depth
 
 
+@functools.lru_cache(maxsize=None)
+def _slice_c0(epsilon: float) -> float:
+    # log(-log(eps)) evaluated in fp32 like the reference (IrregularMesh.py:172)
+    return float(torch.log(-torch.log(torch.tensor(epsilon, dtype=torch.float32))))
+
+
 class SliceParams:
     """Device views of the Rep-Slice / Ada-Temp parameters (in_project_slice, ada_temp_linear)."""
 
     def __init__(self, Ws: Tensor, bs: Tensor, wt: Tensor, bt: float, base_temp: float, epsilon: float):
         self.Ws, self.bs, self.wt = _f32(Ws, "in_project_slice.weight"), _f32(bs, "in_project_slice.bias"), _f32(wt.reshape(-1), "ada_temp_linear.weight")
         self.bt, self.base_temp = float(bt), float(base_temp)
-        # log(-log(eps)) evaluated in fp32 like the reference (IrregularMesh.py:172)
-        self.c0 = float(torch.log(-torch.log(torch.tensor(epsilon, dtype=torch.float32))))
+        self.c0 = _slice_c0(float(epsilon))
 
 
 def slice_partials(x_lin: Tensor, p: SliceParams, H: int, C: int, M: int) -> Tensor:
@@ -145,6 +151,20 @@ def balltree_build(pos: Optional[Tensor], n_clouds: int, M: int, strides: Sequen
     check(lib.haet_balltree_build(_p(pos), n_clouds, M, d, nl, c_str, c_tg, float(angle),
                                   _p(tree_idx), _p(tree_mask), _p(rot), _stream()), "haet_balltree_build")
     return tree_idx, tree_mask, rot, sizes
+
+
+def check_barriers(states):
+    """ErwinTrainState.check_barrier for several states with ONE device -> host copy."""
+    states = [st for st in states if st.workspace.is_cuda]
+    if not states:
+        return
+    words = torch.cat([st.workspace[:2] for st in states]).cpu().contiguous()
+    lib = _lib.load()
+    for i, st in enumerate(states):
+        rc = lib.haet_erwin_barrier_status(ctypes.c_void_p(words.data_ptr() + 8 * i))
+        if rc != 0:
+            st.workspace[1:2].zero_()  # re-arm
+            check(rc, "haet_erwin_barrier_status")
 
 
 class ErwinTrainState:

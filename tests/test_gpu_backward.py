@@ -227,21 +227,28 @@ def test_linear_weight_gradient_vs_fp64(rows, O, K, hip_device):
     assert float((db.cpu().double() - G.double().sum(0)).norm() / G.double().sum(0).norm()) < 2e-6
 
 
-@pytest.mark.parametrize("B,grid,k", [(2, (5, 6, 7), 3), (1, (9, 7), 3), (1, (4, 4, 4), 1), (1, (6, 5), 5)])
-def test_convolution_weight_gradient_vs_fp64(B, grid, k, hip_device):
-    """ops.conv_wgrad (one shifted row-contraction per tap on the f32 MFMA) against fp64 autograd of the convolution."""
+@pytest.mark.parametrize("B,grid,k,Cin,O", [(2, (5, 6, 7), 3, 256, 256), (1, (9, 7), 3, 256, 256), (1, (4, 4, 4), 1, 256, 256),
+                                            (1, (6, 5), 5, 256, 256),
+                                            (2, (9, 7), 3, 128, 128),     # the PDE scripts' width: one tile, its O x Cin corner
+                                            (1, (5, 4, 3), 3, 128, 512),  # two output tiles (the taps' partials reduced together)
+                                            (1, (6, 5), 3, 384, 256)])
+def test_convolution_weight_gradient_vs_fp64(B, grid, k, Cin, O, hip_device):
+    """ops.conv_wgrad (one shifted row-contraction per tap on the matrix cores, the taps' split-K partials reduced in one
+    launch per group) against fp64 autograd of the convolution."""
     from haet_amd import ops
 
+    if not ops.conv_wgrad_supported(Cin, O):
+        pytest.skip("channel counts outside the weight-gradient kernel")
     nd = len(grid)
     N = 1
     for g_ in grid:
         N *= g_
     gen = torch.Generator().manual_seed(N + k)
-    x = torch.randn(B, N, 256, generator=gen)
-    g = torch.randn(B, N, 256, generator=gen)
-    conv = (torch.nn.Conv2d if nd == 2 else torch.nn.Conv3d)(256, 256, k, 1, k // 2).double()
-    xg = x.double().view((B,) + grid + (256,)).permute(0, nd + 1, *range(1, nd + 1))
-    y = conv(xg).permute(0, *range(2, nd + 2), 1).reshape(B, N, 256)
+    x = torch.randn(B, N, Cin, generator=gen)
+    g = torch.randn(B, N, O, generator=gen)
+    conv = (torch.nn.Conv2d if nd == 2 else torch.nn.Conv3d)(Cin, O, k, 1, k // 2).double()
+    xg = x.double().view((B,) + grid + (Cin,)).permute(0, nd + 1, *range(1, nd + 1))
+    y = conv(xg).permute(0, *range(2, nd + 2), 1).reshape(B, N, O)
     gW, gb = torch.autograd.grad(y, [conv.weight, conv.bias], g.double())
     dW, db = ops.conv_wgrad(g.to(hip_device), x.to(hip_device), grid, (k,) * nd)
     assert dW.shape == gW.shape

@@ -310,3 +310,34 @@ def test_car_evaluation_on_cached_sample_format(tmp_path, hip_device):
             ev.add(out, smp.y, smp.surf, seconds=0.01, cd_true=0.3 + 0.1 * i, cd_pred=0.31 + 0.1 * i)
     s = ev.summary()
     assert s["samples"] == 2 and np.isfinite(s["rel_l2_press"]) and np.isfinite(s["rel_l2_velo"]) and abs(s["rho_d"] - 1) < 1e-12
+
+
+def test_eval_blob_follows_running_statistics_updated_by_a_train_mode_launch(hip_device):
+    """A train-mode launch updates the BatchNorm running statistics through raw pointers (no `_version` bump): the
+    eval-mode weight blob folded from the OLD statistics must not be reused afterwards (ErwinTransformer._stats_epoch).
+    eval -> train-mode forward under no_grad (no optimizer step: the parameters' versions stay) -> eval, against a fresh
+    module loaded from the state_dict."""
+    from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh
+
+    torch.manual_seed(5)
+    kw = dict(dim=256, heads=8, dim_head=32, slice_num=64, rotate=45)
+    mod = Physics_Attention_Irregular_Mesh(**kw)
+    with torch.no_grad():
+        for p in mod.erwin.parameters():
+            if p.dim() >= 2:
+                p.mul_(5.0)
+    mod = mod.to(hip_device).eval()
+    x = torch.randn(1, 3000, 256, device=hip_device)
+    with torch.no_grad():
+        y0 = mod(x)
+        mod.train()
+        for _ in range(3):
+            mod(torch.randn(1, 3000, 256, device=hip_device) * 2.0 + 0.5)  # (running statistics move)
+        mod.eval()
+        y1 = mod(x)
+        fresh = Physics_Attention_Irregular_Mesh(**kw).to(hip_device).eval()
+        fresh.load_state_dict(mod.state_dict())
+        y_ref = fresh(x)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    assert rel(y1, y_ref) < 1e-6
+    assert rel(y1, y0) > 1e-5  # (the statistics did change the output: the test would pass vacuously otherwise)

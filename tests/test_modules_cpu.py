@@ -116,7 +116,7 @@ def test_pack_plans_equal_the_direct_packers_bit_for_bit(kw):
             got, gdesc = er.packed()
             assert torch.equal(blob.view(torch.int32), got.view(torch.int32))
             assert bytes(desc) == bytes(gdesc)
-            plan = er.__dict__["_plan_fwd"][1][mode]
+            plan = er.__dict__["_plans_hit"][1][("fwd", mode)]
             assert plans.setdefault(mode, plan) is plan  # (same parameter objects: the layout is not recomputed)
         b32, lay, pmap = pack.pack_erwin_f32(er)
         g32, glay, gpmap = er.packed_f32()

@@ -68,14 +68,14 @@ for name, cls, kw, B, N, fd, tin, clip in CONFIGS:
         opt.step()
         return loss
 
-    for _ in range(3):
+    for _ in range(4):
         loss = step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(5):
+    for _ in range(20):
         loss = step()
     torch.cuda.synchronize()
-    t_train = (time.perf_counter() - t0) / 5
+    t_train = (time.perf_counter() - t0) / 20
     assert bool(torch.isfinite(loss)), name
     print(f"{name}: batch {B} x {N} points: eval forward {1e3 * t_eval:.2f} ms, training step {1e3 * t_train:.2f} ms "
           f"(loss {float(loss):.4f}, peak {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB)", flush=True)
