@@ -284,6 +284,10 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const float* __restrict
             put(buf + (8 + blk) * (2 * kImg), sr + 8 * i, sx[i]);
         }
     };
+    // O, K are multiples of 128 and a wave owns 128 x 64 of the block: at O = 128 or K = 128 (the reference's PDE widths)
+    // whole waves lie outside the matrix -- they stage like the others but neither multiply nor store (the host reads the
+    // O x K corner of a record only): 1/4 of the partial-record traffic at 128 x 128
+    const bool wave_on = ob0 + 128 * wo < O && kb0 + 64 * wk < K;
     fetch(n0);
     stash(0);
     __syncthreads();
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const float* __restrict
         const int gimg = cur * kTileImgBytes + (4 * wo) * (2 * kImg);
         const int ximg = cur * kTileImgBytes + (8 + 2 * wk) * (2 * kImg);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; wave_on && ks < 2; ++ks) {
             u32x4 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) tn_read_cols(tsm, gimg + ob * (2 * kImg), ks, lane, ah[ob], al[ob]);
@@ -318,15 +322,17 @@ __global__ __launch_bounds__(512) void gemm_tn_x3_kernel(const float* __restrict
 
     float* rec = parts + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (size_t)(256 * 256 + 256);
     const int ol = 128 * wo, kl = 64 * wk;
+    if (wave_on) {
 #pragma unroll
-    for (int ob = 0; ob < 4; ++ob)
+        for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int o = ol + 32 * ob + 8 * (v >> 2) + 4 * half + (v & 3);
-                rec[o * 256 + kl + 32 * kb + l31] = acc[ob][kb][v];
-            }
+                for (int v = 0; v < 16; ++v) {
+                    const int o = ol + 32 * ob + 8 * (v >> 2) + 4 * half + (v & 3);
+                    rec[o * 256 + kl + 32 * kb + l31] = acc[ob][kb][v];
+                }
+    }
     // bias gradient: wave w holds the sums over rows = w (mod 8) of all 256 columns (lane l: columns 4l .. 4l+3)
     float* red = reinterpret_cast<float*>(tsm);
     *reinterpret_cast<f4v*>(red + wave * 256 + 4 * lane) = dbs;

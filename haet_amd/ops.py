@@ -497,9 +497,12 @@ def linear_wgrad(g: Tensor, x: Tensor):
     ob, kb = (O + 255) // 256, (K + 255) // 256
     parts = torch.empty((P, ob * kb, 256 * 256 + 256), dtype=torch.float32, device=g.device)
     check(lib.haet_linear_wgrad(_p(g2), _p(x2), N, O, K, _p(parts), _stream()), "haet_linear_wgrad")
-    s = parts.sum(dim=0)
-    dW = s[:, :256 * 256].view(ob, kb, 256, 256).permute(0, 2, 1, 3).reshape(ob * 256, kb * 256)[:O, :K]
-    db = s[:, 256 * 256:].view(ob, kb, 256)[:, 0].reshape(ob * 256)[:O]
+    # (a record's tile is written only where it overlaps the O x K matrix: sum that part, not the whole 256 x 256)
+    db = parts[:, :, 256 * 256:].sum(dim=0).view(ob, kb, 256)[:, 0].reshape(ob * 256)[:O]
+    if ob * kb == 1:
+        return parts[:, 0, :256 * 256].view(P, 256, 256)[:, :O, :K].sum(dim=0), db
+    s = parts[:, :, :256 * 256].sum(dim=0)
+    dW = s.view(ob, kb, 256, 256).permute(0, 2, 1, 3).reshape(ob * 256, kb * 256)[:O, :K]
     return dW, db
 
 
