@@ -257,6 +257,31 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
         w = self._split_linear(name, lin)
         return lin(x) if w is None else ops.linear(x, w)
 
+    # -- dim_head 16 on the matrix-core passes ---------------------------------------------------------------------
+    HEAD_PAD = 32
+    HEAD_PAD_BWD_ROWS = 65536  # B * N from which the backward runs padded too (below it the split-bf16 backward kernels'
+    #                            fixed cost and the extra copies eat the gain: 226 vs 255 us at 45k points, 383 vs 1005 at 200k)
+
+    def head_pad_applies(self, B: int, N: int) -> bool:
+        """dim_head 16 (n_hidden 128 / 8 heads: six of the reference's seven PDE scripts) has no matrix-core slice /
+        de-slice kernels of its own -- the generic vector-ALU ones ran there, 3-5x slower per byte.  The passes are run
+        at 32 channels per head instead, the upper 16 zero: x_lin padded once per forward, W_s and w_t zero-padded
+        (their products with the zero channels vanish exactly: same logits, same tau, same sums), the tokens cut back to
+        16 channels around the Erwin stage and the output around `to_out`.  Two copies of x_lin-sized tensors per
+        direction against kernels that run 3-4x faster; HAET_NO_HEAD_PAD=1 keeps the vector-ALU kernels (A/B, tests)."""
+        return (self.dim_head == 16 and not os.environ.get("HAET_NO_HEAD_PAD")
+                and ops.slice_mfma_supported(B, N, self.heads, self.HEAD_PAD, self.slice_num))
+
+    def _slice_params_padded(self) -> ops.SliceParams:
+        sp = self._slice_params()
+        hit = sp.__dict__.get("_padded")
+        if hit is None:
+            extra = self.HEAD_PAD - self.dim_head
+            hit = ops.SliceParams(torch.nn.functional.pad(sp.Ws, (0, extra)), sp.bs, torch.nn.functional.pad(sp.wt, (0, extra)),
+                                  sp.bt, sp.base_temp, self.epsilon)
+            sp.__dict__["_padded"] = hit
+        return hit
+
     def _slice_tensors(self):
         return (self.in_project_slice.weight, self.in_project_slice.bias, self.ada_temp_linear.weight, self.ada_temp_linear.bias)
 
@@ -520,6 +545,10 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
             if xs is None and pre_norm is not None:
                 x = pre_norm(x)
             x_lin = None if xs is not None else self.project(x).float().contiguous()  # [B, N, H*C]
+            padded = xs is None and self.head_pad_applies(B, N)
+            x_real = x_lin
+            if padded:  # the passes below see dim_head 32 (zero upper channels); tokens and out_x are cut back
+                x_lin, sp, Cr, C = ops.pad_heads(x_lin, H, C, self.HEAD_PAD), self._slice_params_padded(), C, self.HEAD_PAD
         with ev("slice"):
             parts = (ops.slice_partials_split(xs, sp, G) if xs is not None
                      else ops.slice_partials(x_lin, sp, H, C, G))       # [P, record]
@@ -530,10 +559,13 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
                 local = ops.merge_records(parts, B, H, C, G, finalize=False)
                 parts = allgather_records(local, self.shard_group)      # [R, record]
             col_max, col_sum, S = ops.merge_records(parts, B, H, C, G, finalize=True)
+            if padded:
+                S = S[:, :Cr].contiguous()
         with ev("erwin"):  # token positions are derived inside the tree launch (haet_tokens_tree_build)
             self.erwin.__dict__["keep_positions"] = bool(return_intermediates)
             S2 = self.erwin(S, None, n_clouds=B * H)                     # [B*H*G, C]
             pos = self.erwin.__dict__.get("last_positions")              # [B*H*G, d] (kept on request only)
+            S2p = torch.nn.functional.pad(S2, (0, C - Cr)) if padded else S2
         w_out = None
         if xs is not None and not return_intermediates and ops.deslice_out_supported(H, C, G, self.to_out[0].out_features):
             w_out = self._split_linear("to_out", self.to_out[0])
@@ -548,7 +580,9 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
             return out
         with ev("deslice"):
             out_x = (ops.deslice_split(xs, sp, col_max, col_sum, S2, G) if xs is not None
-                     else ops.deslice(x_lin, sp, col_max, col_sum, S2, H, C, G))  # [B, N, H*C]
+                     else ops.deslice(x_lin, sp, col_max, col_sum, S2p, H, C, G))  # [B, N, H*C]
+            if padded:
+                out_x, x_lin = ops.unpad_heads(out_x, H, Cr, C), x_real
         with ev("to_out"):
             out = self.to_out[1](self._linear("to_out", self.to_out[0], out_x)).to(x.dtype)
         if residual is not None:

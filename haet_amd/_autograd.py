@@ -176,6 +176,15 @@ class PhysicsAttentionFunction(torch.autograd.Function):
         ev = mod._stage
         with ev("project"):
             x_lin = mod.project(x).float().contiguous()                  # [B, N, H*C] fp32, kept for backward
+            # dim_head 16: the passes of both directions run at 32 channels per head, the upper 16 zero
+            # (PhysicsAttentionBase.head_pad_applies); the PADDED x_lin is what the backward keeps
+            # -- and, where the cloud is large enough for the split-bf16 backward kernels' fixed cost to pay
+            # (HEAD_PAD_BWD_ROWS; tools/head_pad_probe.py), of the backward: then the PADDED x_lin is what is kept
+            fwd_padded = mod.head_pad_applies(B, N)
+            ctx.padded = fwd_padded and B * N >= mod.HEAD_PAD_BWD_ROWS
+            Cr, x_real = C, x_lin
+            if fwd_padded:
+                x_lin, sp, C = ops.pad_heads(x_lin, H, C, mod.HEAD_PAD), mod._slice_params_padded(), mod.HEAD_PAD
         with ev("slice"):
             parts = ops.slice_partials(x_lin, sp, H, C, G)
         with ev("merge"):
@@ -184,6 +193,8 @@ class PhysicsAttentionFunction(torch.autograd.Function):
 
                 parts = allgather_records(ops.merge_records(parts, B, H, C, G, finalize=False), mod.shard_group)
             col_max, col_sum, S = ops.merge_records(parts, B, H, C, G, finalize=True)
+            if fwd_padded:
+                S = S[:, :Cr].contiguous()
         ctx.inner = None
         ctx.erwin_ctx = None
         with ev("erwin"):
@@ -200,7 +211,12 @@ class PhysicsAttentionFunction(torch.autograd.Function):
             else:
                 S2 = mod.erwin(S, None, n_clouds=B * H)
         with ev("deslice"):
-            out_x = ops.deslice(x_lin, sp, col_max, col_sum, S2, H, C, G)
+            S2p = F.pad(S2, (0, C - Cr)) if fwd_padded else S2
+            out_x = ops.deslice(x_lin, sp, col_max, col_sum, S2p, H, C, G)
+            if fwd_padded:
+                out_x = ops.unpad_heads(out_x, H, Cr, C)
+            if not ctx.padded:
+                x_lin = x_real  # (the backward runs at the real width)
         with ev("to_out"):
             y = mod._linear("to_out", mod.to_out[0], out_x)
         ctx.save_for_backward(x, x_lin, col_max, col_sum, S, S2, out_x)
@@ -214,6 +230,9 @@ class PhysicsAttentionFunction(torch.autograd.Function):
         B, N, _ = x.shape
         H, C, G = mod.heads, mod.dim_head, mod.slice_num
         sp = mod._slice_params()
+        Cr = C
+        if ctx.padded:  # (x_lin was saved padded; S, S2 and out_x at the real width)
+            sp, C = mod._slice_params_padded(), mod.HEAD_PAD
         mod.__dict__["_event_chain"] = [None] if mod.stage_events is not None else None
         ev = mod._stage  # optional per-stage HIP events (tools/train_probe.py)
         wanted = {id(p) for p, need in zip(ctx.all_params, ctx.needs_input_grad[2:]) if need}
@@ -227,8 +246,12 @@ class PhysicsAttentionFunction(torch.autograd.Function):
                 if lin_out.bias is not None:
                     grads[id(lin_out.bias)] = gb
             g_out = mod._linear_transposed("to_out", lin_out, gy)       # dL/d out_x [B, N, H*C]
+            if ctx.padded:
+                g_out = ops.pad_heads(g_out, H, Cr, C)
         with ev("bwd_tokens"):
             dS2 = ops.deslice_bwd_tokens(x_lin, sp, col_max, col_sum, g_out, H, C, G)
+            if ctx.padded:
+                dS2 = dS2[:, :Cr].contiguous()
             share = 1.0
             if mod.shard_group is not None:  # the backward's one exchange; everything token-level is replicated
                 import torch.distributed as dist
@@ -258,7 +281,11 @@ class PhysicsAttentionFunction(torch.autograd.Function):
                 grads[id(p)] = g if share == 1.0 or g is None else g * share
             A = (dS2 * S2).sum(dim=-1) + (S * dS).sum(dim=-1)          # sum_n w[n,g] a[n,g], [B*H*M]
         with ev("bwd_points"):
+            if ctx.padded:
+                S2, dS = F.pad(S2, (0, C - Cr)), F.pad(dS, (0, C - Cr))
             dx_lin, dWs, dbs, dwt, dbt = ops.slice_bwd_points(x_lin, sp, col_max, col_sum, g_out, S2, dS, A, H, C, G)
+            if ctx.padded:
+                dx_lin, dWs, dwt, C = ops.unpad_heads(dx_lin, H, Cr, C), dWs[:, :Cr], dwt.reshape(-1)[:Cr], Cr
         grads[id(mod.in_project_slice.weight)] = dWs
         grads[id(mod.in_project_slice.bias)] = dbs
         grads[id(mod.ada_temp_linear.weight)] = dwt.view(1, C)

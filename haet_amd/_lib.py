@@ -88,6 +88,7 @@ SIGNATURES = {
     "haet_project_split_supported": (c_int, [c_int, c_int, c_int]),
     "haet_project_split_fwd": (c_int, [_P, _P, _P, _P, _P, c_float, c_float, c_int, c_int, c_int, _P, _P, _P]),
     "haet_slice_split_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "haet_slice_mfma_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "haet_slice_fwd_split": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "haet_deslice_fwd_split": (c_int, [_P, _P, _P, _P, c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
                                        _P, _P]),
@@ -268,8 +269,8 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
             fn.restype, fn.argtypes = res, args
-        if lib.haet_abi_version() != 7:
-            raise HaetError(f"libhaet_hip.so ABI {lib.haet_abi_version()} != 7")
+        if lib.haet_abi_version() != 8:
+            raise HaetError(f"libhaet_hip.so ABI {lib.haet_abi_version()} != 8")
         _lib = lib
     return _lib
 

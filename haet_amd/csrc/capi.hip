@@ -141,6 +141,11 @@ extern "C" int haet_deslice_fwd(const float* x_lin, const float* Ws, const float
                             out_x, as_stream(stream));
 }
 
+extern "C" int haet_slice_mfma_supported(int B, int N, int H, int C, int M) {
+    MfmaPlan p;
+    return (slice_shape_ok(B, N, H, C, M) == HAET_OK && use_mfma(B, N, H, C, M, &p)) ? 1 : 0;
+}
+
 // ---- the same two passes on the split-format projection (haet_project_split_fwd) ----------------
 extern "C" int haet_slice_split_supported(int B, int N, int H, int C, int M) {
     MfmaPlan p;

@@ -568,6 +568,23 @@ def project_split_supported(K: int, O: int, rows: int) -> bool:
     return bool(_lib.load().haet_project_split_supported(int(K), int(O), int(rows)))
 
 
+def slice_mfma_supported(B: int, N: int, H: int, C: int, M: int) -> bool:
+    """Whether the fp32-input passes run this shape on the split-bf16 matrix-core kernels (haet_slice_mfma_supported)."""
+    return bool(_lib.load().haet_slice_mfma_supported(B, N, H, C, M))
+
+
+def pad_heads(x: Tensor, H: int, C: int, Cp: int) -> Tensor:
+    """[..., H*C] -> [..., H*Cp]: every head's C channels followed by Cp - C zeros."""
+    lead = x.shape[:-1]
+    return torch.nn.functional.pad(x.reshape(lead + (H, C)), (0, Cp - C)).reshape(lead + (H * Cp,))
+
+
+def unpad_heads(x: Tensor, H: int, C: int, Cp: int) -> Tensor:
+    """Inverse of pad_heads (a copy)."""
+    lead = x.shape[:-1]
+    return x.reshape(lead + (H, Cp))[..., :C].reshape(lead + (H * C,))
+
+
 def slice_split_supported(B: int, N: int, H: int, C: int, M: int) -> bool:
     return bool(_lib.load().haet_slice_split_supported(B, N, H, C, M))
 

@@ -34,10 +34,10 @@
 extern "C" {
 #endif
 
-#define HAET_ABI_VERSION 7  /* 2: + haet_tokens_tree_build, haet_project_split_fwd, haet_*_fwd_split; 4: train-mode
+#define HAET_ABI_VERSION 8  /* 2: + haet_tokens_tree_build, haet_project_split_fwd, haet_*_fwd_split; 4: train-mode
                              BatchNorm (haet_erwin_train), haet_token_stage_fwd; 6: haet_token_stage_fwd_frag (the
                              fragment kernel), haet_erwin_barrier_status, haet_set_deterministic; 7: tile-ordered weight copies in the
-                             Erwin blob, haet_conv_presplit / haet_conv_project_cells_*, haet_conv_project_det_fwd */
+                             Erwin blob, haet_conv_presplit / haet_conv_project_cells_*, haet_conv_project_det_fwd; 8: haet_slice_mfma_supported */
 
 #define HAET_OK 0
 #define HAET_E_ARG (-1)      /* bad argument / unsupported shape */
@@ -351,6 +351,12 @@ int haet_deslice_fwd(const float* x_lin, const float* Ws, const float* bs, const
                      const float* col_max /*[B*H*M]*/, const float* col_sum /*[B*H*M]*/,
                      const float* S2 /*[B*H*M, C]*/, int B, int N, int H, int C, int M,
                      float* out_x /*[B,N,H*C]*/, haet_stream_t stream);
+
+/* Whether haet_slice_fwd / haet_deslice_fwd run (B, N, H, C, M) on the split-bf16 matrix-core kernels (C = 32 with even
+ * H <= 16, C = 64 with H * M / 32 <= 8; M in {32, 64, 128}) rather than on the generic vector-ALU ones.  The host side
+ * uses it to run dim_head 16 -- the reference's PDE-benchmark width, n_hidden 128 / 8 heads -- as dim_head 32 with 16
+ * zero channels per head (x_lin padded, W_s / w_t zero-padded: exact), haet_amd/PhysicsAttention/_base.py.        */
+int haet_slice_mfma_supported(int B, int N, int H, int C, int M);
 
 /* ------------------------------------------------------------------ fused operand format
  * The C = 32 fast path of the module keeps x_lin in the streaming passes' own operand format

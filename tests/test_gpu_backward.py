@@ -372,3 +372,57 @@ def test_erwin_backward_kernel_on_128_token_clouds_of_16_channels(B, train, hip_
         diff = float((by_param[id(p)] - g_ref[n]).norm())
         err = diff / max(float(g_ref[n].norm()), 1e-4 * scale)
         assert err < 5e-4 or diff < 2e-5 * scale, (n, err, diff / scale)
+
+
+@pytest.mark.parametrize("bwd_padded", [False, True])
+@pytest.mark.parametrize("kind,M", [("irregular", 32), ("irregular", 64), ("irregular", 128), ("structured2d", 64)])
+def test_dim_head_16_runs_padded_on_the_matrix_core_passes(kind, M, bwd_padded, hip_device, monkeypatch):
+    """dim_head 16 (the reference's PDE-benchmark width: n_hidden 128 / 8 heads) runs the slice / de-slice passes of both
+    directions at 32 channels per head with 16 zero channels (PhysicsAttentionBase.head_pad_applies).  Forward output,
+    input gradient and every parameter gradient against (a) the same module on the vector-ALU kernels
+    (HAET_NO_HEAD_PAD=1) and (b) torch autograd through the stock-torch restatement of the forward."""
+    from haet_amd import _autograd
+    from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh, Physics_Attention_Structured_Mesh_2D
+
+    torch.manual_seed(M)
+    if kind == "irregular":
+        mod, N = Physics_Attention_Irregular_Mesh(dim=128, heads=8, dim_head=16, slice_num=M, rotate=45), 2077
+    else:
+        mod, N = Physics_Attention_Structured_Mesh_2D(dim=128, heads=8, dim_head=16, slice_num=M, H=37, W=23, rotate=45), 37 * 23
+    with torch.no_grad():
+        for p in mod.erwin.parameters():
+            if p.dim() >= 2:
+                p.mul_(3.0)
+    mod = mod.to(hip_device).eval()
+    assert mod.head_pad_applies(2, N)
+    mod.HEAD_PAD_BWD_ROWS = 0 if bwd_padded else 10 ** 9  # (the backward padded too / on the vector-ALU kernels)
+    x = torch.randn(2, N, 128, device=hip_device)
+    gout = torch.randn(2, N, 128, device=hip_device)
+
+    def run(fn):
+        mod.zero_grad(set_to_none=True)
+        xr = x.clone().requires_grad_(True)
+        y = fn(xr)
+        (y * gout).sum().backward()
+        return y.detach(), xr.grad.clone(), {n: (None if p.grad is None else p.grad.clone()) for n, p in mod.named_parameters()}
+
+    with torch.no_grad():
+        y_inf = mod(x)  # the inference path (_forward_hip), padded
+    y_pad, gx_pad, gp_pad = run(mod)
+    monkeypatch.setenv("HAET_NO_HEAD_PAD", "1")
+    assert not mod.head_pad_applies(2, N)
+    with torch.no_grad():
+        y_inf_valu = mod(x)
+    y_valu, gx_valu, gp_valu = run(mod)
+    monkeypatch.delenv("HAET_NO_HEAD_PAD")
+    y_ref, gx_ref, gp_ref = run(lambda t: _autograd.attention_forward(mod, t))
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    assert rel(y_inf, y_ref) < 2e-5 and rel(y_pad, y_ref) < 2e-5 and rel(y_inf, y_inf_valu) < 2e-5
+    assert rel(gx_pad, gx_ref) < 1e-3 and rel(gx_pad, gx_valu) < 1e-3
+    scale = max(float(g.norm()) for g in gp_ref.values() if g is not None)
+    for name, g_ref in gp_ref.items():
+        if g_ref is None:
+            continue
+        assert gp_pad[name] is not None, name
+        diff = float((gp_pad[name] - g_ref).norm())
+        assert diff / max(float(g_ref.norm()), 1e-4 * scale) < 2e-3 or diff < 2e-5 * scale, (name, diff / scale)
