@@ -259,8 +259,8 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
 
     # -- dim_head 16 on the matrix-core passes ---------------------------------------------------------------------
     HEAD_PAD = 32
-    HEAD_PAD_BWD_ROWS = 65536  # B * N from which the backward runs padded too (below it the split-bf16 backward kernels'
-    #                            fixed cost and the extra copies eat the gain: 226 vs 255 us at 45k points, 383 vs 1005 at 200k)
+    HEAD_PAD_BWD_ROWS = 4096  # B * N from which the backward runs padded too (45k points, M = 64: 43 + 110 us against the
+    #                           vector-ALU kernels' 97 + 253; below a few thousand rows everything is launch latency)
 
     def head_pad_applies(self, B: int, N: int) -> bool:
         """dim_head 16 (n_hidden 128 / 8 heads: six of the reference's seven PDE scripts) has no matrix-core slice /

@@ -178,8 +178,8 @@ class PhysicsAttentionFunction(torch.autograd.Function):
             x_lin = mod.project(x).float().contiguous()                  # [B, N, H*C] fp32, kept for backward
             # dim_head 16: the passes of both directions run at 32 channels per head, the upper 16 zero
             # (PhysicsAttentionBase.head_pad_applies); the PADDED x_lin is what the backward keeps
-            # -- and, where the cloud is large enough for the split-bf16 backward kernels' fixed cost to pay
-            # (HEAD_PAD_BWD_ROWS; tools/head_pad_probe.py), of the backward: then the PADDED x_lin is what is kept
+            # -- and, from HEAD_PAD_BWD_ROWS rows on (tools/head_pad_probe.py), of the backward: then the PADDED x_lin is
+            # what is kept
             fwd_padded = mod.head_pad_applies(B, N)
             ctx.padded = fwd_padded and B * N >= mod.HEAD_PAD_BWD_ROWS
             Cr, x_real = C, x_lin

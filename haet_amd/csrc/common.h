@@ -33,10 +33,22 @@ inline hipStream_t as_stream(haet_stream_t s) { return reinterpret_cast<hipStrea
 // ~256 chunks at large N, so that the per-workgroup partial records stay small next to the stream.  ONE definition:
 // haet_slice_bwd_num_parts sizes the caller's `parts` buffer from it and all three kernel families index that buffer
 // with it.
-inline int slice_bwd_pick_chunk(int N) {
+// `family`: the kernel family that will run (0 = vector ALUs, 1 = f32 matrix cores, 2 = split-bf16 matrix cores:
+// slice_bwd.hip bwd_family) -- the split-bf16 kernels pay a large fixed cost per workgroup (the constant fragments of
+// its head, its partial record: pass 2 at 45k points x 8 heads took 228 us with 256-point chunks, ONE tile per wave,
+// 84 us with 2048-point chunks; tools/head_pad_probe.py), the vector-ALU kernels want many short chunks (271 -> 506 us).
+enum { kBwdValu = 0, kBwdF32 = 1, kBwdX3 = 2 };
+inline int slice_bwd_pick_chunk(int N, int family) {
+    static const int forced = [] {
+        const char* e = getenv("HAET_BWD_CHUNK");  // tuning: a fixed chunk (multiple of 256) for every family
+        const int v = e ? atoi(e) : 0;
+        return v >= 256 ? (v / 256) * 256 : 0;
+    }();
+    if (forced) return forced;
     int c = (N + 255) / 256;
     c = ((c + 255) / 256) * 256;
-    return c < 256 ? 256 : c;
+    const int least = family == kBwdX3 ? 2048 : 256;
+    return c < least ? least : c;
 }
 
 // "1"-valued environment switch, read per call (the tests flip them between calls)

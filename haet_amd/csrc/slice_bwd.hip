@@ -328,6 +328,8 @@ static bool use_bwd_mfma(int C, int M) {  // HAET_FORCE_VALU=1 routes every shap
 static bool use_bwd_x3(int C, int M) {
     return use_bwd_mfma(C, M) && !env_flag("HAET_FORCE_F32_MFMA") && !env_flag("HAET_BWD_F32") && slice_bwd_x3_ok(C, M);
 }
+// the family the two entry points dispatch (C, M) to -- what haet_slice_bwd_num_parts sizes the caller's buffers for
+static int bwd_family(int C, int M) { return use_bwd_x3(C, M) ? kBwdX3 : use_bwd_mfma(C, M) ? kBwdF32 : kBwdValu; }
 
 template <int C, int NG>
 static int launch_tokens(dim3 grid, hipStream_t st, const float* x, const float* Ws, const float* bs,
@@ -378,7 +380,7 @@ using namespace haet;
 
 extern "C" int haet_slice_bwd_num_parts(int B, int N, int H, int C, int M) {
     if (slice_shape_ok(B, N, H, C, M) != HAET_OK) return HAET_E_ARG;
-    const int chunk = slice_bwd_pick_chunk(N);
+    const int chunk = slice_bwd_pick_chunk(N, bwd_family(C, M));  // (the same predicates as the two entry points below)
     return (N + chunk - 1) / chunk;
 }
 
@@ -398,7 +400,7 @@ extern "C" int haet_deslice_bwd_tokens(const float* x_lin, const float* Ws, cons
     if (use_bwd_mfma(C, M))
         return slice_bwd_mfma(0, x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, g_out, nullptr, nullptr,
                               nullptr, B, N, H, C, M, nullptr, parts, as_stream(stream));
-    const int chunk = slice_bwd_pick_chunk(N);
+    const int chunk = slice_bwd_pick_chunk(N, kBwdValu);
     dim3 grid((N + chunk - 1) / chunk, B * H);
     HAET_BWD_DISPATCH(launch_tokens, grid, as_stream(stream), x_lin, Ws, bs, wt, bt, base_temp, c0, col_max,
                       col_sum, g_out, N, H, M, chunk, parts);
@@ -419,7 +421,7 @@ extern "C" int haet_slice_bwd_points(const float* x_lin, const float* Ws, const 
     if (use_bwd_mfma(C, M))
         return slice_bwd_mfma(1, x_lin, Ws, bs, wt, bt, base_temp, c0, col_max, col_sum, g_out, S2, dS, A, B, N, H, C, M,
                               dx_lin, param_parts, as_stream(stream));
-    const int chunk = slice_bwd_pick_chunk(N);
+    const int chunk = slice_bwd_pick_chunk(N, kBwdValu);
     dim3 grid((N + chunk - 1) / chunk, B * H);
     HAET_BWD_DISPATCH(launch_points, grid, as_stream(stream), x_lin, Ws, bs, wt, bt, base_temp, c0, col_max,
                       col_sum, g_out, S2, dS, A, N, H, M, chunk, dx_lin, param_parts);

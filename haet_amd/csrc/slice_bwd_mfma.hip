@@ -376,7 +376,7 @@ int slice_bwd_mfma(int mode, const float* x, const float* Ws, const float* bs, c
                    float base_temp, float c0, const float* cm, const float* cs, const float* go, const float* S2,
                    const float* dS, const float* A, int B, int N, int H, int C, int M, float* dx, float* parts,
                    hipStream_t st) {
-    const int chunk = slice_bwd_pick_chunk(N);
+    const int chunk = slice_bwd_pick_chunk(N, kBwdF32);
     dim3 grid((N + chunk - 1) / chunk, B * H);
 #define HAET_BWD_MFMA(CB, MB, NW)                                                                                     \
     return mode ? launch<CB, MB, NW, 1>(grid, st, x, Ws, bs, wt, bt, base_temp, c0, cm, cs, go, S2, dS, A, N, H, chunk, \
