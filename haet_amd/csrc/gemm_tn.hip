@@ -37,6 +37,12 @@ __device__ __forceinline__ void tn_split8(const float (&v)[8], u32x4& hi, u32x4&
 constexpr int kRowsTile = 32;
 
 int wgrad_chunk(int N) {  // rows per workgroup: ~256 workgroups, whole 32-row tiles
+    static const int forced = [] {
+        const char* e = getenv("HAET_WGRAD_CHUNK");  // tuning: fixed rows per workgroup
+        const int v = e ? atoi(e) : 0;
+        return v >= kRowsTile ? (v / kRowsTile) * kRowsTile : 0;
+    }();
+    if (forced) return forced;
     int c = (N + 255) / 256;
     c = ((c + kRowsTile - 1) / kRowsTile) * kRowsTile;
     return c < kRowsTile ? kRowsTile : c;
