@@ -372,7 +372,9 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
             res_src = x
         if pre_norm is not None and not (x.is_cuda and not torch.is_grad_enabled() and not self.training
                                          and self.fuses_pre_norm(x, pre_norm)):
-            x, pre_norm = pre_norm(x), None
+            from .. import _fast  # (the HIP LayerNorm where it applies: ~10 us against torch's ~45 at 45k x 128)
+
+            x, pre_norm = (_fast.layer_norm(pre_norm, x) if x.is_cuda and x.dtype == torch.float32 else pre_norm(x)), None
         if not x.is_cuda:
             raise HaetError("Physics_Attention_* (haet_amd) runs on a ROCm device only; move the module "
                             "and its input with .cuda() -- there is no CPU fallback")
@@ -543,7 +545,9 @@ class PhysicsAttentionBase(_compile.OpaqueForwardMixin, nn.Module):
         with ev("project"):
             xs = self.project_split(x, sp, pre_norm)                     # fused operand format, or None
             if xs is None and pre_norm is not None:
-                x = pre_norm(x)
+                from .. import _fast
+
+                x = _fast.layer_norm(pre_norm, x) if x.dtype == torch.float32 else pre_norm(x)
             x_lin = None if xs is not None else self.project(x).float().contiguous()  # [B, N, H*C]
             padded = xs is None and self.head_pad_applies(B, N)
             x_real = x_lin
