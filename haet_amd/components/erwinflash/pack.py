@@ -123,6 +123,7 @@ def _fill_resample(dst, mod, blob, train):
 
 
 def pack_erwin(erwin):
+    """The direct packer: the layout's definition and the tests' reference -- the modules pack through ErwinPackPlan below."""
     n_levels = len(erwin.encoder) + 1
     if n_levels > MAX_LEVELS:
         raise HaetError(f"Erwin with {n_levels} levels > {MAX_LEVELS}")
@@ -400,18 +401,18 @@ class ErwinPackPlan:
             _sym_resample(desc.unpool[lvl], layer.unpool, blob, src, train)
         self.desc, self.src = desc, src
         part, elem = blob.index16()
-        self.part, self.elem = part.to(self.device), elem.to(self.device)
-        self._index = None  # (n, index): resolved for a flat vector of n elements
+        self.part, self.elem = part.to(torch.int8), elem.to(torch.int32)  # (host copies: 5 B per 16-bit unit of the blob)
+        self._index = None  # (n, device index): resolved for a flat vector of n elements, 4 B per unit
         hdr = bytearray(bytes(desc)) + bytearray(HEADER_FLOATS * 4 - ctypes.sizeof(desc))
         self.hdr16 = torch.frombuffer(hdr, dtype=torch.int16).to(self.device)
 
     def index(self, n):
         """Indices into  [flat as int16 (2 n) | hi (n) | lo (n) | header]  for a flat vector of n elements."""
         if self._index is None or self._index[0] != n:
-            p, e = self.part, self.elem
+            p, e = self.part.to(torch.int32), self.elem
             body = torch.where(p < 2, 2 * e + p, p * n + e)  # (hi at 2 n + e, lo at 3 n + e)
-            hdr = 4 * n + torch.arange(self.hdr16.numel(), dtype=torch.int64, device=self.device)
-            self._index = (n, torch.cat([hdr, body]).to(torch.int32))
+            hdr = 4 * n + torch.arange(self.hdr16.numel(), dtype=torch.int32)
+            self._index = (n, torch.cat([hdr, body]).to(self.device))
         return self._index[1]
 
     def run(self, flat=None):
@@ -490,13 +491,13 @@ class ErwinF32PackPlan:
         hdr = bytearray(bytes(lay)) + bytearray(head * 4 - ctypes.sizeof(lay))
         self.hdr = torch.frombuffer(hdr, dtype=torch.float32).to(self.device)
         idx = torch.cat(parts)
-        self.body = torch.where(idx >= 0, idx, torch.zeros_like(idx)).to(self.device)  # (element 0 of flat = the zero)
+        self.body = torch.where(idx >= 0, idx, torch.zeros_like(idx)).to(torch.int32)  # (host copy; element 0 of flat = the zero)
         self._index = None
 
     def index(self, n):
         if self._index is None or self._index[0] != n:
-            hdr = n + torch.arange(self.hdr.numel(), dtype=torch.int64, device=self.device)
-            self._index = (n, torch.cat([hdr, self.body]).to(torch.int32))
+            hdr = n + torch.arange(self.hdr.numel(), dtype=torch.int32)
+            self._index = (n, torch.cat([hdr, self.body]).to(self.device))
         return self._index[1]
 
     def run(self, flat=None):
