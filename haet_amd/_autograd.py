@@ -176,10 +176,9 @@ class PhysicsAttentionFunction(torch.autograd.Function):
         ev = mod._stage
         with ev("project"):
             x_lin = mod.project(x).float().contiguous()                  # [B, N, H*C] fp32, kept for backward
-            # dim_head 16: the passes of both directions run at 32 channels per head, the upper 16 zero
-            # (PhysicsAttentionBase.head_pad_applies); the PADDED x_lin is what the backward keeps
-            # -- and, from HEAD_PAD_BWD_ROWS rows on (tools/head_pad_probe.py), of the backward: then the PADDED x_lin is
-            # what is kept
+            # dim_head 16: the forward's passes run at 32 channels per head, the upper 16 zero
+            # (PhysicsAttentionBase.head_pad_applies) -- and, from HEAD_PAD_BWD_ROWS rows on (tools/head_pad_probe.py),
+            # the backward's too: then the PADDED x_lin is what is kept for it
             fwd_padded = mod.head_pad_applies(B, N)
             ctx.padded = fwd_padded and B * N >= mod.HEAD_PAD_BWD_ROWS
             Cr, x_real = C, x_lin

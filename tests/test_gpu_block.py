@@ -341,3 +341,29 @@ def test_eval_blob_follows_running_statistics_updated_by_a_train_mode_launch(hip
     rel = lambda a, b: float((a - b).norm() / b.norm())
     assert rel(y1, y_ref) < 1e-6
     assert rel(y1, y0) > 1e-5  # (the statistics did change the output: the test would pass vacuously otherwise)
+
+
+def test_slice_parameter_scalars_of_all_live_modules_are_read_together(hip_device):
+    """The Ada-Temp bias is a scalar kernel argument (a device -> host read when the weights changed): the first module
+    that finds its parameters changed reads the scalars of every live module on its device in one copy
+    (_base._refresh_slice_params) -- once per optimizer step, not once per layer."""
+    from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh
+
+    mods = [Physics_Attention_Irregular_Mesh(64, heads=4, dim_head=16, slice_num=8).to(hip_device) for _ in range(3)]
+    with torch.no_grad():
+        for i, m in enumerate(mods):
+            m.ada_temp_linear.bias.fill_(0.1 * (i + 1))
+    sp0 = mods[0]._slice_params()
+    assert abs(sp0.bt - 0.1) < 1e-7
+    for i, m in enumerate(mods[1:], 2):  # filled by the first module's refresh, with their own values
+        assert m._slice_cache is not None and m._slice_cache[0] == m._slice_key() and abs(m._slice_cache[1].bt - 0.1 * i) < 1e-7
+    cached = mods[2]._slice_cache[1]
+    with torch.no_grad():
+        mods[1].ada_temp_linear.bias.add_(1.0)   # an "optimizer step" on one module
+    assert mods[2]._slice_params() is cached      # unchanged modules keep their cache
+    assert abs(mods[1]._slice_params().bt - 1.2) < 1e-6
+    import copy
+    clone = copy.deepcopy(mods[0])                # (never ran __init__: registers itself at its first refresh)
+    with torch.no_grad():
+        clone.ada_temp_linear.bias.fill_(0.7)
+    assert abs(clone._slice_params().bt - 0.7) < 1e-7 and abs(mods[0]._slice_params().bt - 0.1) < 1e-7

@@ -233,3 +233,4 @@ def test_structured_3d_model_defaults_follow_reference():
     from haet_amd.HAETransolver_Structured_Mesh_3D import Model
 
     assert Model(n_layers=1, n_hidden=64, n_head=4, H=4, W=4, D=4, slice_num=8).use_checkpoint is False
+
