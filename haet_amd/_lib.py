@@ -74,6 +74,7 @@ SIGNATURES = {
     "haet_abi_version": (c_int, []),
     "haet_last_error_string": (c_char_p, []),
     "haet_split_bf16": (c_int, [_P, c_size_t, _P, _P, _P]),
+    "haet_split_bf16_tiled": (c_int, [_P, c_int, c_int, _P, _P, _P]),
     "haet_linear_supported": (c_int, [c_int, c_int]),
     "haet_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
     "haet_slice_num_parts": (c_int, [c_int] * 5),
@@ -269,8 +270,8 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
             fn.restype, fn.argtypes = res, args
-        if lib.haet_abi_version() != 8:
-            raise HaetError(f"libhaet_hip.so ABI {lib.haet_abi_version()} != 8")
+        if lib.haet_abi_version() != 9:
+            raise HaetError(f"libhaet_hip.so ABI {lib.haet_abi_version()} != 9")
         _lib = lib
     return _lib
 

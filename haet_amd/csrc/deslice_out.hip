@@ -105,13 +105,17 @@ __global__ __launch_bounds__(512) void deslice_out_kernel(
     const int l15 = lane & 15, kg = lane >> 4;
     u32x4 wh[16], wl[16];
     {
+        // (from the tile-ordered copies behind the planes -- gemm_x3.hip split_bf16_tiled_kernel: piece (row, k-chunk
+        //  4 ks + kg) at [row / 16][chunk][row % 16], so a wave instruction reads ONE run of 1 KB, not 16 of 64 B)
 #pragma unroll
         for (int io = 0; io < 2; ++io) {
-            const size_t o = (size_t)(32 * wave + 16 * io + l15) * kDO + 8 * kg;
+            const size_t piece0 = (((size_t)(2 * wave + io) * (kDO / 8) + kg) << 4) + l15;
+            const unsigned short* th = Whi + (size_t)kDO * kDO + piece0 * 8;
+            const unsigned short* tl = Wlo + (size_t)kDO * kDO + piece0 * 8;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                wh[2 * ks + io] = *reinterpret_cast<const u32x4*>(Whi + o + 32 * ks);
-                wl[2 * ks + io] = *reinterpret_cast<const u32x4*>(Wlo + o + 32 * ks);
+                wh[2 * ks + io] = *reinterpret_cast<const u32x4*>(th + (size_t)ks * 4 * 16 * 8);
+                wl[2 * ks + io] = *reinterpret_cast<const u32x4*>(tl + (size_t)ks * 4 * 16 * 8);
             }
         }
     }

@@ -107,6 +107,35 @@ __global__ void split_bf16_kernel(const float* __restrict__ w, size_t n, unsigne
     }
 }
 
+// The same planes [O][K], each FOLLOWED by a tile-ordered copy of itself: 16-B pieces (8 consecutive k of one row) stored
+// [row / 16][k / 8][row % 16].  The kernels that keep W STATIONARY in registers (gemm_ws_kernel, deslice_out_kernel) fetch
+// one such piece per lane and k-step for 16 or 32 different rows per wave instruction: from the row-major plane that is
+// 16-32 separate 16-64-B runs per instruction (~11 B/cycle per CU: 256 KB per workgroup, the 16-23 us of fixed cost
+// tools/gemm_fixed_cost_probe.py measures), from this copy runs of 512 B - 1 KB.
+__global__ void split_bf16_tiled_kernel(const float* __restrict__ w, int O, int K, unsigned short* __restrict__ hi,
+                                        unsigned short* __restrict__ lo) {
+    const int kch = K >> 3;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // chunk (row o, k-chunk kc)
+    if (i >= (size_t)O * kch) return;
+    const int o = (int)(i / kch), kc = (int)(i - (size_t)o * kch);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(w + (size_t)o * K + 8 * kc);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(w + (size_t)o * K + 8 * kc + 4);
+    u32x4 h, l;
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = g_pack(v[2 * j], v[2 * j + 1]);
+        l[j] = g_pack(v[2 * j] - __uint_as_float(h[j] << 16), v[2 * j + 1] - __uint_as_float(h[j] & 0xffff0000u));
+    }
+    const size_t plane = (size_t)O * K;
+    const size_t rowmajor = (size_t)o * K + 8 * kc;
+    const size_t tiled = plane + ((((size_t)(o >> 4) * kch + kc) << 4) + (o & 15)) * 8;
+    *reinterpret_cast<u32x4*>(hi + rowmajor) = h;
+    *reinterpret_cast<u32x4*>(lo + rowmajor) = l;
+    *reinterpret_cast<u32x4*>(hi + tiled) = h;
+    *reinterpret_cast<u32x4*>(lo + tiled) = l;
+}
+
 // LDS by byte offset only (generic pointers to LDS turn into flat_* accesses, which wait for
 // the global prefetch too).
 extern __shared__ __attribute__((aligned(16))) char gsm[];
@@ -650,12 +679,18 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(
     if (my_tiles == 0) return;
 
     // stationary B fragments: k-step s (16 wide) -> k = 16 s + 8 hf .. + 8 of row `col` of W
+    // (from the TILE-ORDERED copy behind each plane -- split_bf16_tiled_kernel: piece (row, k-chunk 2 s + hf) at
+    //  [row / 16][chunk][row % 16]: a wave instruction reads two runs of 512 B instead of 32 pieces of 32 B)
     u32x4 wh[2 * NKT], wl[2 * NKT];
+    {
+        const size_t piece0 = (((size_t)(col >> 4) * (K / 8) + hf) << 4) + (col & 15);
+        const unsigned short* th = Whi + (size_t)O * K + piece0 * 8;
+        const unsigned short* tl = Wlo + (size_t)O * K + piece0 * 8;
 #pragma unroll
-    for (int s = 0; s < 2 * NKT; ++s) {
-        const size_t o = (size_t)col * K + 16 * s + 8 * hf;
-        wh[s] = *reinterpret_cast<const u32x4*>(Whi + o);
-        wl[s] = *reinterpret_cast<const u32x4*>(Wlo + o);
+        for (int s = 0; s < 2 * NKT; ++s) {
+            wh[s] = *reinterpret_cast<const u32x4*>(th + (size_t)s * 2 * 16 * 8);
+            wl[s] = *reinterpret_cast<const u32x4*>(tl + (size_t)s * 2 * 16 * 8);
+        }
     }
     const float bv = bias ? bias[col] : 0.f;
     f32x16 acc[2];
@@ -908,6 +943,15 @@ extern "C" int haet_split_bf16(const float* w, size_t n, uint16_t* hi, uint16_t*
     hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0,
                        as_stream(stream), w, n, hi, lo);
     return check_launch("split_bf16_kernel");
+}
+
+extern "C" int haet_split_bf16_tiled(const float* w, int O, int K, uint16_t* hi, uint16_t* lo, haet_stream_t stream) {
+    if (!w || !hi || !lo || O < 16 || K < 8 || O % 16 || K % 8)
+        return fail(HAET_E_ARG, "split_bf16_tiled: O=%d (multiple of 16) / K=%d (multiple of 8) unsupported or null pointer", O, K);
+    const size_t chunks = (size_t)O * (K / 8);
+    hipLaunchKernelGGL(split_bf16_tiled_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, as_stream(stream), w,
+                       O, K, hi, lo);
+    return check_launch("split_bf16_tiled_kernel");
 }
 
 #ifdef HAET_STAMPS

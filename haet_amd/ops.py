@@ -368,9 +368,18 @@ class SplitLinear:
         lib = _lib.load()
         w = _f32(weight.detach(), "weight")
         self.O, self.K = w.shape
-        self.hi = torch.empty((self.O, self.K), dtype=torch.int16, device=w.device)
-        self.lo = torch.empty_like(self.hi)
-        check(lib.haet_split_bf16(_p(w), w.numel(), _p(self.hi), _p(self.lo), _stream()), "haet_split_bf16")
+        self.tiled = self.O % 16 == 0 and self.K % 8 == 0
+        if self.tiled:  # plane + its tile-ordered copy (what the Linear entry points expect: include/haet_hip.h, ABI 9)
+            self.hi_all = torch.empty(2 * self.O * self.K, dtype=torch.int16, device=w.device)
+            self.lo_all = torch.empty_like(self.hi_all)
+            check(lib.haet_split_bf16_tiled(_p(w), self.O, self.K, _p(self.hi_all), _p(self.lo_all), _stream()),
+                  "haet_split_bf16_tiled")
+            self.hi = self.hi_all[:self.O * self.K].view(self.O, self.K)  # (same base pointers: `_p(w.hi)` is the plane,
+            self.lo = self.lo_all[:self.O * self.K].view(self.O, self.K)  #  the copy follows it in memory)
+        else:  # (shapes no Linear kernel takes: planes only)
+            self.hi = torch.empty((self.O, self.K), dtype=torch.int16, device=w.device)
+            self.lo = torch.empty_like(self.hi)
+            check(lib.haet_split_bf16(_p(w), w.numel(), _p(self.hi), _p(self.lo), _stream()), "haet_split_bf16")
         self.bias = None if bias is None else _f32(bias.detach(), "bias")
 
 

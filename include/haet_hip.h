@@ -34,10 +34,11 @@
 extern "C" {
 #endif
 
-#define HAET_ABI_VERSION 8  /* 2: + haet_tokens_tree_build, haet_project_split_fwd, haet_*_fwd_split; 4: train-mode
+#define HAET_ABI_VERSION 9  /* 2: + haet_tokens_tree_build, haet_project_split_fwd, haet_*_fwd_split; 4: train-mode
                              BatchNorm (haet_erwin_train), haet_token_stage_fwd; 6: haet_token_stage_fwd_frag (the
                              fragment kernel), haet_erwin_barrier_status, haet_set_deterministic; 7: tile-ordered weight copies in the
-                             Erwin blob, haet_conv_presplit / haet_conv_project_cells_*, haet_conv_project_det_fwd; 8: haet_slice_mfma_supported */
+                             Erwin blob, haet_conv_presplit / haet_conv_project_cells_*, haet_conv_project_det_fwd; 8: haet_slice_mfma_supported; 9: the W planes
+                             of the Linear entry points are followed by their tile-ordered copies (haet_split_bf16_tiled) */
 
 #define HAET_OK 0
 #define HAET_E_ARG (-1)      /* bad argument / unsupported shape */
@@ -69,6 +70,16 @@ int haet_get_deterministic(void);
  * ([O][K] each) once per weight version.  Supported when haet_linear_supported(K, O) != 0
  * (K % 32 == 0, O % 128 == 0); callers use a library GEMM otherwise.                    */
 int haet_split_bf16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, haet_stream_t stream);
+/* ABI 9 -- what every Linear entry point of this header expects behind `W_hi` / `W_lo` (haet_linear_*_fwd,
+ * haet_project_split_*fwd, haet_linear_swiglu_fwd, haet_deslice_out_fwd_split; the convolution entry points read the
+ * row-major planes only): buffers of 2 * O * K bf16 each -- the [O][K] plane as haet_split_bf16 writes it, then a
+ * TILE-ORDERED copy of the same values: 16-B pieces (8 consecutive k of one row) at
+ *     piece(row, k / 8) = ((row / 16) * (K / 8) + k / 8) * 16 + row % 16.
+ * The kernels that keep W stationary in registers fetch one piece per lane and k-step for 16 or 32 rows per wave
+ * instruction: 16-32 separate runs of the row-major plane, one or two runs of this copy (the per-launch fixed cost of those
+ * kernels, 16-23 us, was this fetch).  O % 16 == 0, K % 8 == 0.                                                   */
+int haet_split_bf16_tiled(const float* w /*[O][K]*/, int O, int K, uint16_t* hi /*[2*O*K]*/, uint16_t* lo /*[2*O*K]*/,
+                          haet_stream_t stream);
 int haet_linear_supported(int K, int O);
 int haet_linear_fwd(const float* x /*[Nrows,K]*/, const uint16_t* W_hi, const uint16_t* W_lo,
                     const float* bias /*[O] or NULL*/, int Nrows, int K, int O,

@@ -36,7 +36,7 @@ def test_binding_loads_and_reports_errors_without_gpu():
     from haet_amd import _lib
 
     lib = _lib.load()
-    assert lib.haet_abi_version() == 8
+    assert lib.haet_abi_version() == 9
     # argument validation happens before any HIP call, so it is testable on CPU
     assert lib.haet_slice_num_parts(1, 1000, 8, 48, 64) < 0  # dim_head 48 unsupported
     assert b"dim_head" in lib.haet_last_error_string()

@@ -367,3 +367,21 @@ def test_slice_parameter_scalars_of_all_live_modules_are_read_together(hip_devic
     with torch.no_grad():
         clone.ada_temp_linear.bias.fill_(0.7)
     assert abs(clone._slice_params().bt - 0.7) < 1e-7 and abs(mods[0]._slice_params().bt - 0.1) < 1e-7
+
+
+@pytest.mark.parametrize("O,K", [(256, 256), (128, 96), (512, 128), (48, 40)])
+def test_split_linear_planes_carry_their_tile_ordered_copy(O, K, hip_device):
+    """haet_split_bf16_tiled (ABI 9): behind each [O][K] bf16 plane its tile-ordered copy -- 16-B pieces (8 consecutive k of
+    one row) at ((row / 16) * (K / 8) + k / 8) * 16 + row % 16 -- which the W-stationary kernels fetch; hi = RNE(w),
+    hi + lo = w to 2^-16."""
+    from haet_amd import ops
+
+    torch.manual_seed(O + K)
+    W = torch.randn(O, K)
+    w = ops.SplitLinear(W.to(hip_device), None)
+    assert w.tiled and w.hi.data_ptr() == w.hi_all.data_ptr() and w.hi_all.numel() == 2 * O * K
+    for plane_all, want in ((w.hi_all, W.bfloat16()), (w.lo_all, (W - W.bfloat16().float()).bfloat16())):
+        plane = plane_all[:O * K].view(torch.bfloat16).view(O, K).cpu()
+        assert torch.equal(plane, want)
+        tiled = plane_all[O * K:].view(torch.bfloat16).view(O // 16, K // 8, 16, 8).cpu()
+        assert torch.equal(tiled.permute(0, 2, 1, 3).reshape(O, K), plane)
