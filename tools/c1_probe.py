@@ -10,6 +10,11 @@ import torch
 
 import haet_amd
 
+import gc  # (a full collection of the import-time heap is a ~75 ms stall inside a timed loop: tools/stall_probe.py)
+
+gc.collect()
+gc.freeze()
+
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = haet_amd.HAETransolver_Structured_Mesh_2D(space_dim=2, fun_dim=1, n_layers=1, slice_num=8, H=64, W=64).eval().to(dev)

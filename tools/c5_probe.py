@@ -10,6 +10,11 @@ import torch
 
 from haet_amd.PhysicsAttention import Physics_Attention_Structured_Mesh_3D
 
+import gc  # (a full collection of the import-time heap is a ~75 ms stall inside a timed loop: tools/stall_probe.py)
+
+gc.collect()
+gc.freeze()
+
 dev = torch.device("cuda", 0)
 planes = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 torch.manual_seed(0)

@@ -14,6 +14,11 @@ import haet_amd
 from haet_amd import _fast
 
 
+import gc  # (a full collection of the import-time heap is a ~75 ms stall inside a timed loop: tools/stall_probe.py)
+
+gc.collect()
+gc.freeze()
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=1_000_000)

@@ -5,6 +5,11 @@ import torch
 from haet_amd import pc_ops
 from haet_amd.components.erwinflash import ErwinTransformer
 
+import gc  # (a full collection of the import-time heap is a ~75 ms stall inside a timed loop: tools/stall_probe.py)
+
+gc.collect()
+gc.freeze()
+
 ap = argparse.ArgumentParser()
 ap.add_argument("--points", type=int, default=32186)
 ap.add_argument("--radius", type=float, default=0.04)

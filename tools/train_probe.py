@@ -16,6 +16,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+import gc  # (a full collection of the import-time heap is a ~75 ms stall inside a timed loop: tools/stall_probe.py)
+
+gc.collect()
+gc.freeze()
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=1_000_000)
