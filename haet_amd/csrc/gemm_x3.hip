@@ -195,7 +195,10 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
 
     // loader geometry: x tile = BM rows x 8 chunks(16 B) -> XPT chunks per thread (rows +64 apart)
     const int xrow0 = tid >> 3, xq = tid & 7;
-    const int wrow0 = tid >> 2, wch = tid & 3; // W chunk i: row + 128 i
+    // W chunk i: row + 128 i.  Split-bf16 (PREC 0): from the TILE-ORDERED copy behind each plane (split_bf16_tiled_kernel:
+    // pieces at [row / 16][k / 8][row % 16]) with lane -> (row % 16, chunk), so that a wave's 64 pieces of a k-tile are ONE run
+    // of 1 KB instead of 16 runs of 64 B; the fp16 plane of PREC 1 has no such copy: rows of 64 B as before
+    const int wrow0 = PREC == 0 ? 16 * wave + (lane & 15) : tid >> 2, wch = PREC == 0 ? lane >> 4 : tid & 3;
     const int x_st0 = XIMG + (xrow0 >> 5) * (2 * GIMG) + g_off(xrow0 & 31, xq >> 1) + ((xq & 1) << 3);
     int w_st[WPT];
 #pragma unroll
@@ -307,7 +310,9 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(
             kk = ((kk >= nkt ? kk - nkt : kk) + kt0) * GBK;
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
-                const size_t o = (size_t)(col0 + wrow0 + 128 * i) * K + kk + 8 * wch;
+                const size_t row = (size_t)(col0 + wrow0 + 128 * i);
+                const size_t o = PREC == 0 ? (size_t)O * K + ((((row >> 4) * (size_t)(K >> 3) + (kk >> 3) + wch) << 4) + (row & 15)) * 8
+                                           : row * K + kk + 8 * wch;
                 d[2 * i] = *reinterpret_cast<const u32x4*>(Whi + o);
                 if (PREC == 0) d[2 * i + 1] = *reinterpret_cast<const u32x4*>(Wlo + o);  // (fp16x2: one weight plane)
             }
