@@ -229,6 +229,12 @@ ATTN_CASES = [
     # padded tile, the MFMA ball attention on a partial tile)
     ("irr_memchk_amp", "irregular", dict(dim=256, heads=8, dim_head=32, slice_num=32, rotate=45), 800, "amp", False),
     ("irr_memchk_b2_amp", "irregular", dict(dim=256, heads=8, dim_head=32, slice_num=32, rotate=45), 300, "amp", False),
+    # round 4 -- the widths of the reference's PDE-benchmark scripts (benchmarks/04-PDE-Solving-StandardBenchmark/scripts/*.sh:
+    # n_hidden 128, 8 heads -> dim_head 16; slice_num 64 / 128): dim_head 16 with >= 32 slices runs the split-bf16 passes padded
+    # to 32 channels per head, 128-token x 16-channel clouds the wave-cooperative tree builder
+    ("irr_pde_amp", "irregular", dict(dim=128, heads=8, dim_head=16, slice_num=64, rotate=45), 1100, "amp", False),
+    ("irr_pde_m128_amp", "irregular", dict(dim=128, heads=8, dim_head=16, slice_num=128, rotate=45), 700, "amp", False),
+    ("s2d_pde_amp", "structured2d", dict(dim=128, heads=8, dim_head=16, slice_num=64, H=24, W=20, rotate=45), (24, 20), "amp", False),
 ]
 
 # BASELINE configs C1 and C5 at their REAL widths (dim 256 -> 8 heads x 32: inside the HIP convolution's envelope),
