@@ -329,7 +329,8 @@ def gen_big_fixtures(models, tree_store, only=None):
 
 
 GRAD_CASES = ["irr_small_amp", "irr_small_amp_train", "irr_b2_amp", "irr_b2_amp_train", "irr_norot_amp",
-              "s2d_c1like_amp", "s3d_c5like_amp", "irr_stride1_amp", "irr_stride1_amp_train", "irr_nonpow2_amp"]
+              "s2d_c1like_amp", "s3d_c5like_amp", "irr_stride1_amp", "irr_stride1_amp_train", "irr_nonpow2_amp",
+              "irr_pde_amp", "irr_pde_m128_amp", "s2d_pde_amp"]  # (round 4: the PDE scripts' width -- the padded dim_head-16 backward)
 
 
 def gen_grad_fixtures(models, only=None):

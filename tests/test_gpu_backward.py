@@ -270,6 +270,9 @@ def test_module_gradients_vs_reference_fixture(name, hip_device):
     mod = CTOR[meta["kind"]](**meta["kw"])
     mod.load_state_dict(sd)
     mod = mod.to(hip_device).train(meta["train"])
+    if "pde" in name:  # (dim_head 16: the backward padded to 32 channels per head too, whatever the cloud's size)
+        mod.HEAD_PAD_BWD_ROWS = 0
+        assert mod.head_pad_applies(x.shape[0], x.shape[1])
     xr = x.to(hip_device).requires_grad_(True)
     out = mod(xr)
     assert O.rel_l2(out.detach().cpu(), exp["out"]) < 1e-4
