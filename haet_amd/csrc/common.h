@@ -52,6 +52,23 @@ inline int slice_bwd_pick_chunk(int N, int family) {
     return c < least ? least : c;
 }
 
+// Zero `bytes` (a multiple of 4) at `p` (4-byte aligned) with a KERNEL: hipMemsetAsync captured into a HIP graph
+// (torch.compile mode="reduce-overhead") did not reliably re-run ahead of its consumer on replay -- the split-k convolution,
+// which adds into a zeroed output, returned garbage from the second replay on (tools/graph_replay_check.py).
+template <int kDummy = 0>
+__global__ void zero_words_kernel(unsigned* __restrict__ p, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0u;
+}
+inline hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
+    const size_t n = bytes / 4;
+    if (n == 0) return hipSuccess;
+    const size_t want = (n + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
+    hipLaunchKernelGGL(zero_words_kernel<0>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<unsigned*>(p), n);
+    return hipGetLastError();
+}
+
 // "1"-valued environment switch, read per call (the tests flip them between calls)
 inline bool env_flag(const char* name) {
     const char* e = getenv(name);

@@ -1245,10 +1245,10 @@ static int erwin_train_args(const haet_erwin_desc* desc, const haet_erwin_train*
     t.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(train->workspace) + 64);
     t.cmax = cmax;
     t.on = 1;
-    // the barrier COUNTER is zeroed before EVERY launch (a memset node under graph capture); the time-out word next
+    // the barrier COUNTER is zeroed before EVERY launch (by a kernel: a kernel node under graph capture); the time-out word next
     // to it is sticky: set by a barrier that gave up, cleared only by the host that reads it (haet_erwin_barrier_status)
-    hipError_t e = hipMemsetAsync(train->workspace, 0, 4, stream);
-    if (e != hipSuccess) return fail(HAET_E_LAUNCH, "erwin: hipMemsetAsync: %s", hipGetErrorString(e));
+    hipError_t e = zero_async(train->workspace, 4, stream);  // (a kernel, not hipMemsetAsync: common.h)
+    if (e != hipSuccess) return fail(HAET_E_LAUNCH, "erwin: zeroing the barrier counter: %s", hipGetErrorString(e));
     *out = t;
     return HAET_OK;
 }

@@ -1345,8 +1345,8 @@ extern "C" int haet_erwin_bwd(const float* g_out, const float* tape, const float
         attr_dev.store(bytes, std::memory_order_release);
     }
     if (desc->bn_train) {
-        hipError_t e = hipMemsetAsync(workspace, 0, 4, as_stream(stream));  // the counter; the time-out word stays (sticky)
-        if (e != hipSuccess) return fail(HAET_E_LAUNCH, "erwin_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+        hipError_t e = zero_async(workspace, 4, as_stream(stream));  // the counter; the time-out word stays (sticky)
+        if (e != hipSuccess) return fail(HAET_E_LAUNCH, "erwin_bwd: zeroing the barrier counter: %s", hipGetErrorString(e));
     }
     hipLaunchKernelGGL(erwin_bwd_kernel, dim3(n_clouds), dim3(kBT), bytes, as_stream(stream), a, T);
     return check_launch("erwin_bwd_kernel");

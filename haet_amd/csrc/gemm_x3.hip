@@ -1162,8 +1162,8 @@ static int conv_project_impl(const float* x, const uint16_t* W_hi, const uint16_
         int Z = ncb;
         while (Z > 1 && tiles * ny * Z > 512) Z /= 2;
         if (Z > 1 && ncb % Z == 0) {
-            if (hipMemsetAsync(out, 0, (size_t)Nrows * O * sizeof(float), as_stream(stream)) != hipSuccess)
-                return fail(HAET_E_LAUNCH, "conv_project_fwd: memset failed");
+            if (zero_async(out, (size_t)Nrows * O * sizeof(float), as_stream(stream)) != hipSuccess)  // (a kernel: common.h)
+                return fail(HAET_E_LAUNCH, "conv_project_fwd: zeroing the output failed");
             auto launch_z = [&](auto kern) {
                 if (lds > 64 * 1024)
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -385,3 +385,23 @@ def test_split_linear_planes_carry_their_tile_ordered_copy(O, K, hip_device):
         assert torch.equal(plane, want)
         tiled = plane_all[O * K:].view(torch.bfloat16).view(O // 16, K // 8, 16, 8).cpu()
         assert torch.equal(tiled.permute(0, 2, 1, 3).reshape(O, K), plane)
+
+
+def test_structured_small_grid_model_replays_as_a_hip_graph(hip_device):
+    """exp_plas.py:177 compiles its model with mode="reduce-overhead": the forward replays as one captured HIP graph.  The
+    small-grid convolution splits its k-tiles over workgroups that ADD into a zeroed output; zeroed by hipMemsetAsync, that
+    output came back as garbage from the second replay on (two layers, n_hidden 128: `tools/graph_replay_check.py`) -- the
+    zeroing is a kernel now (csrc/common.h zero_async).  Five calls: eager warm-up, capture, three replays."""
+    import haet_amd
+
+    torch.manual_seed(0)
+    model = haet_amd.HAETransolver_Structured_Mesh_2D(space_dim=2, n_layers=2, n_hidden=128, n_head=8, fun_dim=0, out_dim=1,
+                                                      slice_num=64, H=61, W=31).eval().to(hip_device)
+    x = torch.rand(2, 61 * 31, 2, device=hip_device)
+    with torch.no_grad():
+        ref = model(x, None)
+        compiled = torch.compile(model, mode="reduce-overhead")
+        outs = [compiled(x, None).clone() for _ in range(5)]
+    for i, o in enumerate(outs):
+        assert bool(torch.isfinite(o).all()), i
+        assert O.rel_l2(o.cpu(), ref.cpu()) < 1e-4, i  # (float atomics: the summation order varies, ~1e-5)
