@@ -187,6 +187,23 @@ def reference_grid_distances(x, ref, dims):
     """Distances from every point to a ref^dims reference grid on [0,1]^dims
     (get_grid, HAETransolver_Irregular_Mesh.py:297-336); on x's device instead of the
     reference's hard-coded .cuda()."""
-    axes = [torch.tensor(np.linspace(0, 1, ref), dtype=torch.float, device=x.device)] * dims
-    grid = torch.stack(torch.meshgrid(*axes, indexing="ij"), dim=-1).reshape(1, ref ** dims, dims)
+    grid = _reference_grid(ref, dims, x.device) if not torch.compiler.is_compiling() else _make_reference_grid(ref, dims, x.device)
     return torch.sqrt(torch.sum((x[:, :, None, :] - grid[:, None, :, :]) ** 2, dim=-1)).contiguous()
+
+
+def _make_reference_grid(ref, dims, device):
+    axes = [torch.tensor(np.linspace(0, 1, ref), dtype=torch.float, device=device)] * dims
+    return torch.stack(torch.meshgrid(*axes, indexing="ij"), dim=-1).reshape(1, ref ** dims, dims)
+
+
+_GRIDS = {}
+
+
+def _reference_grid(ref, dims, device):
+    """The constant grid, built once per (ref, dims, device): rebuilding it was a host -> device copy and five tiny launches
+    per forward of every `unified_pos` model (darcy, Navier-Stokes)."""
+    key = (int(ref), int(dims), str(device))
+    g = _GRIDS.get(key)
+    if g is None:
+        g = _GRIDS[key] = _make_reference_grid(ref, dims, device)
+    return g
