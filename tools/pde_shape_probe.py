@@ -13,6 +13,10 @@ from haet_amd import HAETransolver_Irregular_Mesh
 from haet_amd.PhysicsAttention import Physics_Attention_Irregular_Mesh
 
 dev = torch.device("cuda", 0)
+import gc  # (a full collection of the import-time heap is a ~75 ms stall inside a timed loop: tools/stall_probe.py)
+
+gc.collect()
+gc.freeze()
 for N, M in [(972, 128), (11271, 64), (16641, 64)]:
     torch.manual_seed(0)
     model = HAETransolver_Irregular_Mesh(space_dim=2, fun_dim=0, n_hidden=128, n_layers=8, n_head=8, mlp_ratio=1, out_dim=1,
