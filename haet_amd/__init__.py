@@ -19,3 +19,20 @@ __all__ = [
     "HAETransolver_Structured_Mesh_2D",
     "HAETransolver_Structured_Mesh_3D",
 ]
+
+
+def _freeze_import_heap():
+    """Importing this package imports torch and, through haet_amd._compile, torch._dynamo with its symbolic-math stack:
+    ~10^6 long-lived objects that every FULL garbage collection walks again -- ~75 ms per collection on the GPU boxes
+    (tools/stall_probe.py), i.e. two or three training steps of the reference's PDE configurations or fifty 1M-point
+    forwards, at moments the caller does not choose.  gc.freeze() moves what is alive NOW (import-time objects) out of the
+    collector's reach; the collector stays on for everything created afterwards.  HAET_NO_GC_FREEZE=1 leaves it alone."""
+    import gc
+    import os
+
+    if not os.environ.get("HAET_NO_GC_FREEZE"):
+        gc.collect()
+        gc.freeze()
+
+
+_freeze_import_heap()
