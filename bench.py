@@ -199,6 +199,12 @@ def main():
                          "all_kernels_frac": {k: round(n_local * BYTES_PER_POINT[k](256) / (stage_ms[k] * 1e-3)
                                                        / 1e9 / HBM_PEAK_GBS, 4) for k in candidates}},
         }
+        if world == 1:
+            # the vendor peak AND a streaming-copy ceiling measured on this box (a 1 GB fp32 torch copy_:
+            # read + write), outside the timed region
+            ceil = copy_ceiling_gbs(dev)
+            res["roofline"]["copy_ceiling"] = round(ceil, 1)
+            res["roofline"]["frac_of_copy_ceiling"] = gbs / ceil
         if rehearsal:
             res["rehearsal"] = f"{world} ranks on {n_dev} GPU(s), records over gloo: functional run, not a measurement"
         if world == 1 and not args.no_cpu_baseline:
@@ -209,6 +215,21 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def copy_ceiling_gbs(dev, mb: int = 1024, reps: int = 10) -> float:
+    """GB/s of a device-to-device copy of `mb` MB (bytes read + bytes written over the time of `reps` copies)."""
+    a = torch.empty(mb * 2 ** 20 // 4, dtype=torch.float32, device=dev).normal_()
+    b_ = torch.empty_like(a)
+    for _ in range(3):
+        b_.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b_.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * a.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def sweep_main(args):
